@@ -1,0 +1,152 @@
+/*
+ * omc.h -- C ABI of libomc.so: MI355X (gfx950) American-option Monte-Carlo hot path.
+ *
+ * The reference (Levicoz/Options-model) is 100 % Python and has no FFI, plugin or operator
+ * interface; its boundary for this path is the Python call surface.  This header is the
+ * drop-in boundary underneath that surface: each entry point names the reference code it
+ * replaces (paths relative to the reference root).  Host bindings: ctypes, see
+ * options_model_amd/_ffi.py and INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int: 0 ok; <0 invalid argument (Python raises ValueError with
+ *     the reference's message); >0 a hipError_t (Python raises RuntimeError).
+ *     omc_last_error() returns a thread-local description of the last failure.
+ *   - no HIP call happens at load time; a context is created lazily per (process, device),
+ *     so the library is safe under the reference's `spawn`ed ProcessPoolExecutor workers
+ *     (options_model_2_ui.py:8-11).
+ *   - path matrices are float32 [n_steps+1][ld], row = time step, ld >= n_paths elements
+ *     (the reference's S[t, j] C-order layout, options_model_3/options_model_3.py:477).
+ *     Antithetic partner of column j is j + n_paths/2 (options_model_3.py:476).
+ *   - device pointers passed in are borrowed; the library frees only what omc_alloc returned.
+ *   - calls on one context are serialised by the caller; all entry points are synchronous
+ *     (return after the stream has drained) unless stated otherwise.
+ */
+#ifndef OMC_H
+#define OMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMC_ABI_VERSION 1
+
+typedef struct omc_ctx omc_ctx;
+
+/* semantics of the backward induction */
+enum {
+    OMC_SEM_REFERENCE = 0, /* per-step sticky flow: Options_model.py:108-157, options_model_2.py:278-313 */
+    OMC_SEM_TEXTBOOK = 1,  /* classic Longstaff-Schwartz, discounted to t=0                        */
+    OMC_SEM_TWO_PASS = 2   /* v3 flow: options_model_3/options_model_3.py:482-516 + :615-651        */
+};
+enum { OMC_MODEL_GBM = 0, OMC_MODEL_HESTON = 1 };
+enum { OMC_HESTON_REFERENCE_CLAMP = 0, OMC_HESTON_FULL_TRUNCATION = 1 };
+
+typedef struct {
+    int32_t model;         /* OMC_MODEL_*                                               */
+    int32_t is_put;        /* payoff: options_model_3.py:376-380                          */
+    int32_t semantics;     /* OMC_SEM_*                                                 */
+    int32_t antithetic;    /* 1 = reference layout (GBM only may pass 0)                */
+    int32_t heston_scheme; /* OMC_HESTON_*                                              */
+    int32_t n_steps;
+    int64_t n_paths;       /* LOCAL paths of this context (even when antithetic)        */
+    double S0, K, r, sigma, T;
+    double v0, kappa, theta, xi, rho; /* Heston only (dict keys of options_model_2_ui.py:74-80) */
+    uint64_t seed;         /* Philox key                                                */
+    uint64_t stream;       /* sub-stream id (low 32 bits used): one per pricing call    */
+    uint64_t pair_offset;  /* global index of this context's first pair (multi-GPU)     */
+} omc_params;
+
+typedef struct {
+    double price;          /* mean cash-flow (reference flows: valued at t = dt)   */
+    double sum, sumsq;     /* over the local paths                                        */
+    double std;            /* population std, as Options_model.py:154                     */
+    double zero_prob;      /* P(cash-flow == 0), Options_model.py:155                     */
+    int64_t n_paths, n_exercised, n_zero, sum_nitm;
+    double ms_paths, ms_lsm, ms_total; /* HIP-event times of this call on the context's stream */
+} omc_result;
+
+/* ---- library / context --------------------------------------------------------------- */
+int omc_abi_version(void);
+const char* omc_last_error(void);
+int omc_device_count(int* count);
+/* hip_stream == NULL: the context creates its own stream; else it borrows the caller's
+ * (e.g. torch.cuda.current_stream().cuda_stream) and never destroys it. */
+int omc_ctx_create(int device, void* hip_stream, omc_ctx** out);
+int omc_ctx_destroy(omc_ctx* ctx);
+int omc_sync(omc_ctx* ctx);
+int omc_alloc(omc_ctx* ctx, size_t bytes, void** dptr);
+int omc_free(omc_ctx* ctx, void* dptr);
+int omc_memcpy_h2d(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
+int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* tuning knobs: "gbm_vec" / "heston_vec" (pairs per thread: 1,2,4), "use_graph" (0/1) */
+int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
+
+/* ---- path generation ------------------------------------------------------------------- */
+/* replaces the inline GBM block options_model_3.py:473-480 (== Options_model.py:79-88,
+ * options_model_2.py:257-264) and the torch loops option_model_3_gpu.py:117-185 */
+int omc_gbm_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, int n_steps, double S0,
+                      double r, double sigma, double T, uint64_t seed, uint64_t stream,
+                      uint64_t pair_offset, int antithetic);
+/* replaces simulate_heston_paths_antithetic options_model_3.py:211-251
+ * (option_model_3_gpu.py:187-248); the variance never reaches memory */
+int omc_heston_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, int n_steps,
+                         double S0, double r, double T, double v0, double kappa, double theta,
+                         double xi, double rho, uint64_t seed, uint64_t stream,
+                         uint64_t pair_offset, int scheme);
+/* injected-normals parity mode: Zhalf is device float32 [n_steps][ldz], row t-1 drives step t
+ * (the exact consumption order of options_model_3.py:475-480 / :223-233) */
+int omc_gbm_paths_from_normals_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths,
+                                   int n_steps, double S0, double r, double sigma, double T,
+                                   const float* Zhalf, int64_t ldz, int antithetic);
+int omc_heston_paths_from_normals_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths,
+                                      int n_steps, double S0, double r, double T, double v0,
+                                      double kappa, double theta, double xi, double rho,
+                                      const float* Z1half, const float* Z2half, int64_t ldz,
+                                      int scheme);
+/* RNG taps for known-answer tests: in = n x {ctr[4], key[2]} (host), out = n x 4 (host) */
+int omc_philox4x32_10(omc_ctx* ctx, const uint32_t* in, uint32_t* out, int n);
+/* the normals the GBM generator consumes: Z device float32 [n_steps][ldz] */
+int omc_gbm_normals_f32(omc_ctx* ctx, float* Z, int64_t ldz, int64_t n_pairs, int n_steps,
+                        uint64_t seed, uint64_t stream, uint64_t pair_offset);
+
+/* ---- Longstaff-Schwartz backward induction (polynomial regressor) -------------------------- */
+/* replaces the backward loops Options_model.py:108-157 / options_model_2.py:278-313
+ * (semantics 0), options_model_3.py:482-651 (semantics 2), with the per-step MLP swapped for
+ * OLS on [1,u,u^2], u = S/K-1 (the reference accepts lsm_poly_degree and ignores it:
+ * Options_model.py:53, options_model_2.py:178-179).
+ * betas_out: optional host [n_steps+1][4] = b0,b1,b2,n_itm per step.
+ * sx_out / tex_out: optional host [n_paths] final exercise spot / step per path. */
+int omc_lsm_poly(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                 double r, double T, int is_put, int semantics, omc_result* res,
+                 double* betas_out, float* sx_out, int32_t* tex_out);
+/* decision replay with given per-step fits (host betas [n_steps+1][4], n<=0 skips the step) */
+int omc_lsm_apply_frozen(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps,
+                         double K, double r, double T, int is_put, const double* betas,
+                         omc_result* res, float* sx_out, int32_t* tex_out);
+
+/* multi-GPU: paths shard by antithetic pair, only regression moments and the final sums
+ * cross GPUs.  `hook(user, dptr, count)` must all-reduce (sum) `count` DEVICE doubles in place,
+ * ordered on the context's stream (RCCL via torch.distributed on the host side).  It is called
+ * ONCE with the whole [n_steps+1][8] moment table for the two-pass flow (decision-independent
+ * moments), and once per time step with 8 doubles for the per-step flows.  The returned
+ * omc_result carries LOCAL sums; the caller all-reduces {sum, sumsq, counts}. */
+typedef int (*omc_allreduce_fn)(void* user, double* dptr, int count);
+int omc_set_allreduce_hook(omc_ctx* ctx, omc_allreduce_fn fn, void* user);
+
+/* ---- fused pricing: paths -> LSM -> discounted mean ----------------------------------------- */
+/* replaces AdvancedOptionPricer.price_american_enhanced_lsm options_model_3.py:439-651 and
+ * price_american_option Options_model.py:44-157 end to end on one GPU.  S_keep: optional
+ * caller-owned device matrix [n_steps+1][ld] to receive the paths (NULL: internal workspace) */
+int omc_price_american(omc_ctx* ctx, const omc_params* p, omc_result* res, float* S_keep,
+                       int64_t ld);
+/* European discounted payoff from terminal values only (no path matrix): replaces
+ * price_european_streaming options_model_3.py:382-437; sums2 host {sum, sumsq} */
+int omc_price_european(omc_ctx* ctx, const omc_params* p, omc_result* res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMC_H */

@@ -1,0 +1,347 @@
+"""ctypes binding of libomc.so (include/omc.h).  No torch, no numpy compute: this module
+only marshals arguments.  If the HIP library is missing or there is no GPU the calls fail
+loudly -- there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _build
+
+ABI_VERSION = 1
+
+SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
+MODELS = {"gbm": 0, "heston": 1}
+HESTON_SCHEMES = {"reference": 0, "clamp": 0, "full_truncation": 1}
+
+
+class OmcError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("model", C.c_int32), ("is_put", C.c_int32), ("semantics", C.c_int32),
+                ("antithetic", C.c_int32), ("heston_scheme", C.c_int32), ("n_steps", C.c_int32),
+                ("n_paths", C.c_int64),
+                ("S0", C.c_double), ("K", C.c_double), ("r", C.c_double), ("sigma", C.c_double),
+                ("T", C.c_double),
+                ("v0", C.c_double), ("kappa", C.c_double), ("theta", C.c_double), ("xi", C.c_double),
+                ("rho", C.c_double),
+                ("seed", C.c_uint64), ("stream", C.c_uint64), ("pair_offset", C.c_uint64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("price", C.c_double), ("sum", C.c_double), ("sumsq", C.c_double),
+                ("std", C.c_double), ("zero_prob", C.c_double),
+                ("n_paths", C.c_int64), ("n_exercised", C.c_int64), ("n_zero", C.c_int64),
+                ("sum_nitm", C.c_int64),
+                ("ms_paths", C.c_double), ("ms_lsm", C.c_double), ("ms_total", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+# name -> (restype, argtypes); every symbol include/omc.h declares
+_P, _I, _I64, _U64, _D, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double, C.c_size_t
+SIGNATURES = {
+    "omc_abi_version": (C.c_int, []),
+    "omc_last_error": (C.c_char_p, []),
+    "omc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "omc_ctx_create": (C.c_int, [_I, _P, C.POINTER(_P)]),
+    "omc_ctx_destroy": (C.c_int, [_P]),
+    "omc_sync": (C.c_int, [_P]),
+    "omc_alloc": (C.c_int, [_P, _SZ, C.POINTER(_P)]),
+    "omc_free": (C.c_int, [_P, _P]),
+    "omc_memcpy_h2d": (C.c_int, [_P, _P, _P, _SZ]),
+    "omc_memcpy_d2h": (C.c_int, [_P, _P, _P, _SZ]),
+    "omc_set_option": (C.c_int, [_P, C.c_char_p, _I64]),
+    "omc_gbm_paths_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _D, _U64, _U64, _U64, _I]),
+    "omc_heston_paths_f32": (C.c_int, [_P, _P, _I64, _I64, _I] + [_D] * 8 + [_U64, _U64, _U64, _I]),
+    "omc_gbm_paths_from_normals_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _D, _P, _I64, _I]),
+    "omc_heston_paths_from_normals_f32": (C.c_int, [_P, _P, _I64, _I64, _I] + [_D] * 8 + [_P, _P, _I64, _I]),
+    "omc_philox4x32_10": (C.c_int, [_P, _P, _P, _I]),
+    "omc_gbm_normals_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _U64, _U64, _U64]),
+    "omc_lsm_poly": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, C.POINTER(Result), _P, _P, _P]),
+    "omc_lsm_apply_frozen": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _P, C.POINTER(Result), _P, _P]),
+    "omc_set_allreduce_hook": (C.c_int, [_P, ALLREDUCE_FN, _P]),
+    "omc_price_american": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result), _P, _I64]),
+    "omc_price_european": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result)]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(build_if_missing: bool = True):
+    """dlopen libomc.so (building it in-tree first if needed).  No HIP call happens here."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB
+        if not os.path.exists(path) or (build_if_missing and _build._stale()):
+            if not build_if_missing:
+                raise OmcError(f"{path} is missing: run `python -m options_model_amd._build`")
+            try:
+                path = _build.build()
+            except Exception as e:  # stale-but-present library is still usable on a box w/o hipcc
+                if not os.path.exists(_build.LIB):
+                    raise OmcError(f"libomc.so is missing and cannot be built: {e}") from e
+                path = _build.LIB
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError = symbol missing = broken build
+            fn.restype = res
+            fn.argtypes = args
+        if lib.omc_abi_version() != ABI_VERSION:
+            raise OmcError("libomc.so ABI version mismatch: rebuild the library")
+        _lib = lib
+        return lib
+
+
+def _check(lib, rc):
+    if rc == 0:
+        return
+    msg = (lib.omc_last_error() or b"").decode(errors="replace")
+    if rc < 0:
+        raise ValueError(msg)
+    raise OmcError(f"HIP error {rc}: {msg}")
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.omc_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class DeviceArray:
+    """A device allocation owned by a Context (freed with it or explicitly)."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _check(ctx.lib, ctx.lib.omc_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        ctx._arrays.add(self)
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        _check(self.ctx.lib, self.ctx.lib.omc_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr,
+                                                          self.nbytes))
+        return out
+
+    def from_host(self, a):
+        a = np.ascontiguousarray(a, self.dtype)
+        assert a.shape == self.shape, (a.shape, self.shape)
+        _check(self.ctx.lib, self.ctx.lib.omc_memcpy_h2d(self.ctx.handle, self.ptr, a.ctypes.data,
+                                                          self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.omc_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+            self.ctx._arrays.discard(self)
+
+
+class Context:
+    """One per (process, device).  Calls on a context are serialised by the caller."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.omc_ctx_create(int(device), C.c_void_p(stream) if stream else None,
+                                                  C.byref(h)))
+        self.handle = h
+        self.device = device
+        self._arrays = set()
+        self._hook = None
+
+    # -- housekeeping
+    def close(self):
+        if self.handle:
+            for a in list(self._arrays):
+                a.free()
+            self.lib.omc_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, a, dtype=None):
+        a = np.ascontiguousarray(a, dtype or a.dtype)
+        return DeviceArray(self, a.shape, a.dtype).from_host(a)
+
+    def sync(self):
+        _check(self.lib, self.lib.omc_sync(self.handle))
+
+    def set_option(self, key: str, value: int):
+        _check(self.lib, self.lib.omc_set_option(self.handle, key.encode(), int(value)))
+
+    def set_allreduce_hook(self, fn):
+        """fn(dptr:int, count:int) -> None must sum-all-reduce `count` device doubles in place."""
+        if fn is None:
+            self._hook = None
+            _check(self.lib, self.lib.omc_set_allreduce_hook(self.handle, C.cast(None, ALLREDUCE_FN), None))
+            return
+
+        def tramp(_user, dptr, count):
+            try:
+                fn(dptr, count)
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._hook = ALLREDUCE_FN(tramp)
+        _check(self.lib, self.lib.omc_set_allreduce_hook(self.handle, self._hook, None))
+
+    # -- RNG taps
+    def philox4x32_10(self, ctr_key):
+        a = np.ascontiguousarray(ctr_key, np.uint32).reshape(-1, 6)
+        out = np.empty((a.shape[0], 4), np.uint32)
+        _check(self.lib, self.lib.omc_philox4x32_10(self.handle, a.ctypes.data, out.ctypes.data,
+                                                     a.shape[0]))
+        return out
+
+    def gbm_normals(self, n_pairs, n_steps, seed, stream=0, pair_offset=0):
+        Z = self.empty((n_steps, n_pairs), np.float32)
+        _check(self.lib, self.lib.omc_gbm_normals_f32(self.handle, Z.ptr, n_pairs, n_pairs, n_steps,
+                                                       seed, stream, pair_offset))
+        return Z
+
+    # -- paths (device matrices [n_steps+1][n_paths], ld == n_paths)
+    def gbm_paths(self, n_paths, n_steps, S0, r, sigma, T, seed, stream=0, pair_offset=0,
+                  antithetic=True, out=None):
+        S = out if out is not None else self.empty((n_steps + 1, n_paths), np.float32)
+        _check(self.lib, self.lib.omc_gbm_paths_f32(self.handle, S.ptr, S.shape[1], n_paths, n_steps,
+                                                     S0, r, sigma, T, seed, stream, pair_offset,
+                                                     int(antithetic)))
+        return S
+
+    def heston_paths(self, n_paths, n_steps, S0, r, T, v0, kappa, theta, xi, rho, seed, stream=0,
+                     pair_offset=0, scheme=0, out=None):
+        S = out if out is not None else self.empty((n_steps + 1, n_paths), np.float32)
+        _check(self.lib, self.lib.omc_heston_paths_f32(self.handle, S.ptr, S.shape[1], n_paths,
+                                                        n_steps, S0, r, T, v0, kappa, theta, xi, rho,
+                                                        seed, stream, pair_offset, scheme))
+        return S
+
+    def gbm_paths_from_normals(self, z_half, S0, r, sigma, T, antithetic=True):
+        z = self.to_device(z_half, np.float32)
+        N, P = z.shape
+        M = 2 * P if antithetic else P
+        S = self.empty((N + 1, M), np.float32)
+        _check(self.lib, self.lib.omc_gbm_paths_from_normals_f32(self.handle, S.ptr, M, M, N, S0, r,
+                                                                  sigma, T, z.ptr, P, int(antithetic)))
+        z.free()
+        return S
+
+    def heston_paths_from_normals(self, z1_half, z2_half, S0, r, T, v0, kappa, theta, xi, rho,
+                                  scheme=0):
+        z1 = self.to_device(z1_half, np.float32)
+        z2 = self.to_device(z2_half, np.float32)
+        N, P = z1.shape
+        S = self.empty((N + 1, 2 * P), np.float32)
+        _check(self.lib, self.lib.omc_heston_paths_from_normals_f32(
+            self.handle, S.ptr, 2 * P, 2 * P, N, S0, r, T, v0, kappa, theta, xi, rho, z1.ptr, z2.ptr,
+            P, scheme))
+        z1.free()
+        z2.free()
+        return S
+
+    # -- backward induction on a device path matrix
+    def lsm_poly(self, S, K, r, T, is_put, semantics="reference", want_state=False, n_paths=None):
+        N = S.shape[0] - 1
+        ld = S.shape[1]
+        M = ld if n_paths is None else n_paths
+        res = Result()
+        betas = np.zeros((N + 1, 4))
+        sx = np.zeros(M, np.float32) if want_state else None
+        tex = np.zeros(M, np.int32) if want_state else None
+        ptr = S.ptr if isinstance(S, DeviceArray) else int(S.data_ptr())
+        _check(self.lib, self.lib.omc_lsm_poly(self.handle, ptr, ld, M, N, K, r, T, int(is_put),
+                                                SEMANTICS[semantics], C.byref(res), betas.ctypes.data,
+                                                sx.ctypes.data if want_state else None,
+                                                tex.ctypes.data if want_state else None))
+        d = res.as_dict()
+        d.update(betas=betas[:, :3], nitm=betas[:, 3].astype(np.int64), sx=sx, tex=tex)
+        return d
+
+    def lsm_apply_frozen(self, S, K, r, T, is_put, betas4, want_state=True):
+        N, M = S.shape[0] - 1, S.shape[1]
+        b = np.ascontiguousarray(betas4, np.float64)
+        assert b.shape == (N + 1, 4)
+        res = Result()
+        sx = np.zeros(M, np.float32) if want_state else None
+        tex = np.zeros(M, np.int32) if want_state else None
+        _check(self.lib, self.lib.omc_lsm_apply_frozen(self.handle, S.ptr, M, M, N, K, r, T,
+                                                        int(is_put), b.ctypes.data, C.byref(res),
+                                                        sx.ctypes.data if want_state else None,
+                                                        tex.ctypes.data if want_state else None))
+        d = res.as_dict()
+        d.update(sx=sx, tex=tex)
+        return d
+
+    # -- fused pricing
+    def price_american(self, params: Params, keep_paths: DeviceArray | None = None):
+        res = Result()
+        _check(self.lib, self.lib.omc_price_american(
+            self.handle, C.byref(params), C.byref(res), keep_paths.ptr if keep_paths else None,
+            keep_paths.shape[1] if keep_paths else 0))
+        return res.as_dict()
+
+    def price_european(self, params: Params):
+        res = Result()
+        _check(self.lib, self.lib.omc_price_european(self.handle, C.byref(params), C.byref(res)))
+        return res.as_dict()
+
+
+def make_params(model="gbm", is_put=True, semantics="reference", antithetic=True,
+                heston_scheme="reference", n_paths=0, n_steps=0, S0=100.0, K=100.0, r=0.05,
+                sigma=0.2, T=1.0, v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7, seed=42,
+                stream=0, pair_offset=0) -> Params:
+    p = Params()
+    p.model = MODELS[model.lower()]
+    p.is_put = int(bool(is_put))
+    p.semantics = SEMANTICS[semantics]
+    p.antithetic = int(bool(antithetic))
+    p.heston_scheme = HESTON_SCHEMES[heston_scheme] if isinstance(heston_scheme, str) else int(heston_scheme)
+    p.n_steps = int(n_steps)
+    p.n_paths = int(n_paths)
+    p.S0, p.K, p.r, p.sigma, p.T = float(S0), float(K), float(r), float(sigma or 0.0), float(T)
+    p.v0, p.kappa, p.theta, p.xi, p.rho = float(v0), float(kappa), float(theta), float(xi), float(rho)
+    p.seed, p.stream, p.pair_offset = int(seed), int(stream), int(pair_offset)
+    return p
+
+
+_default_ctx = {}
+_ctx_lock = threading.Lock()
+
+
+def default_context(device: int = 0) -> Context:
+    """Lazily created per (process, device) -- safe under spawn'ed worker pools."""
+    key = (os.getpid(), device)
+    with _ctx_lock:
+        ctx = _default_ctx.get(key)
+        if ctx is None:
+            ctx = Context(device)
+            _default_ctx[key] = ctx
+        return ctx

@@ -1,0 +1,597 @@
+// omc_api.hip -- the C ABI of libomc.so (include/omc.h): contexts, workspaces, argument
+// checks, launch sequencing, HIP-event timing.  No kernel code here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/omc.h"
+#include "omc_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            char buf_[256];                                                                \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                  \
+            g_err = buf_;                                                                  \
+            return (int)e_ > 0 ? (int)e_ : 999;                                            \
+        }                                                                                  \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return (int)e;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            g_err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
+            p = nullptr;
+            return (int)e;
+        }
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct omc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf S, sx, tex, D, part, gmom, betas, part1, result, scratch;
+    std::vector<double> hD;
+    double hres[8];
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int gbm_vec = 0, heston_vec = 0, use_graph = 0;
+    omc_allreduce_fn hook = nullptr;
+    void* hook_user = nullptr;
+};
+
+namespace {
+
+int check_market(double S0, double K, double T, double r)
+{
+    if (!(S0 > 0) || !(K > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
+    if (!(r >= 0)) return fail(-2, "r must be non-negative.");
+    return 0;
+}
+
+int check_sizes(int64_t n_paths, int n_steps)
+{
+    if (n_paths <= 0 || n_steps <= 0)
+        return fail(-3, "num_simulations and num_time_steps must be positive integers.");
+    if (n_steps > omc::kMaxSteps) return fail(-8, "num_time_steps exceeds the supported maximum (4094).");
+    return 0;
+}
+
+int check_matrix(const void* S, int64_t ld, int64_t n_paths)
+{
+    if (!S) return fail(-7, "null path matrix pointer.");
+    if (ld < n_paths) return fail(-6, "leading dimension smaller than n_paths.");
+    return 0;
+}
+
+int bind(omc_ctx* c)
+{
+    if (!c) return fail(-7, "null context.");
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+// workspace for the backward induction on M paths x N steps
+int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
+                omc::LsmWorkspace* w)
+{
+    int rc;
+    if ((rc = c->sx.ensure(sizeof(float) * (size_t)M))) return rc;
+    if ((rc = c->tex.ensure(sizeof(int32_t) * (size_t)M))) return rc;
+    if ((rc = c->D.ensure(sizeof(double) * (size_t)(N + 1)))) return rc;
+    if ((rc = c->part.ensure(sizeof(double) * 2 * 8 * omc::kMaxLsmBlocks))) return rc;
+    if ((rc = c->gmom.ensure(sizeof(double) * 8 * (size_t)(N + 1)))) return rc;
+    if ((rc = c->betas.ensure(sizeof(double) * 4 * (size_t)(N + 1)))) return rc;
+    if ((rc = c->result.ensure(sizeof(double) * 8))) return rc;
+    w->part1 = nullptr;
+    w->part1_tiles = 0;
+    if (two_pass) {
+        const size_t tiles = omc::lsm_part1_tiles(M);
+        if ((rc = c->part1.ensure(sizeof(double) * 8 * (size_t)(N + 1) * tiles))) return rc;
+        w->part1 = (double*)c->part1.p;
+        w->part1_tiles = (int64_t)tiles;
+    }
+    w->sx = (float*)c->sx.p;
+    w->tex = (int32_t*)c->tex.p;
+    w->D = (double*)c->D.p;
+    w->part = (double*)c->part.p;
+    w->gmom = (double*)c->gmom.p;
+    w->betas = (double*)c->betas.p;
+    w->result = (double*)c->result.p;
+    // discount table computed on the host in double (same libm exp as the oracle)
+    c->hD.resize((size_t)N + 1);
+    const double dt = T / N;
+    for (int k = 0; k <= N; ++k) c->hD[(size_t)k] = std::exp(-r * dt * (double)k);
+    HIP_TRY(hipMemcpyAsync(w->D, c->hD.data(), sizeof(double) * (size_t)(N + 1),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(w->gmom, 0, sizeof(double) * 8 * (size_t)(N + 1), c->stream));
+    HIP_TRY(hipMemsetAsync(w->betas, 0, sizeof(double) * 4 * (size_t)(N + 1), c->stream));
+    HIP_TRY(hipMemsetAsync(w->result, 0, sizeof(double) * 8, c->stream));
+    return 0;
+}
+
+// enqueue the whole backward induction on c->stream; sums land in w.result
+int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w, int semantics,
+                bool write_state)
+{
+    hipStream_t st = c->stream;
+    if (semantics == OMC_SEM_TWO_PASS) {
+        HIP_TRY(omc::lsm_pass1_moments(st, p, w));
+        if (c->hook) {
+            int rc = c->hook(c->hook_user, w.gmom, 8 * (p.N + 1));
+            if (rc) return fail(998, "all-reduce hook failed");
+        }
+        HIP_TRY(omc::lsm_solve_all(st, p, w));
+        HIP_TRY(omc::lsm_pass2_apply(st, p, w, write_state));
+    } else {
+        const bool ext = c->hook != nullptr;
+        const int nblk = omc::lsm_step_blocks(p.M);
+        for (int t = p.N; t >= 1; --t) {
+            HIP_TRY(omc::lsm_step(st, p, w, semantics, t, ext));
+            if (ext && t >= 2) {
+                HIP_TRY(omc::lsm_reduce_step_moments(st, w, t - 1, nblk));
+                int rc = c->hook(c->hook_user, w.gmom + (size_t)(t - 1) * 8, 8);
+                if (rc) return fail(998, "all-reduce hook failed");
+            }
+        }
+        HIP_TRY(omc::lsm_final_reduce(st, p, w, semantics == OMC_SEM_TEXTBOOK ? 0 : 1));
+    }
+    return 0;
+}
+
+void fill_result(omc_result* res, const double* h, int64_t M)
+{
+    res->sum = h[0];
+    res->sumsq = h[1];
+    res->n_paths = M;
+    res->n_exercised = (int64_t)llround(h[2]);
+    res->n_zero = (int64_t)llround(h[3]);
+    res->sum_nitm = (int64_t)llround(h[4]);
+    res->price = h[0] / (double)M;
+    const double var = h[1] / (double)M - res->price * res->price;
+    res->std = var > 0 ? std::sqrt(var) : 0.0;
+    res->zero_prob = (double)res->n_zero / (double)M;
+}
+
+int copy_outputs(omc_ctx* c, const omc::LsmWorkspace& w, int64_t M, int N, double* betas_out,
+                 float* sx_out, int32_t* tex_out)
+{
+    if (betas_out)
+        HIP_TRY(hipMemcpyAsync(betas_out, w.betas, sizeof(double) * 4 * (size_t)(N + 1),
+                               hipMemcpyDeviceToHost, c->stream));
+    if (sx_out)
+        HIP_TRY(hipMemcpyAsync(sx_out, w.sx, sizeof(float) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    if (tex_out)
+        HIP_TRY(hipMemcpyAsync(tex_out, w.tex, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost,
+                               c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int omc_abi_version(void) { return OMC_ABI_VERSION; }
+
+const char* omc_last_error(void) { return g_err.c_str(); }
+
+int omc_device_count(int* count)
+{
+    if (!count) return fail(-7, "null pointer.");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        (void)hipGetLastError();
+        g_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return (int)e;
+    }
+    *count = n;
+    return 0;
+}
+
+int omc_ctx_create(int device, void* hip_stream, omc_ctx** out)
+{
+    if (!out) return fail(-7, "null pointer.");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(-4, "no such HIP device.");
+    HIP_TRY(hipSetDevice(device));
+    omc_ctx* c = new omc_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            HIP_TRY(e);
+        }
+        c->own_stream = true;
+    }
+    for (auto& ev : c->ev) {
+        hipError_t e = hipEventCreate(&ev);
+        if (e != hipSuccess) {
+            delete c;
+            HIP_TRY(e);
+        }
+    }
+    *out = c;
+    return 0;
+}
+
+int omc_ctx_destroy(omc_ctx* c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
+                      &c->result, &c->scratch})
+        b->release();
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int omc_sync(omc_ctx* c)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_alloc(omc_ctx* c, size_t bytes, void** dptr)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!dptr) return fail(-7, "null pointer.");
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+    return 0;
+}
+
+int omc_free(omc_ctx* c, void* dptr)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (dptr) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(dptr));
+    }
+    return 0;
+}
+
+int omc_memcpy_h2d(omc_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!bytes) return 0;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_memcpy_d2h(omc_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!bytes) return 0;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_set_option(omc_ctx* c, const char* key, int64_t value)
+{
+    if (!c || !key) return fail(-7, "null pointer.");
+    if (!strcmp(key, "gbm_vec")) c->gbm_vec = (int)value;
+    else if (!strcmp(key, "heston_vec")) c->heston_vec = (int)value;
+    else if (!strcmp(key, "use_graph")) c->use_graph = (int)value;
+    else return fail(-4, "unknown option key.");
+    return 0;
+}
+
+int omc_set_allreduce_hook(omc_ctx* c, omc_allreduce_fn fn, void* user)
+{
+    if (!c) return fail(-7, "null context.");
+    c->hook = fn;
+    c->hook_user = user;
+    return 0;
+}
+
+// ------------------------------------------------------------------ path generation
+int omc_gbm_paths_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, int n_steps, double S0,
+                      double r, double sigma, double T, uint64_t seed, uint64_t stream,
+                      uint64_t pair_offset, int antithetic)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
+    if (!(sigma > 0)) return fail(-5, "S0, K, T, and sigma must be positive.");
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (antithetic && (n_paths & 1)) return fail(-3, "antithetic layout needs an even n_paths.");
+    HIP_TRY(omc::launch_gbm_paths(c->stream, S, ld, n_paths, n_steps, S0, r, sigma, T, seed,
+                                  (uint32_t)stream, pair_offset, antithetic, c->gbm_vec));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_heston_paths_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, int n_steps, double S0,
+                         double r, double T, double v0, double kappa, double theta, double xi,
+                         double rho, uint64_t seed, uint64_t stream, uint64_t pair_offset,
+                         int scheme)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
+    if (!(rho >= -1.0 && rho <= 1.0) || !(v0 >= 0)) return fail(-5, "invalid Heston parameters.");
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (n_paths & 1) return fail(-3, "antithetic layout needs an even n_paths.");
+    if (scheme != 0 && scheme != 1) return fail(-4, "unknown Heston scheme.");
+    HIP_TRY(omc::launch_heston_paths(c->stream, S, ld, n_paths, n_steps, S0, r, T, v0, kappa, theta,
+                                     xi, rho, seed, (uint32_t)stream, pair_offset, scheme,
+                                     c->heston_vec));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_gbm_paths_from_normals_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, int n_steps,
+                                   double S0, double r, double sigma, double T, const float* Z,
+                                   int64_t ldz, int antithetic)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (!Z) return fail(-7, "null normals pointer.");
+    if (antithetic && (n_paths & 1)) return fail(-3, "antithetic layout needs an even n_paths.");
+    if (ldz < (antithetic ? n_paths / 2 : n_paths)) return fail(-6, "ldz too small.");
+    HIP_TRY(omc::launch_gbm_from_normals(c->stream, S, ld, n_paths, n_steps, S0, r, sigma, T, Z, ldz,
+                                         antithetic));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_heston_paths_from_normals_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths,
+                                      int n_steps, double S0, double r, double T, double v0,
+                                      double kappa, double theta, double xi, double rho,
+                                      const float* Z1, const float* Z2, int64_t ldz, int scheme)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (!Z1 || !Z2) return fail(-7, "null normals pointer.");
+    if (n_paths & 1) return fail(-3, "antithetic layout needs an even n_paths.");
+    if (ldz < n_paths / 2) return fail(-6, "ldz too small.");
+    if (scheme != 0 && scheme != 1) return fail(-4, "unknown Heston scheme.");
+    HIP_TRY(omc::launch_heston_from_normals(c->stream, S, ld, n_paths, n_steps, S0, r, T, v0, kappa,
+                                            theta, xi, rho, Z1, Z2, ldz, scheme));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_philox4x32_10(omc_ctx* c, const uint32_t* in, uint32_t* out, int n)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!in || !out || n <= 0) return fail(-7, "bad arguments.");
+    if ((rc = c->scratch.ensure(sizeof(uint32_t) * 10 * (size_t)n))) return rc;
+    uint32_t* din = (uint32_t*)c->scratch.p;
+    uint32_t* dout = din + 6 * (size_t)n;
+    HIP_TRY(hipMemcpyAsync(din, in, sizeof(uint32_t) * 6 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(omc::launch_philox_kat(c->stream, din, dout, n));
+    HIP_TRY(hipMemcpyAsync(out, dout, sizeof(uint32_t) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_gbm_normals_f32(omc_ctx* c, float* Z, int64_t ldz, int64_t n_pairs, int n_steps,
+                        uint64_t seed, uint64_t stream, uint64_t pair_offset)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!Z || n_pairs <= 0 || n_steps <= 0 || ldz < n_pairs) return fail(-7, "bad arguments.");
+    HIP_TRY(omc::launch_gbm_normals(c->stream, Z, ldz, n_pairs, n_steps, seed, (uint32_t)stream,
+                                    pair_offset));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ backward induction
+int omc_lsm_poly(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                 double r, double T, int is_put, int semantics, omc_result* res, double* betas_out,
+                 float* sx_out, int32_t* tex_out)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_market(1.0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (semantics < 0 || semantics > 2) return fail(-4, "unknown semantics.");
+    if (!res) return fail(-7, "null result pointer.");
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, semantics == OMC_SEM_TWO_PASS, &w))) return rc;
+    omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = enqueue_lsm(c, p, w, semantics, sx_out || tex_out))) return rc;
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = copy_outputs(c, w, n_paths, n_steps, betas_out, sx_out, tex_out))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    fill_result(res, c->hres, n_paths);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    res->ms_lsm = ms;
+    res->ms_total = ms;
+    return 0;
+}
+
+int omc_lsm_apply_frozen(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps,
+                         double K, double r, double T, int is_put, const double* betas,
+                         omc_result* res, float* sx_out, int32_t* tex_out)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_market(1.0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (!betas || !res) return fail(-7, "null pointer.");
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, &w))) return rc;
+    HIP_TRY(hipMemcpyAsync(w.betas, betas, sizeof(double) * 4 * (size_t)(n_steps + 1),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `betas` is caller memory
+    omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
+    HIP_TRY(omc::lsm_pass2_apply(c->stream, p, w, sx_out || tex_out));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    fill_result(res, c->hres, n_paths);
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused pricing
+static int check_params(const omc_params* p)
+{
+    int rc;
+    if (!p) return fail(-7, "null params.");
+    if ((rc = check_market(p->S0, p->K, p->T, p->r))) return rc;
+    if ((rc = check_sizes(p->n_paths, p->n_steps))) return rc;
+    if (p->model == OMC_MODEL_GBM) {
+        if (!(p->sigma > 0)) return fail(-5, "S0, K, T, and sigma must be positive.");
+    } else if (p->model == OMC_MODEL_HESTON) {
+        if (!(p->rho >= -1.0 && p->rho <= 1.0) || !(p->v0 >= 0)) return fail(-5, "invalid Heston parameters.");
+        if (p->heston_scheme != 0 && p->heston_scheme != 1) return fail(-4, "unknown Heston scheme.");
+        if (!p->antithetic) return fail(-4, "Heston paths are always antithetic.");
+    } else {
+        return fail(-4, "unknown model.");
+    }
+    if (p->semantics < 0 || p->semantics > 2) return fail(-4, "unknown semantics.");
+    if (p->antithetic && (p->n_paths & 1)) return fail(-3, "antithetic layout needs an even n_paths.");
+    return 0;
+}
+
+int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* S_keep, int64_t ld)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_params(p))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    const int64_t M = p->n_paths;
+    const int N = p->n_steps;
+    float* S = S_keep;
+    if (S) {
+        if (ld < M) return fail(-6, "leading dimension smaller than n_paths.");
+    } else {
+        ld = (M + 63) / 64 * 64;
+        if ((rc = c->S.ensure(sizeof(float) * (size_t)ld * (size_t)(N + 1)))) return rc;
+        S = (float*)c->S.p;
+    }
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, M, N, p->r, p->T, p->semantics == OMC_SEM_TWO_PASS, &w))) return rc;
+    omc::LsmProblem prob{S, ld, M, N, p->is_put ? 1 : 0, p->K, p->r, p->T};
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (p->model == OMC_MODEL_GBM)
+        HIP_TRY(omc::launch_gbm_paths(c->stream, S, ld, M, N, p->S0, p->r, p->sigma, p->T, p->seed,
+                                      (uint32_t)p->stream, p->pair_offset, p->antithetic, c->gbm_vec));
+    else
+        HIP_TRY(omc::launch_heston_paths(c->stream, S, ld, M, N, p->S0, p->r, p->T, p->v0, p->kappa,
+                                         p->theta, p->xi, p->rho, p->seed, (uint32_t)p->stream,
+                                         p->pair_offset, p->heston_scheme, c->heston_vec));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if ((rc = enqueue_lsm(c, prob, w, p->semantics, false))) return rc;
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    fill_result(res, c->hres, M);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    res->ms_paths = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+    res->ms_lsm = ms;
+    res->ms_total = res->ms_paths + res->ms_lsm;
+    return 0;
+}
+
+int omc_price_european(omc_ctx* c, const omc_params* p, omc_result* res)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_params(p))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    if ((rc = c->part.ensure(sizeof(double) * 2 * 8 * omc::kMaxLsmBlocks))) return rc;
+    if ((rc = c->result.ensure(sizeof(double) * 8))) return rc;
+    double* part = (double*)c->part.p;
+    HIP_TRY(hipMemsetAsync(part, 0, sizeof(double) * 8 * omc::kMaxLsmBlocks, c->stream));
+    int nblk = 0;
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(omc::launch_terminal(c->stream, part, &nblk, p->model, p->heston_scheme, p->antithetic,
+                                 p->n_paths, p->n_steps, p->S0, p->K, p->r, p->sigma, p->T, p->v0,
+                                 p->kappa, p->theta, p->xi, p->rho, p->is_put ? 1 : 0, p->seed,
+                                 (uint32_t)p->stream, p->pair_offset));
+    HIP_TRY(omc::lsm_finalize(c->stream, part, nullptr, (double*)c->result.p, nblk, 0));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->hres, c->result.p, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    c->hres[2] = 0.0;
+    c->hres[4] = 0.0;
+    fill_result(res, c->hres, p->n_paths);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    res->ms_paths = ms;
+    res->ms_total = ms;
+    return 0;
+}
+
+}  // extern "C"

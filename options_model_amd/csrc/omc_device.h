@@ -1,0 +1,139 @@
+// omc_device.h -- device-side building blocks shared by the gfx950 kernels:
+// Philox4x32-10 counter RNG, Box-Muller on the hardware transcendental units,
+// block-wide reduction of 8 double accumulators through LDS, 3x3 normal-equation solve.
+//
+// Wave = 64 lanes (gfx950).  Everything here is written for 256-thread workgroups.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace omc {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 waves, one per SIMD)
+constexpr int kRedStride = 264;    // doubles per quantity row in LDS: 256 + 8 pad ->
+                                   // ds_read_b64 by (q,sub) lanes lands on distinct banks
+constexpr int kNQ = 8;             // quantities reduced together
+
+// ------------------------------------------------------------------ Philox4x32-10
+// Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3" (SC'11).
+// Round keys are wave-uniform, so they stay in SGPRs; each round is two 32x32->64
+// multiplies (v_mad_u64_u32 / v_mul_hi_u32) plus three XORs per lane.
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// ------------------------------------------------------------------ Box-Muller
+// u1 in (0,1], u2 in [0,1) built from the top 24 bits of each word (exact in f32).
+// v_log_f32 is log2, v_sin_f32 / v_cos_f32 take their argument in revolutions, so the
+// 2*pi never has to be multiplied in: radius = sqrt(-2 ln2 * log2(u1)), angle = u2 turns.
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& zc, float& zs)
+{
+    const float u1 = __builtin_fmaf((float)(a >> 8), 0x1p-24f, 0x1p-25f);
+    const float u2 = (float)(b >> 8) * 0x1p-24f;
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    zc = rad * __builtin_amdgcn_cosf(u2);
+    zs = rad * __builtin_amdgcn_sinf(u2);
+}
+
+// four N(0,1) draws of one Philox block; counter = (pair_lo, pair_hi, block, stream)
+__device__ __forceinline__ void normals4(uint64_t pair, uint32_t block, uint32_t stream,
+                                         uint32_t k0, uint32_t k1, float (&z)[4])
+{
+    const U4 o = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), block, stream, k0, k1);
+    box_muller(o.x, o.y, z[0], z[1]);
+    box_muller(o.z, o.w, z[2], z[3]);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ------------------------------------------------------------------ block reduction
+// Sums acc[0..7] over the 256 threads of the block in a fixed order (bitwise
+// reproducible run to run).  `red` is LDS, kNQ*kRedStride doubles.  On return lanes of
+// wave 0 with (lane & 7) == 0 hold the total of quantity lane >> 3 in the return value;
+// other threads get garbage.  The caller decides where the totals go.  One barrier
+// inside; the caller must separate two uses of the same `red` by another barrier.
+__device__ __forceinline__ double block_reduce8(const double (&acc)[kNQ], double* red)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) red[q * kRedStride + tid] = acc[q];
+    __syncthreads();
+    double s = 0.0;
+    if (tid < 64) {
+        const int q = tid >> 3, sub = tid & 7;
+        const double* p = red + q * kRedStride + sub;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) s += p[8 * i];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+    }
+    return s;
+}
+
+// ------------------------------------------------------------------ 3x3 OLS solve
+// y ~ b0 + b1 u + b2 u^2 from m = {n, Su, Su2, Su3, Su4, Sy, Suy, Su2y}; centred LDL^T,
+// degree reduced to n-1 for n < 3 or when a pivot is not safely positive.
+__device__ __forceinline__ void solve_poly2(const double (&m)[8], double (&beta)[3])
+{
+    const double n = m[0];
+    beta[0] = beta[1] = beta[2] = 0.0;
+    if (n < 0.5) return;
+    const double mu = m[1] / n, my = m[5] / n;
+    const double c11 = m[2] - m[1] * mu;
+    const double c1y = m[6] - m[1] * my;
+    if (n < 1.5 || !(c11 > 1e-14 * fabs(m[2]) + 1e-300)) { beta[0] = my; return; }
+    const double mq = m[2] / n;
+    const double c22 = m[4] - m[2] * mq;
+    const double c12 = m[3] - m[1] * mq;
+    const double c2y = m[7] - m[2] * my;
+    const double l21 = c12 / c11;
+    const double d2 = c22 - l21 * c12;
+    if (n < 2.5 || !(d2 > 1e-12 * fabs(c22) + 1e-300)) {
+        beta[1] = c1y / c11;
+        beta[0] = my - beta[1] * mu;
+        return;
+    }
+    const double b2 = (c2y - l21 * c1y) / d2;
+    const double b1 = (c1y - c12 * b2) / c11;
+    beta[2] = b2;
+    beta[1] = b1;
+    beta[0] = my - b1 * mu - b2 * mq;
+}
+
+__device__ __forceinline__ double payoff_d(float s, double K, int is_put)
+{
+    return is_put ? K - (double)s : (double)s - K;
+}
+
+__device__ __forceinline__ void accumulate_moments(double (&acc)[8], double u, double y)
+{
+    const double u2 = u * u;
+    acc[0] += 1.0;
+    acc[1] += u;
+    acc[2] += u2;
+    acc[3] += u2 * u;
+    acc[4] += u2 * u2;
+    acc[5] += y;
+    acc[6] += u * y;
+    acc[7] += u2 * y;
+}
+
+}  // namespace omc

@@ -1,0 +1,82 @@
+// omc_kernels.h -- host-callable launchers of the gfx950 kernels (internal to libomc.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace omc {
+
+// ---- omc_paths.hip
+hipError_t launch_gbm_paths(hipStream_t st, float* S, int64_t ld, int64_t n_paths, int n_steps,
+                            double S0, double r, double sigma, double T, uint64_t seed,
+                            uint32_t stream, uint64_t pair_offset, int antithetic, int vec_hint);
+hipError_t launch_heston_paths(hipStream_t st, float* S, int64_t ld, int64_t n_paths, int n_steps,
+                               double S0, double r, double T, double v0, double kappa,
+                               double theta, double xi, double rho, uint64_t seed, uint32_t stream,
+                               uint64_t pair_offset, int scheme, int vec_hint);
+hipError_t launch_gbm_from_normals(hipStream_t st, float* S, int64_t ld, int64_t n_paths,
+                                   int n_steps, double S0, double r, double sigma, double T,
+                                   const float* Z, int64_t ldz, int antithetic);
+hipError_t launch_heston_from_normals(hipStream_t st, float* S, int64_t ld, int64_t n_paths,
+                                      int n_steps, double S0, double r, double T, double v0,
+                                      double kappa, double theta, double xi, double rho,
+                                      const float* Z1, const float* Z2, int64_t ldz, int scheme);
+hipError_t launch_philox_kat(hipStream_t st, const uint32_t* in, uint32_t* out, int n);
+hipError_t launch_gbm_normals(hipStream_t st, float* Z, int64_t ldz, int64_t n_pairs, int n_steps,
+                              uint64_t seed, uint32_t stream, uint64_t pair_offset);
+
+constexpr int kMaxLsmBlocks = 1024;  // grid of the per-step sweep (also partial-moment slots)
+// discounted terminal payoff partial sums -> part[8][kMaxLsmBlocks] (rows 0,1,3 used)
+hipError_t launch_terminal(hipStream_t st, double* part, int* nblk_out, int model, int scheme,
+                           int antithetic, int64_t n_paths, int n_steps, double S0, double K,
+                           double r, double sigma, double T, double v0, double kappa, double theta,
+                           double xi, double rho, int is_put, uint64_t seed, uint32_t stream,
+                           uint64_t pair_offset);
+
+// ---- omc_lsm.hip
+constexpr int kMaxSteps = 4094;      // discount table / beta table live in LDS
+
+struct LsmProblem {
+    const float* S;   // [N+1][ld]
+    int64_t ld, M;
+    int N, is_put;
+    double K, r, T;
+};
+
+// device workspace carved by the API layer (all sizes in elements)
+struct LsmWorkspace {
+    float* sx;        // [M]   spot at the (current) exercise time of each path
+    int32_t* tex;     // [M]   step index of that exercise (N = maturity / never exercised)
+    double* D;        // [N+1] discount table exp(-r dt k)
+    double* part;     // [2][8][kMaxLsmBlocks] per-block partial moments, ping-pong by step parity
+    double* gmom;     // [N+1][8] reduced moments per step
+    double* betas;    // [N+1][4] b0,b1,b2,n
+    double* part1;    // two-pass: [N+1][8][ntiles] partial moments of pass 1
+    int64_t part1_tiles;
+    double* result;   // [8] sum, sumsq, n_exercised, n_zero, sum_nitm, -, -, -
+};
+
+size_t lsm_part1_tiles(int64_t M);
+// part[0][q][0..nblk) -> result[q], result[4] = sum_t gmom[t][0] (N<=1: skipped)
+hipError_t lsm_finalize(hipStream_t st, const double* part, const double* gmom, double* result,
+                        int nblk, int N);
+
+// per-step flows (semantics 0 reference sticky / 1 textbook).
+//   lsm_step(t) for t = N .. 1; when `external_moments` the prologue of step t reads
+//   gmom[t] (already reduced, possibly all-reduced across GPUs) instead of the partials.
+hipError_t lsm_step(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
+                    int t, bool external_moments);
+// partials of step t -> gmom[t]  (only needed between steps when moments leave the GPU)
+hipError_t lsm_reduce_step_moments(hipStream_t st, const LsmWorkspace& w, int t, int nblk);
+int lsm_step_blocks(int64_t M);
+
+// two-pass flow (semantics 2)
+hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);
+hipError_t lsm_solve_all(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);
+// sticky sweep with given betas; writes sx/tex when write_state, leaves sums in w.result
+hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w,
+                           bool write_state);
+
+// valuation of (sx,tex): sums into w.result ; tval = 1 (reference flows) or 0 (textbook)
+hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval);
+
+}  // namespace omc

@@ -1,0 +1,555 @@
+// omc_lsm.hip -- Longstaff-Schwartz backward induction kernels for gfx950 (MI355X).
+//
+// Replaces the reference's per-step torch/numpy chains (mask -> gather -> regress ->
+// compare -> scatter, with host syncs every step):
+//   per-step flow   Options_model.py:108-157, options_model_2.py:278-313
+//   two-pass flow   options_model_3/options_model_3.py:482-516 (pass 1), :615-651 (pass 2)
+//   GPU intent      options_model_3/option_model_3_gpu.py:705-721, :804-831
+// The regressor is OLS on [1,u,u^2], u = S/K - 1: eight double sums per time step, reduced
+// per block through LDS, solved on chip; nothing is gathered, compacted or materialised.
+//
+// Per-path state is (sx, tex) = spot and step index of the path's current exercise time
+// (tex == N: terminal payoff).  A cash-flow seen from step t is payoff(sx) * D[tex - t]
+// with D[k] = exp(-r dt k): no per-step rescaling pass, no rounding drift, and the state is
+// only rewritten when a path actually exercises.
+//
+// All kernels: 256-thread workgroups, 16-byte loads per lane where alignment allows,
+// fixed-order reductions (bitwise reproducible), no atomics.
+#include "omc_device.h"
+#include "omc_kernels.h"
+
+namespace omc {
+
+constexpr int kPStride = kMaxLsmBlocks;
+
+template <int VEC>
+__device__ __forceinline__ void loadf(const float* __restrict__ p, float (&v)[VEC])
+{
+    if constexpr (VEC == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(p);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void loadi(const int32_t* __restrict__ p, int32_t (&v)[VEC])
+{
+    if constexpr (VEC == 4) {
+        const int4 x = *reinterpret_cast<const int4*>(p);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void storef(float* p, const float (&v)[VEC])
+{
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else *p = v[0];
+}
+template <int VEC>
+__device__ __forceinline__ void storei(int32_t* p, const int32_t (&v)[VEC])
+{
+    if constexpr (VEC == 4) *reinterpret_cast<int4*>(p) = make_int4(v[0], v[1], v[2], v[3]);
+    else *p = v[0];
+}
+
+// ------------------------------------------------------------------ per-step sweep
+struct StepArgs {
+    const float* S;
+    int64_t ld, M;
+    int N, is_put;
+    double K, invK;
+    float* sx;
+    int32_t* tex;
+    const double* D;
+    double* part;
+    double* gmom;
+    double* betas;
+    int t, nblk, external;
+};
+
+// One launch per time step t = N .. 1 (the launch boundary is the grid-wide barrier the
+// regression needs).  Launch t:
+//   prologue  reduce the partial moments of step t (written by launch t+1), solve beta_t
+//   body      per path: apply the exercise rule at t, then add the path's contribution to
+//             the moments of step t-1 -- one pass over S_t, S_{t-1} and the path state
+//   epilogue  per-block partial moments of step t-1 -> part[(t-1)&1]
+// SEM 0: sticky "exercised" mask (reference per-step flow).  SEM 1: textbook LSM.
+template <int SEM, int VEC>
+__global__ __launch_bounds__(kBlock) void lsm_step_kernel(StepArgs a)
+{
+    __shared__ double red[kNQ * kRedStride];
+    __shared__ double sh_m[8];
+    __shared__ double sh_beta[4];
+    extern __shared__ double sh_D[];  // SEM 1 only: [N+1]
+
+    const int tid = threadIdx.x;
+    const int t = a.t, N = a.N;
+    const bool do_apply = t < N, do_mom = t >= 2, init = (t == N);
+
+    if (SEM == 1 && do_mom) {
+        for (int k = tid; k <= N; k += kBlock) sh_D[k] = a.D[k];
+    }
+
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0, nfit = 0.0;
+    if (do_apply) {
+        if (a.external) {
+            if (tid < 8) sh_m[tid] = a.gmom[(size_t)t * 8 + tid];
+        } else {
+            double acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+            const double* pp = a.part + (size_t)(t & 1) * 8 * kPStride;
+            for (int i = tid; i < a.nblk; i += kBlock) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += pp[q * kPStride + i];
+            }
+            const double s = block_reduce8(acc, red);
+            if (tid < 64 && (tid & 7) == 0) sh_m[tid >> 3] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double m[8], beta[3];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = sh_m[q];
+            solve_poly2(m, beta);
+            sh_beta[0] = beta[0]; sh_beta[1] = beta[1]; sh_beta[2] = beta[2]; sh_beta[3] = m[0];
+            if (blockIdx.x == 0) {
+                double* bo = a.betas + (size_t)t * 4;
+                bo[0] = beta[0]; bo[1] = beta[1]; bo[2] = beta[2]; bo[3] = m[0];
+                if (!a.external) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a.gmom[(size_t)t * 8 + q] = m[q];
+                }
+            }
+        }
+        __syncthreads();
+        b0 = sh_beta[0]; b1 = sh_beta[1]; b2 = sh_beta[2]; nfit = sh_beta[3];
+    } else if (SEM == 1 && do_mom) {
+        __syncthreads();
+    }
+
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    const double Dm = do_mom ? a.D[N - (t - 1)] : 0.0;
+    const double K = a.K, invK = a.invK;
+    const int is_put = a.is_put;
+    const float* St = a.S + (int64_t)t * a.ld;
+    const float* Sm = a.S + (int64_t)(t - 1) * a.ld;
+    const bool fit_ok = do_apply && nfit > 0.5;
+    const int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
+    for (int64_t j = ((int64_t)blockIdx.x * kBlock + tid) * VEC; j < a.M; j += stride) {
+        float st[VEC], sm[VEC], sx[VEC];
+        int32_t tex[VEC];
+        loadf<VEC>(St + j, st);
+        if (do_mom) loadf<VEC>(Sm + j, sm);
+        bool changed = false;
+        if (init) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { sx[v] = st[v]; tex[v] = N; }
+            changed = true;
+        } else {
+            loadf<VEC>(a.sx + j, sx);
+            loadi<VEC>(a.tex + j, tex);
+        }
+        if (fit_ok) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double imm = payoff_d(st[v], K, is_put);
+                if (imm > 0.0 && (SEM == 1 || tex[v] == N)) {
+                    const double u = fma((double)st[v], invK, -1.0);
+                    const double cont = fma(u, fma(u, b2, b1), b0);
+                    if (imm > cont) { sx[v] = st[v]; tex[v] = t; changed = true; }
+                }
+            }
+        }
+        if (changed) {
+            storef<VEC>(a.sx + j, sx);
+            storei<VEC>(a.tex + j, tex);
+        }
+        if (do_mom) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double imm = payoff_d(sm[v], K, is_put);
+                if (imm > 0.0 && (SEM == 1 || tex[v] == N)) {
+                    double p = payoff_d(sx[v], K, is_put);
+                    p = p > 0.0 ? p : 0.0;
+                    const double y = p * (SEM == 1 ? sh_D[tex[v] - (t - 1)] : Dm);
+                    accumulate_moments(acc, fma((double)sm[v], invK, -1.0), y);
+                }
+            }
+        }
+    }
+    if (do_mom) {
+        const double s = block_reduce8(acc, red);
+        if (tid < 64 && (tid & 7) == 0)
+            a.part[(size_t)((t - 1) & 1) * 8 * kPStride + (size_t)(tid >> 3) * kPStride + blockIdx.x] = s;
+    }
+}
+
+// partial moments of step t -> gmom[t] (used when the moments leave the GPU between steps)
+__global__ __launch_bounds__(kBlock) void lsm_reduce_step_kernel(const double* __restrict__ part,
+                                                                 double* __restrict__ gmom, int t,
+                                                                 int nblk)
+{
+    __shared__ double red[kNQ * kRedStride];
+    const int tid = threadIdx.x;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    const double* pp = part + (size_t)(t & 1) * 8 * kPStride;
+    for (int i = tid; i < nblk; i += kBlock) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += pp[q * kPStride + i];
+    }
+    const double s = block_reduce8(acc, red);
+    if (tid < 64 && (tid & 7) == 0) gmom[(size_t)t * 8 + (tid >> 3)] = s;
+}
+
+// ------------------------------------------------------------------ two-pass flow
+struct Pass1Args {
+    const float* S;
+    int64_t ld, M;
+    int N, is_put;
+    double K, invK;
+    const double* D;
+    double* part1;
+    int64_t ntiles;
+    int tchunk;
+};
+
+// Pass 1 (options_model_3.py:482-516): no decisions, so every time step is independent.
+// grid = (path tiles, step chunks).  Targets are the discounted TERMINAL payoffs.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void lsm_pass1_kernel(Pass1Args a)
+{
+    __shared__ double red[2][kNQ * kRedStride];
+    const int tid = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t j = (tile * kBlock + tid) * VEC;
+    const bool valid = j < a.M;
+    const int t0 = 1 + blockIdx.y * a.tchunk;
+    const int t1 = min(t0 + a.tchunk, a.N);
+    const double K = a.K, invK = a.invK;
+    const int is_put = a.is_put;
+    double pN[VEC];
+    if (valid) {
+        float sn[VEC];
+        loadf<VEC>(a.S + (int64_t)a.N * a.ld + j, sn);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const double p = payoff_d(sn[v], K, is_put);
+            pN[v] = p > 0.0 ? p : 0.0;
+        }
+    }
+    for (int t = t0; t < t1; ++t) {
+        double acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+        if (valid) {
+            float st[VEC];
+            loadf<VEC>(a.S + (int64_t)t * a.ld + j, st);
+            const double d = a.D[a.N - t];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double imm = payoff_d(st[v], K, is_put);
+                if (imm > 0.0) accumulate_moments(acc, fma((double)st[v], invK, -1.0), pN[v] * d);
+            }
+        }
+        const double s = block_reduce8(acc, red[(t - t0) & 1]);
+        if (tid < 64 && (tid & 7) == 0)
+            a.part1[((size_t)t * 8 + (tid >> 3)) * a.ntiles + tile] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void lsm_reduce_pass1_kernel(const double* __restrict__ part1,
+                                                                  double* __restrict__ gmom,
+                                                                  int64_t ntiles)
+{
+    __shared__ double red[kNQ * kRedStride];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x + 1;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        acc[q] = 0.0;
+        const double* pp = part1 + ((size_t)t * 8 + q) * ntiles;
+        for (int64_t i = tid; i < ntiles; i += kBlock) acc[q] += pp[i];
+    }
+    const double s = block_reduce8(acc, red);
+    if (tid < 64 && (tid & 7) == 0) gmom[(size_t)t * 8 + (tid >> 3)] = s;
+}
+
+__global__ void lsm_solve_all_kernel(const double* __restrict__ gmom, double* __restrict__ betas,
+                                     int N)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 1 || t >= N) return;
+    double m[8], beta[3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = gmom[(size_t)t * 8 + q];
+    solve_poly2(m, beta);
+    double* bo = betas + (size_t)t * 4;
+    bo[0] = beta[0]; bo[1] = beta[1]; bo[2] = beta[2]; bo[3] = m[0];
+}
+
+struct Pass2Args {
+    const float* S;
+    int64_t ld, M;
+    int N, is_put;
+    double K, invK;
+    const double* D;
+    const double* betas;
+    float* sx;
+    int32_t* tex;
+    double* part;
+};
+
+// Pass 2 (options_model_3.py:615-651) with frozen per-step fits: every path is
+// independent, so one thread walks its VEC paths backward through all steps and stops as
+// soon as they have all exercised (sticky mask).  Sums of the t=dt-valued cash-flows are
+// reduced per block.
+template <int VEC, bool WRITE_STATE>
+__global__ __launch_bounds__(kBlock) void lsm_pass2_kernel(Pass2Args a)
+{
+    __shared__ double red[kNQ * kRedStride];
+    extern __shared__ double sh_b[];  // [N+1][4]
+    const int tid = threadIdx.x;
+    const int N = a.N;
+    for (int k = tid; k < (N + 1) * 4; k += kBlock) sh_b[k] = (k >= 4 && k < N * 4) ? a.betas[k] : 0.0;
+    __syncthreads();
+    const double K = a.K, invK = a.invK;
+    const int is_put = a.is_put;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
+    for (int64_t j = ((int64_t)blockIdx.x * kBlock + tid) * VEC; j < a.M; j += stride) {
+        float sx[VEC];
+        int32_t tex[VEC];
+        loadf<VEC>(a.S + (int64_t)N * a.ld + j, sx);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) tex[v] = N;
+        int live = VEC;
+        constexpr int U = 4;
+        for (int tb = N - 1; tb >= 1 && live > 0; tb -= U) {
+            float st[U][VEC];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (tb - k >= 1) loadf<VEC>(a.S + (int64_t)(tb - k) * a.ld + j, st[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int t = tb - k;
+                if (t < 1) break;
+                const double* b = sh_b + 4 * t;
+                if (!(b[3] > 0.5)) continue;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    if (tex[v] != N) continue;
+                    const double imm = payoff_d(st[k][v], K, is_put);
+                    if (imm > 0.0) {
+                        const double u = fma((double)st[k][v], invK, -1.0);
+                        const double cont = fma(u, fma(u, b[2], b[1]), b[0]);
+                        if (imm > cont) { sx[v] = st[k][v]; tex[v] = t; --live; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            double p = payoff_d(sx[v], K, is_put);
+            p = p > 0.0 ? p : 0.0;
+            const double cf = p * a.D[tex[v] - 1];
+            acc[0] += cf;
+            acc[1] += cf * cf;
+            acc[2] += (tex[v] < N) ? 1.0 : 0.0;
+            acc[3] += (cf == 0.0) ? 1.0 : 0.0;
+        }
+        if (WRITE_STATE) {
+            storef<VEC>(a.sx + j, sx);
+            storei<VEC>(a.tex + j, tex);
+        }
+    }
+    const double s = block_reduce8(acc, red);
+    if (tid < 64 && (tid & 7) == 0) a.part[(size_t)(tid >> 3) * kPStride + blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------ valuation + finalize
+struct FinalArgs {
+    const float* sx;
+    const int32_t* tex;
+    int64_t M;
+    int N, is_put, tval;
+    double K;
+    const double* D;
+    double* part;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void lsm_final_kernel(FinalArgs a)
+{
+    __shared__ double red[kNQ * kRedStride];
+    const int tid = threadIdx.x;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
+    for (int64_t j = ((int64_t)blockIdx.x * kBlock + tid) * VEC; j < a.M; j += stride) {
+        float sx[VEC];
+        int32_t tex[VEC];
+        loadf<VEC>(a.sx + j, sx);
+        loadi<VEC>(a.tex + j, tex);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            double p = payoff_d(sx[v], a.K, a.is_put);
+            p = p > 0.0 ? p : 0.0;
+            const double cf = p * a.D[tex[v] - a.tval];
+            acc[0] += cf;
+            acc[1] += cf * cf;
+            acc[2] += (tex[v] < a.N) ? 1.0 : 0.0;
+            acc[3] += (cf == 0.0) ? 1.0 : 0.0;
+        }
+    }
+    const double s = block_reduce8(acc, red);
+    if (tid < 64 && (tid & 7) == 0) a.part[(size_t)(tid >> 3) * kPStride + blockIdx.x] = s;
+}
+
+// part[0][q][0..nblk) -> result[q]; result[4] = sum over t of the regression-set sizes
+__global__ __launch_bounds__(kBlock) void lsm_finalize_kernel(const double* __restrict__ part,
+                                                              const double* __restrict__ gmom,
+                                                              double* __restrict__ result, int nblk,
+                                                              int N)
+{
+    __shared__ double red[kNQ * kRedStride];
+    const int tid = threadIdx.x;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    for (int i = tid; i < nblk; i += kBlock) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += part[(size_t)q * kPStride + i];
+    }
+    for (int t = 1 + tid; t < N; t += kBlock) acc[4] += gmom[(size_t)t * 8];
+    const double s = block_reduce8(acc, red);
+    if (tid < 64 && (tid & 7) == 0) result[tid >> 3] = s;
+}
+
+// ------------------------------------------------------------------ host launchers
+static inline bool vec4_ok(const LsmProblem& p)
+{
+    return (p.M % 4) == 0 && (p.ld % 4) == 0 && ((uintptr_t)p.S % 16) == 0;
+}
+
+int lsm_step_blocks(int64_t M)
+{
+    const int64_t per_block = (int64_t)kBlock * 4;
+    int64_t b = (M + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > kMaxLsmBlocks ? kMaxLsmBlocks : b);
+}
+
+size_t lsm_part1_tiles(int64_t M)
+{
+    // sized for the VEC=1 fallback too (4x more tiles); the kernel uses what it needs
+    return (size_t)((M + kBlock - 1) / kBlock);
+}
+
+hipError_t lsm_step(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
+                    int t, bool external_moments)
+{
+    StepArgs a;
+    a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
+    a.K = p.K; a.invK = 1.0 / p.K;
+    a.sx = w.sx; a.tex = w.tex; a.D = w.D; a.part = w.part; a.gmom = w.gmom; a.betas = w.betas;
+    a.t = t; a.nblk = lsm_step_blocks(p.M); a.external = external_moments ? 1 : 0;
+    const dim3 grid(a.nblk), block(kBlock);
+    const bool v4 = vec4_ok(p);
+    const size_t dyn = semantics == 1 ? sizeof(double) * (size_t)(p.N + 1) : 0;
+    if (semantics == 0) {
+        if (v4) hipLaunchKernelGGL((lsm_step_kernel<0, 4>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((lsm_step_kernel<0, 1>), grid, block, 0, st, a);
+    } else {
+        if (v4) hipLaunchKernelGGL((lsm_step_kernel<1, 4>), grid, block, dyn, st, a);
+        else hipLaunchKernelGGL((lsm_step_kernel<1, 1>), grid, block, dyn, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t lsm_reduce_step_moments(hipStream_t st, const LsmWorkspace& w, int t, int nblk)
+{
+    hipLaunchKernelGGL(lsm_reduce_step_kernel, dim3(1), dim3(kBlock), 0, st, w.part, w.gmom, t, nblk);
+    return hipGetLastError();
+}
+
+hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w)
+{
+    if (p.N < 2) return hipSuccess;
+    Pass1Args a;
+    a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
+    a.K = p.K; a.invK = 1.0 / p.K; a.D = w.D; a.part1 = w.part1;
+    const bool v4 = vec4_ok(p);
+    const int vec = v4 ? 4 : 1;
+    a.ntiles = (p.M + (int64_t)kBlock * vec - 1) / ((int64_t)kBlock * vec);
+    a.tchunk = 16;
+    const dim3 grid((unsigned)a.ntiles, (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
+    if (v4) hipLaunchKernelGGL((lsm_pass1_kernel<4>), grid, dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((lsm_pass1_kernel<1>), grid, dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1), dim3(kBlock), 0, st, w.part1, w.gmom,
+                       a.ntiles);
+    return hipGetLastError();
+}
+
+hipError_t lsm_solve_all(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w)
+{
+    hipLaunchKernelGGL(lsm_solve_all_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, w.gmom,
+                       w.betas, p.N);
+    return hipGetLastError();
+}
+
+hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w,
+                           bool write_state)
+{
+    Pass2Args a;
+    a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
+    a.K = p.K; a.invK = 1.0 / p.K; a.D = w.D; a.betas = w.betas; a.sx = w.sx; a.tex = w.tex;
+    a.part = w.part;
+    const int nblk = lsm_step_blocks(p.M);
+    const size_t dyn = sizeof(double) * 4 * (size_t)(p.N + 1);
+    const bool v4 = vec4_ok(p);
+    if (v4) {
+        if (write_state) hipLaunchKernelGGL((lsm_pass2_kernel<4, true>), dim3(nblk), dim3(kBlock), dyn, st, a);
+        else hipLaunchKernelGGL((lsm_pass2_kernel<4, false>), dim3(nblk), dim3(kBlock), dyn, st, a);
+    } else {
+        if (write_state) hipLaunchKernelGGL((lsm_pass2_kernel<1, true>), dim3(nblk), dim3(kBlock), dyn, st, a);
+        else hipLaunchKernelGGL((lsm_pass2_kernel<1, false>), dim3(nblk), dim3(kBlock), dyn, st, a);
+    }
+    hipLaunchKernelGGL(lsm_finalize_kernel, dim3(1), dim3(kBlock), 0, st, w.part, w.gmom, w.result,
+                       nblk, p.N);
+    return hipGetLastError();
+}
+
+hipError_t lsm_finalize(hipStream_t st, const double* part, const double* gmom, double* result,
+                        int nblk, int N)
+{
+    hipLaunchKernelGGL(lsm_finalize_kernel, dim3(1), dim3(kBlock), 0, st, part, gmom, result, nblk, N);
+    return hipGetLastError();
+}
+
+hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval)
+{
+    FinalArgs a;
+    a.sx = w.sx; a.tex = w.tex; a.M = p.M; a.N = p.N; a.is_put = p.is_put; a.tval = tval;
+    a.K = p.K; a.D = w.D; a.part = w.part;
+    const int nblk = lsm_step_blocks(p.M);
+    if ((p.M % 4) == 0) hipLaunchKernelGGL((lsm_final_kernel<4>), dim3(nblk), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((lsm_final_kernel<1>), dim3(nblk), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(lsm_finalize_kernel, dim3(1), dim3(kBlock), 0, st, w.part, w.gmom, w.result,
+                       nblk, p.N);
+    return hipGetLastError();
+}
+
+}  // namespace omc

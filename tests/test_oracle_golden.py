@@ -1,0 +1,186 @@
+"""CPU suite, part 1: the oracle (oracle/) against the fixtures captured from the reference
+(tests/golden/, tools/capture_golden.py).  No GPU.  This is what pins the checker itself.
+"""
+import numpy as np
+import pytest
+
+from oracle import cpu as orc
+from oracle import reference_flow as rf
+
+K, R, SIG, T = 100.0, 0.05, 0.2, 1.0
+
+
+def test_philox_known_answers(golden):
+    for k in golden["scalars"]["philox4x32_10_kat"]:
+        o = orc.philox4x32_10([int(x, 16) for x in k["ctr"]], [int(x, 16) for x in k["key"]])
+        assert [f"{v:08x}" for v in o] == k["out"]
+
+
+def test_rng_manager_child_seeds(golden):
+    m = rf.RNGManager(42)
+    assert [m.get_child_seed() for _ in range(6)] == golden["scalars"]["rng_manager_42_child_seeds"]
+    assert golden["scalars"]["c1_seed42_gbm_put"]["child_seed"] == rf.RNGManager(42).get_child_seed()
+
+
+@pytest.mark.parametrize("tag", ["small", "mid"])
+def test_gbm_recurrence_bit_exact(golden, tag):
+    g = golden["paths"]
+    S = rf.gbm_paths_from_normals(g[f"gbm_{tag}_zhalf"], *g["gbm_params"])
+    assert np.array_equal(S, g[f"gbm_{tag}_S"])
+    S32 = orc.gbm_paths_from_normals(g[f"gbm_{tag}_zhalf"], *g["gbm_params"])
+    assert np.abs(S32 / g[f"gbm_{tag}_S"] - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("pname", ["feller", "clamp"])
+@pytest.mark.parametrize("tag", ["small", "mid"])
+def test_heston_recurrence_bit_exact(golden, pname, tag):
+    g = golden["paths"]
+    z1, z2 = g[f"heston_{pname}_{tag}_z1"], g[f"heston_{pname}_{tag}_z2"]
+    hp = g[f"heston_{pname}_params"]
+    assert np.array_equal(rf.heston_paths_from_normals(z1, z2, *hp), g[f"heston_{pname}_{tag}_S"])
+    S32 = orc.heston_paths_from_normals(z1, z2, *hp)
+    assert np.abs(S32 / g[f"heston_{pname}_{tag}_S"] - 1).max() < 2e-5
+
+
+def test_features_bit_exact(golden):
+    g = golden["paths"]
+    Kf, _, Tf = g["feat_KrT"]
+    for t, ref in zip(g["feat_tcur"], g["feat_out"]):
+        assert np.array_equal(rf.regression_features(g["feat_S"], Kf, Tf, t), ref)
+
+
+def test_welford_merge(golden):
+    g = golden["paths"]
+    data, sizes = g["welford_data"], g["welford_sizes"]
+    mean, m2, n, o = 0.0, 0.0, 0, 0
+    for s, ref in zip(sizes, g["welford_trace"]):
+        mean, m2, n = rf.welford_batch_update(mean, m2, n, data[o:o + s])
+        o += s
+        assert (mean, m2, n) == tuple(ref[:2]) + (int(ref[2]),)
+    res = rf.streaming_stats(np.split(data, np.cumsum([500] * 9)))
+    assert np.allclose(res, g["welford_streaming_result"], rtol=0, atol=0)
+    assert abs(res[0] - data.mean()) < 1e-12 and res[2] == data.size
+
+
+def test_black_scholes_closed_form(golden):
+    bs = golden["scalars"]["black_scholes"]
+    assert abs(rf.black_scholes_price(100, 100, 1, 0.05, 0.2, "put") - bs["put_100_100_1_0.05_0.2"]) < 1e-12
+    assert abs(rf.black_scholes_price(100, 100, 1, 0.05, 0.2, "call") - bs["call_100_100_1_0.05_0.2"]) < 1e-12
+    assert abs(rf.black_scholes_price(90, 100, 0.25, 0.03, 0.35, "put") - bs["put_90_100_0.25_0.03_0.35"]) < 1e-12
+    assert abs(rf.black_scholes_price(120, 100, 2, 0.01, 0.15, "call") - bs["call_120_100_2_0.01_0.15"]) < 1e-12
+
+
+SEM = {"ref": "reference", "textbook": "textbook", "twopass": "two_pass"}
+
+
+@pytest.mark.parametrize("pc", ["put", "call"])
+@pytest.mark.parametrize("name", ["ref", "textbook", "twopass"])
+@pytest.mark.parametrize("tag", ["small", "mid"])
+def test_c_oracle_flows_against_golden(golden, tag, name, pc):
+    g, pf = golden["paths"], golden["poly"]
+    Sref = g[f"gbm_{tag}_S"]
+    N = Sref.shape[0] - 1
+    is_put = pc == "put"
+    o = orc.lsm_poly(Sref.astype(np.float32), K, R, T, is_put, SEM[name])
+    assert np.array_equal(o["nitm"][1:N], pf[f"poly_{tag}_{pc}_{name}_nitm"][1:N])
+    if name != "textbook":
+        assert np.array_equal(o["tex"] < N, pf[f"poly_{tag}_{pc}_{name}_ex"])
+    cf_g = pf[f"poly_{tag}_{pc}_{name}_cf"]
+    pay = np.maximum(K - o["sx"].astype(np.float64), 0) if is_put else np.maximum(o["sx"].astype(np.float64) - K, 0)
+    cf = pay * np.exp(-R * T / N * (o["tex"] - (0 if name == "textbook" else 1)))
+    assert np.allclose(cf, cf_g, rtol=2e-6, atol=1e-5)  # atol: float32 rounding of S (ulp(100) = 7.6e-6)
+    assert abs(o["price"] - cf_g.mean()) <= 2e-6 * cf_g.mean()
+
+
+@pytest.mark.parametrize("name", ["ref", "textbook", "twopass"])
+def test_numpy_flows_reproduce_golden_exactly(golden, name):
+    g, pf = golden["paths"], golden["poly"]
+    S = g["gbm_mid_S"]
+    if name == "twopass":
+        reg, pred = rf.two_pass_poly_regressor(K)
+        cf, ex, _ = rf.lsm_two_pass(S, K, R, T, True, reg, pred)
+    else:
+        cf, ex, _, _ = rf.lsm_per_step(S, K, R, T, True, textbook=(name == "textbook"))
+    assert np.array_equal(ex, pf[f"poly_mid_put_{name}_ex"])
+    assert np.allclose(cf, pf[f"poly_mid_put_{name}_cf"], rtol=1e-12, atol=0)
+
+
+def _c1_paths(golden):
+    c1 = golden["scalars"]["c1_seed42_gbm_put"]
+    z_half = rf.RNGManager(42).get_child_rng().standard_normal((50, 5000))
+    assert z_half.sum() == c1["zhalf_sum"] and list(z_half.ravel()[:4]) == c1["zhalf_first4"]
+    return c1, rf.gbm_paths_from_normals(z_half, 100.0, R, SIG, T)
+
+
+def test_c1_anchors_seed42(golden):
+    """10k x 50 ATM put on the reference's seed-42 paths (SURVEY section 6 / BASELINE.md)."""
+    c1, S = _c1_paths(golden)
+    assert S[-1].sum() == c1["S_T_sum"]
+    cf, ex, _, nitm = rf.lsm_per_step(S, K, R, T, True)
+    assert cf.mean() == pytest.approx(c1["poly_ref_price"], rel=1e-12)
+    assert int(nitm.sum()) == c1["poly_ref_sum_nitm"] and ex.mean() == c1["poly_ref_exercised_frac"]
+    cf, *_ = rf.lsm_per_step(S, K, R, T, True, textbook=True)
+    assert cf.mean() == pytest.approx(c1["poly_textbook_price"], rel=1e-12)
+    reg, pred = rf.two_pass_ols7_regressor(K, T, 50)
+    cf, ex, model = rf.lsm_two_pass(S, K, R, T, True, reg, pred)
+    assert model["R"] == c1["R"]
+    assert model["Y_mean"] == pytest.approx(c1["Y_mean"], rel=1e-13)
+    assert model["Y_std"] == pytest.approx(c1["Y_std"], rel=1e-13)
+    assert cf.mean() == pytest.approx(c1["ols7_twopass_price"], rel=1e-9)
+    # float32-path C oracle on the same paths: same decisions up to a handful of paths
+    S32 = S.astype(np.float32)
+    for sem, key in (("reference", "poly_ref_price"), ("textbook", "poly_textbook_price"),
+                     ("two_pass", "poly_twopass_price")):
+        o = orc.lsm_poly(S32, K, R, T, True, sem)
+        assert o["price"] == pytest.approx(c1[key], rel=2e-5)
+    assert o["sum_nitm"] == c1["poly_twopass_sum_nitm_pass1"] == c1["R"]
+
+
+def test_frozen_mlp_pass2_reproduces_reference_decisions(golden):
+    """G4: the reference's own trained net (eval mode) replayed by the numpy restatement."""
+    nn = golden["nn"]
+    for tag, hes in (("gbm_put", False), ("heston_call", True)):
+        S0, Kp, r, sig, Tm, is_put, hidden = nn[f"{tag}_params"]
+        S = nn[f"{tag}_S"]
+        N = S.shape[0] - 1
+        state = {k[len(tag) + 4:]: nn[k] for k in nn.files if k.startswith(f"{tag}_sd_")}
+        Ym, Ys = nn[f"{tag}_Y_mean_std"]
+        reg, pred = rf.two_pass_frozen_mlp_regressor(Kp, Tm, N, state, nn[f"{tag}_feat_mean"],
+                                                     nn[f"{tag}_feat_std"], Ym, Ys)
+        cf, ex, _ = rf.lsm_two_pass(S, Kp, r, Tm, bool(is_put), reg, pred)
+        flips = int((ex != nn[f"{tag}_ex_eval"]).sum())
+        assert flips <= 2, flips  # float32 matmul order (numpy vs torch) can flip a boundary path
+        assert abs(cf.mean() - float(nn[f"{tag}_price_eval"])) < 2e-3 * float(nn[f"{tag}_price_eval"])
+        # normalisers restated from the paths alone
+        rows = []
+        disc = np.exp(-r * Tm / N)
+        c = rf.payoff(S[-1], Kp, bool(is_put)).astype(np.float64)
+        for t in range(N - 1, 0, -1):
+            c *= disc
+            itm = rf.payoff(S[t], Kp, bool(is_put)) > 0
+            if itm.any():
+                rows.append((t, S[t, itm], c[itm]))
+        _, _, fm, fs, ym, ys = rf.normalisers(rows, Kp, Tm, Tm / N)
+        assert np.array_equal(fm, nn[f"{tag}_feat_mean"]) and np.array_equal(fs, nn[f"{tag}_feat_std"])
+        assert (ym, ys) == (Ym, Ys)
+
+
+def test_reference_end_to_end_scalars_recorded(golden):
+    e2e = golden["scalars"]["end_to_end_10k_x_50_seed42"]
+    assert e2e["gbm_put_cv_off"] == 6.812542119814994
+    assert e2e["gbm_put_cv_on"] == 6.803039032349685
+    assert e2e["heston_call_cv_off"] == 10.346080827233468
+
+
+def test_philox_paths_statistics():
+    S = orc.gbm_paths(200_000, 16, 100.0, R, SIG, T, 99)
+    x = S[-1].astype(np.float64)
+    assert abs(x.mean() - 100 * np.exp(R * T)) < 5 * x.std() / np.sqrt(x.size)
+    s, q = orc.european_from_paths(S, K, R, T, True)
+    bs = rf.black_scholes_price(100, 100, 1, R, SIG, "put")
+    n = S.shape[1]
+    assert abs(s / n - bs) < 5 * np.sqrt((q / n - (s / n) ** 2) / n)
+    # shard invariance of the oracle's counter layout
+    a = orc.gbm_paths(1000, 8, 100.0, R, SIG, T, 1, 0, 0)
+    b = orc.gbm_paths(500, 8, 100.0, R, SIG, T, 1, 0, 250)
+    assert np.array_equal(b[:, :250], a[:, 250:500]) and np.array_equal(b[:, 250:], a[:, 750:])
