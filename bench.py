@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: whole American-option pricings per second on MI355X.
+
+One "step" = one full pricing of the workload through the C ABI (libomc.so):
+Philox/Box-Muller path generation into the [step][path] float32 matrix -> polynomial
+Longstaff-Schwartz backward induction -> discounted mean.  Nothing is cached between
+steps (each step uses a fresh Philox sub-stream); inputs are scalars, so there is no
+host->device data and `value` is the HBM-resident rate by construction.
+
+Workload (BASELINE.json configs[1]): GBM American put, S0=K=100, r=5%, sigma=20%, T=1,
+1,000,000 paths x 252 steps per GPU, polynomial LSM.  With N GPUs every rank prices its
+own 1M-path shard of an N x 1M-path problem (weak scaling; BASELINE configs[2] is the
+same thing at 8M paths per GPU: --paths-per-gpu 8000000), moments and sums all-reduced
+over RCCL.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      path-generation kernel: algorithmic bytes (n_steps+1)*n_paths*4 per launch
+                / mean HIP-event duration of that launch inside the timed region, vs 8 TB/s
+  roofline_lsm  the backward induction as a whole (all its kernels), same accounting
+  cpu_baseline  the C oracle (oracle/, a port: the reference is Python) on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
+
+
+def lsm_algorithmic_bytes(semantics: str, M: int, N: int) -> float:
+    """DESIGN.md 'Algorithmic bytes': what the backward induction must move per pricing."""
+    if semantics == "two_pass":
+        # pass 1 reads S rows 1..N-1 once (+ terminal row), pass 2 reads them again
+        return 2.0 * 4 * M * N
+    # per-step sweep t: S_t, S_{t-1} (4+4), state sx/tex (4+4) per path
+    return 16.0 * M * (N - 1) + 12.0 * M
+
+
+def cpu_baseline(M, N, semantics, budget_s=25.0):
+    """Oracle port timed on this host, bounded sample of the same workload."""
+    from oracle import cpu as orc
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    # size the sample so the CPU leg stays ~10-30 s: probe with 1/50 of the paths
+    probe = max(2000, (M // 50) // 4 * 4)
+    t0 = time.perf_counter()
+    S = orc.gbm_paths(probe, N, 100.0, 0.05, 0.2, 1.0, 42)
+    orc.lsm_poly(S, 100.0, 0.05, 1.0, True, semantics)
+    dt = time.perf_counter() - t0
+    frac = min(1.0, budget_s / max(dt * M / probe, 1e-9))
+    Ms = max(probe, int(M * frac) // 4 * 4)
+    t0 = time.perf_counter()
+    S = orc.gbm_paths(Ms, N, 100.0, 0.05, 0.2, 1.0, 42)
+    t1 = time.perf_counter()
+    res = orc.lsm_poly(S, 100.0, 0.05, 1.0, True, semantics)
+    t2 = time.perf_counter()
+    return {
+        "value": Ms * N / (t2 - t0), "unit": "path-steps/s", "cores": threads, "kind": "port",
+        "sample": f"{Ms} paths x {N} steps, same workload/semantics; path-gen {t1 - t0:.2f}s "
+                  f"(OpenMP x{threads}) + LSM sweep {t2 - t1:.2f}s (1 thread); C oracle, f32 paths/f64 sums",
+        "price": res["price"],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--paths-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--n-steps", type=int, default=252)
+    ap.add_argument("--semantics", default="two_pass", choices=["two_pass", "reference", "textbook"])
+    ap.add_argument("--model", default="gbm", choices=["gbm", "heston"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    M, N = a.paths_per_gpu, a.n_steps
+
+    import torch
+    from options_model_amd import _ffi, dist as omc_dist
+
+    if not torch.cuda.is_available() or _ffi.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        pricer = omc_dist.ShardedPricer(local_rank)
+        barrier = td.barrier
+    else:
+        pricer = None
+        ctx = _ffi.Context(local_rank)
+        barrier = lambda: None  # noqa: E731
+
+    kw = dict(model=a.model, is_put=(a.model == "gbm"), semantics=a.semantics, n_steps=N, seed=42)
+
+    def one_step(i):
+        if pricer is not None:
+            out = pricer.price_american(M * world, stream=i, **kw)
+            return out, out["local"]
+        out = ctx.price_american(_ffi.make_params(n_paths=M, stream=i, **kw))
+        return out, out
+
+    for i in range(a.warmup):
+        one_step(1000 + i)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_paths = ms_lsm = 0.0
+    price = 0.0
+    for i in range(a.steps):
+        out, loc = one_step(i)
+        ms_paths += loc["ms_paths"]
+        ms_lsm += loc["ms_lsm"]
+        price = out["price"]
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as td
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_paths /= a.steps
+    ms_lsm /= a.steps
+    b_gen = 4.0 * (N + 1) * M
+    b_lsm = lsm_algorithmic_bytes(a.semantics, M, N)
+    line = {
+        "metric": "paths x steps / sec (whole American pricing: path-gen + LSM + mean)",
+        "value": world * M * N * a.steps / elapsed,
+        "unit": "path-steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.model.upper()} American {'put' if a.model == 'gbm' else 'call'}, "
+                               f"S0=K=100 r=0.05 sigma=0.2 T=1, {M} paths x {N} steps per GPU, "
+                               f"polynomial LSM [1,u,u^2] ({a.semantics} flow)",
+                   "paths_per_gpu": M, "n_steps": N, "semantics": a.semantics,
+                   "parallelism": f"path-sharded x{world}" if world > 1 else "single GPU",
+                   "rng": "Philox4x32-10 + Box-Muller, antithetic"},
+        "paths_x252_per_sec_per_gpu": M * N * a.steps / elapsed / 252.0,
+        "price": price,
+        "roofline": {"kernel": f"{a.model}_paths_kernel", "bound": "hbm",
+                     "achieved": b_gen / (ms_paths * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b_gen / (ms_paths * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "bytes_per_launch": b_gen, "ms_per_launch": ms_paths, "traffic": None},
+        "roofline_lsm": {"kernel": "lsm_* (all kernels of the backward induction)", "bound": "hbm",
+                         "achieved": b_lsm / (ms_lsm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b_lsm / (ms_lsm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "bytes_per_pricing": b_lsm, "ms_per_pricing": ms_lsm, "traffic": None},
+    }
+    # measured PMC traffic, if a profile summary for this round was committed
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            pt = json.load(open(prof))
+            line["roofline"]["traffic"] = pt.get("paths_kernel_bytes_per_launch")
+            line["roofline_lsm"]["traffic"] = pt.get(f"lsm_{a.semantics}_bytes_per_pricing")
+        except Exception:
+            pass
+
+    if world == 1 and not a.no_variants:
+        var = {}
+        for sem in ("two_pass", "reference", "textbook"):
+            if sem == a.semantics:
+                continue
+            k2 = dict(kw, semantics=sem)
+            ctx.price_american(_ffi.make_params(n_paths=M, stream=77, **k2))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = max(3, a.steps // 4)
+            for i in range(reps):
+                o = ctx.price_american(_ffi.make_params(n_paths=M, stream=i, **k2))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            var[sem] = {"path_steps_per_s": M * N / dt, "ms_per_pricing": 1e3 * dt, "ms_lsm": o["ms_lsm"],
+                        "price": o["price"]}
+        line["variants"] = var
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(M, N, a.semantics)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as td
+        pricer.close()
+        td.destroy_process_group()
+    else:
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()

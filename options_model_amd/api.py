@@ -1,0 +1,128 @@
+"""North-star facade (BASELINE.json):
+
+    price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model='GBM'|'Heston', ...)
+
+A thin host-side wrapper over the C ABI (include/omc.h).  The reference has no function with
+this exact signature; its three real call shapes are mirrored in
+`options_model_amd.pricer` (options_model_3.py) and `options_model_amd.compat`
+(Options_model.py, options_model_2.py).
+
+semantics (the reference's exercise rule is not textbook LSM, and it is kept):
+  "two_pass"  (default) control flow of options_model_3/options_model_3.py:482-651: pass 1
+              regresses discounted TERMINAL payoffs with no decisions, pass 2 applies the
+              sticky rule; valued at t = dt.  Moments are decision-independent -> one
+              all-reduce across GPUs.
+  "per_step"  control flow of Options_model.py:108-157 / options_model_2.py:278-313:
+              regress-and-decide per time step with the sticky `exercised` mask.
+  "textbook"  classic Longstaff-Schwartz (overwrite on earlier exercise, discounted to t=0).
+regressor:
+  "poly"      OLS on [1,u,u^2], u=S/K-1, one fit per time step (the reference validates
+              lsm_poly_degree and then ignores it: Options_model.py:53,69-70)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+from . import _ffi
+
+_SEM = {"two_pass": "two_pass", "v3": "two_pass", "reference_v3": "two_pass",
+        "per_step": "reference", "v1": "reference", "reference_v1": "reference",
+        "textbook": "textbook"}
+
+
+@dataclass
+class PriceResult:
+    price: float
+    stderr: float
+    std: float
+    zero_prob: float
+    n_paths: int
+    n_exercised: int
+    sum_nitm: int
+    model: str
+    semantics: str
+    option_type: str
+    timings_ms: dict = field(default_factory=dict)
+
+    def __float__(self):
+        return float(self.price)
+
+
+def _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=True):
+    # same checks and messages as options_model_3.py:447-452,471-472 / Options_model.py:63-72
+    if S0 <= 0 or K <= 0 or T <= 0:
+        raise ValueError("S0, K, T must be positive.")
+    if r < 0:
+        raise ValueError("r must be non-negative.")
+    if n_paths <= 0 or n_steps <= 0:
+        raise ValueError("num_simulations and num_time_steps must be positive integers.")
+    if option_type not in ("call", "put"):
+        raise ValueError("option_type must be 'call' or 'put'.")
+    if need_sigma and (sigma is None or sigma <= 0):
+        raise ValueError("sigma is None: provide sigma, iv_model, or heston configuration"
+                         if sigma is None else "S0, K, T, and sigma must be positive.")
+
+
+def heston_defaults(sigma, heston_params=None):
+    """kappa=2, xi=0.3, rho=-0.7, v0=theta=sigma^2: the reference's hard-coded defaults
+    (options_model_3.py:948-950,995-996; options_model_2_ui.py:74-80)."""
+    hp = dict(v0=(sigma or 0.2) ** 2, kappa=2.0, theta=(sigma or 0.2) ** 2, xi=0.3, rho=-0.7)
+    if heston_params:
+        hp.update({k: float(v) for k, v in heston_params.items() if k in hp})
+    return hp
+
+
+def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", option_type="put",
+                          regressor="poly", semantics="two_pass", heston_params=None,
+                          heston_scheme="reference", antithetic=True, seed=42, stream=0,
+                          device=0, ctx=None) -> PriceResult:
+    model_l = str(model).lower()
+    if model_l not in ("gbm", "heston"):
+        raise ValueError("model must be 'GBM' or 'Heston'.")
+    if semantics not in _SEM:
+        raise ValueError(f"semantics must be one of {sorted(set(_SEM))}.")
+    if regressor != "poly":
+        if regressor == "nn":
+            from . import nn_regressor
+            return nn_regressor.price_american_option_nn(
+                S0, K, r, sigma, T, n_paths, n_steps, model=model, option_type=option_type,
+                heston_params=heston_params, seed=seed, stream=stream, device=device)
+        raise ValueError("regressor must be 'poly' or 'nn'.")
+    _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
+    M = int(n_paths) // 2 * 2 if antithetic else int(n_paths)  # options_model_3.py:458
+    if M <= 0:
+        raise ValueError("num_simulations and num_time_steps must be positive integers.")
+    hp = heston_defaults(sigma, heston_params)
+    c = ctx or _ffi.default_context(device)
+    p = _ffi.make_params(model=model_l, is_put=(option_type == "put"), semantics=_SEM[semantics],
+                         antithetic=antithetic, heston_scheme=heston_scheme, n_paths=M,
+                         n_steps=int(n_steps), S0=S0, K=K, r=r, sigma=sigma or 0.0, T=T,
+                         seed=seed, stream=stream, **hp)
+    out = c.price_american(p)
+    var = max(out["sumsq"] / M - out["price"] ** 2, 0.0)
+    return PriceResult(price=out["price"], stderr=math.sqrt(var / M), std=out["std"],
+                       zero_prob=out["zero_prob"], n_paths=M, n_exercised=out["n_exercised"],
+                       sum_nitm=out["sum_nitm"], model=model_l, semantics=semantics,
+                       option_type=option_type,
+                       timings_ms=dict(paths=out["ms_paths"], lsm=out["ms_lsm"], total=out["ms_total"]))
+
+
+def price_european_option(S0, K, r, sigma, T, n_paths, n_steps=1, model="GBM", option_type="put",
+                          heston_params=None, heston_scheme="reference", antithetic=True, seed=42,
+                          stream=0, device=0, ctx=None) -> PriceResult:
+    """Discounted terminal payoff mean; no path matrix is stored (options_model_3.py:382-437)."""
+    model_l = str(model).lower()
+    _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
+    M = int(n_paths) // 2 * 2 if antithetic else int(n_paths)
+    hp = heston_defaults(sigma, heston_params)
+    c = ctx or _ffi.default_context(device)
+    p = _ffi.make_params(model=model_l, is_put=(option_type == "put"), antithetic=antithetic,
+                         heston_scheme=heston_scheme, n_paths=M, n_steps=int(n_steps), S0=S0, K=K,
+                         r=r, sigma=sigma or 0.0, T=T, seed=seed, stream=stream, **hp)
+    out = c.price_european(p)
+    var = max(out["sumsq"] / M - out["price"] ** 2, 0.0)
+    return PriceResult(price=out["price"], stderr=math.sqrt(var / max(M - 1, 1)), std=out["std"],
+                       zero_prob=out["zero_prob"], n_paths=M, n_exercised=0, sum_nitm=0,
+                       model=model_l, semantics="european", option_type=option_type,
+                       timings_ms=dict(total=out["ms_total"]))

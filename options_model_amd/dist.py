@@ -1,0 +1,97 @@
+"""Path sharding across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+The reference has no distributed code at all (its only parallelism is a ProcessPoolExecutor
+over S0 values, options_model_3.py:1053).  Paths are independent, so they shard by antithetic
+pair; the Philox counter carries the GLOBAL pair index, hence the simulated path set -- and
+the price -- does not depend on the number of shards.  Only two things cross GPUs:
+
+  * regression moments: the two-pass flow's moments do not depend on exercise decisions, so
+    the whole [n_steps+1][8] table goes in ONE all-reduce (~16 KB at 252 steps); the per-step
+    flows need 8 doubles per time step (sequential by data dependence);
+  * the final {sum, sumsq, counts}: one all-reduce of 6 doubles.
+"""
+from __future__ import annotations
+
+import math
+
+
+def shard(n_paths_global: int, world: int, rank: int, antithetic: bool = True):
+    """-> (n_paths_local, pair_offset).  Shards are equal; pairs stay together."""
+    unit = 2 if antithetic else 1
+    if n_paths_global % (unit * world):
+        raise ValueError(f"n_paths={n_paths_global} must be a multiple of {unit * world} "
+                         f"({'pairs' if antithetic else 'paths'} x ranks)")
+    local = n_paths_global // world
+    return local, rank * (local // unit)
+
+
+SUM_KEYS = ("sum", "sumsq", "n_paths", "n_exercised", "n_zero", "sum_nitm")
+
+
+def merge(local: dict, all_reduce_sum) -> dict:
+    """Combine per-shard results.  `all_reduce_sum(list[float]) -> list[float]`."""
+    tot = all_reduce_sum([float(local[k]) for k in SUM_KEYS])
+    out = dict(zip(SUM_KEYS, tot))
+    n = out["n_paths"]
+    out["price"] = out["sum"] / n
+    var = max(out["sumsq"] / n - out["price"] ** 2, 0.0)
+    out["std"] = math.sqrt(var)
+    out["stderr"] = math.sqrt(var / n)
+    out["zero_prob"] = out["n_zero"] / n
+    for k in ("n_paths", "n_exercised", "n_zero", "sum_nitm"):
+        out[k] = int(round(out[k]))
+    return out
+
+
+class _DevPtr:
+    """Expose a raw device pointer to torch (no ownership) via __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class ShardedPricer:
+    """One per rank.  Requires torch.distributed to be initialised (nccl) and a GPU."""
+
+    def __init__(self, local_rank: int, group=None):
+        import torch
+        import torch.distributed as dist
+
+        from . import _ffi
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        # kernels and RCCL collectives are ordered on torch's current stream: no host syncs
+        self.ctx = _ffi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        self._ffi = _ffi
+        self._sums = torch.zeros(len(SUM_KEYS), dtype=torch.float64, device=self.device)
+        if self.world > 1:
+            self.ctx.set_allreduce_hook(self._allreduce_device)
+
+    def _allreduce_device(self, dptr: int, count: int):
+        t = self.torch.as_tensor(_DevPtr(dptr, count), device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def _allreduce_host(self, vals):
+        self._sums.copy_(self.torch.tensor(vals, dtype=self.torch.float64))
+        if self.world > 1:
+            self.dist.all_reduce(self._sums, op=self.dist.ReduceOp.SUM, group=self.group)
+        return self._sums.tolist()
+
+    def price_american(self, n_paths_global: int, **kw) -> dict:
+        """kw: arguments of _ffi.make_params except n_paths / pair_offset."""
+        anti = kw.get("antithetic", True)
+        n_local, off = shard(n_paths_global, self.world, self.rank, anti)
+        p = self._ffi.make_params(n_paths=n_local, pair_offset=off, **kw)
+        local = self.ctx.price_american(p)
+        out = merge(local, self._allreduce_host)
+        out["local"] = local
+        return out
+
+    def close(self):
+        self.ctx.close()

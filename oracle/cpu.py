@@ -52,6 +52,8 @@ def lib():
                                               C.c_void_p, C.POINTER(LsmResult), C.c_void_p,
                                               C.c_void_p]
         _lib.orc_lsm_apply_frozen.restype = C.c_int
+        _lib.orc_lsm_pass1_moments.argtypes = [f32p, i64, i64, i32, dbl, dbl, dbl, i32, C.c_void_p]
+        _lib.orc_solve_poly2.argtypes = [C.c_void_p, C.c_void_p]
         _lib.orc_european_from_paths.argtypes = [f32p, i64, i64, i32, dbl, dbl, dbl, i32,
                                                  C.c_void_p, C.c_void_p]
     return _lib
@@ -147,3 +149,24 @@ def european_from_paths(S, K, r, T, is_put):
     s, q = C.c_double(), C.c_double()
     lib().orc_european_from_paths(_p(S), M, M, N, K, r, T, int(is_put), C.byref(s), C.byref(q))
     return s.value, q.value
+
+
+def lsm_pass1_moments(S, K, r, T, is_put):
+    S = np.ascontiguousarray(S, np.float32)
+    N, M = S.shape[0] - 1, S.shape[1]
+    m = np.zeros((N + 1, 8))
+    lib().orc_lsm_pass1_moments(_p(S), M, M, N, K, r, T, int(is_put), _p(m))
+    return m
+
+
+def solve_poly2(moments):
+    """moments [N+1][8] -> betas4 [N+1][4] (b0,b1,b2,n)"""
+    m = np.ascontiguousarray(moments, np.float64)
+    out = np.zeros((m.shape[0], 4))
+    b = np.zeros(3)
+    for t in range(m.shape[0]):
+        row = m[t].copy()
+        lib().orc_solve_poly2(_p(row), _p(b))
+        out[t, :3] = b
+        out[t, 3] = row[0]
+    return out

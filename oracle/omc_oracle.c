@@ -410,3 +410,30 @@ void orc_european_from_paths(const float *S, int64_t ld, int64_t n_paths, int n_
     }
     *sum = s; *sumsq = q;
 }
+
+/* ---- pieces of the two-pass flow exposed separately (multi-process sharding tests):
+ * pass-1 moments [n_steps+1][8] of a shard, and the per-step solve on (all-reduced) moments */
+void orc_lsm_pass1_moments(const float *S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                           double r, double T, int is_put, double *moments)
+{
+    const int N = n_steps;
+    const double dt = T / N, invK = 1.0 / K;
+    const float *SN = S + (int64_t)N * ld;
+    memset(moments, 0, sizeof(double) * 8 * (size_t)(N + 1));
+    for (int t = N - 1; t >= 1; --t) {
+        const float *St = S + (int64_t)t * ld;
+        double *m = moments + 8 * (size_t)t;
+        const double d = exp(-r * dt * (double)(N - t));
+        for (int64_t j = 0; j < n_paths; ++j) {
+            double imm = payoff_d((double)St[j], K, is_put);
+            if (!(imm > 0.0)) continue;
+            double pN = payoff_d((double)SN[j], K, is_put);
+            double y = (pN > 0.0 ? pN : 0.0) * d;
+            double u = fma((double)St[j], invK, -1.0), u2 = u * u;
+            m[0] += 1.0; m[1] += u; m[2] += u2; m[3] += u2 * u; m[4] += u2 * u2;
+            m[5] += y; m[6] += u * y; m[7] += u2 * y;
+        }
+    }
+}
+
+void orc_solve_poly2(const double m[8], double beta[3]) { solve_poly2(m, beta); }
