@@ -66,7 +66,7 @@ def cpu_baseline(M, N, semantics, budget_s=25.0):
     return {
         "value": Ms * N / (t2 - t0), "unit": "path-steps/s", "cores": threads, "kind": "port",
         "sample": f"{Ms} paths x {N} steps, same workload/semantics; path-gen {t1 - t0:.2f}s "
-                  f"(OpenMP x{threads}) + LSM sweep {t2 - t1:.2f}s (1 thread); C oracle, f32 paths/f64 sums",
+                  f"+ LSM sweeps {t2 - t1:.2f}s, both OpenMP x{threads}; C oracle, f32 paths/f64 sums",
         "price": res["price"],
     }
 

@@ -1,0 +1,48 @@
+"""v1 functional surface (reference Options_model.py:44-157, :190-211) on the GPU hot path.
+
+Flow kept: per-time-step regress-and-decide with the sticky `exercised` mask, valued at t=dt
+(Options_model.py:108-157); the per-step ContNet is replaced by OLS on [1,u,u^2].  As in the
+reference every pricing reseeds with `seed`, so all points of a curve share their normals
+(common random numbers across maturities, Options_model.py:74,197).
+"""
+from __future__ import annotations
+
+import math
+
+from .. import _ffi
+
+
+def price_american_option(S0, K, T, r, sigma, num_simulations=10000, num_time_steps=50,
+                          option_type="call", lsm_poly_degree=2, plot_paths=False, seed=42):
+    """-> (mean, std, probability the option ends worthless)"""
+    if S0 <= 0 or K <= 0 or T <= 0 or sigma <= 0:
+        raise ValueError("S0, K, T, and sigma must be positive.")
+    if r < 0:
+        raise ValueError("r must be non-negative.")
+    if num_simulations <= 0 or num_time_steps <= 0:
+        raise ValueError("num_simulations and num_time_steps must be positive integers.")
+    if not isinstance(lsm_poly_degree, int) or lsm_poly_degree < 0:
+        raise ValueError("lsm_poly_degree must be a non-negative integer.")
+    if option_type not in ("call", "put"):
+        raise ValueError("option_type must be 'call' or 'put'.")
+    M = int(num_simulations) // 2 * 2
+    if M == 0:
+        raise ValueError("num_simulations and num_time_steps must be positive integers.")
+    p = _ffi.make_params(model="gbm", is_put=(option_type == "put"), semantics="reference",
+                         n_paths=M, n_steps=int(num_time_steps), S0=S0, K=K, r=r, sigma=sigma, T=T,
+                         seed=int(seed), stream=0)
+    out = _ffi.default_context().price_american(p)
+    return out["price"], out["std"], out["zero_prob"]
+
+
+def compute_curve_for_S0(S0, K, r, sigma, num_simulations, intervals_per_day, total_points,
+                         option_type, lsm_poly_degree, plot_paths, seed):
+    records = []
+    for i in range(total_points, 0, -1):
+        d = i / intervals_per_day
+        steps = max(10, min(130, int(math.ceil(d))))
+        price, std, zero = price_american_option(S0, K, d / 365, r, sigma, num_simulations, steps,
+                                                 option_type, lsm_poly_degree, plot_paths, seed)
+        records.append({"S0": S0, "Days to Expiry": d, "Option Value": price, "Std Dev": std,
+                        "Zero Prob": zero})
+    return records

@@ -1,0 +1,82 @@
+"""v2 class surface (reference options_model_2.py:176-355, :443-457) on the GPU hot path:
+`OptionPricer` and the `compute_curve_worker` that options_model_2_ui.py imports.
+
+Same per-step sticky flow as v1; Heston paths are antithetic here (v2's simulator is not,
+options_model_2.py:150-170) -- a variance reduction, not a change of distribution.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Any, Dict, List, Optional
+
+from .. import _ffi
+from ..api import heston_defaults
+
+
+class OptionPricer:
+    def __init__(self, K: float, r: float, sigma: Optional[float], option_type: str = "call",
+                 lsm_poly_degree: int = 2, seed: int = 42, use_heston: bool = False,
+                 heston_params: Optional[Dict[str, Any]] = None, nn_hidden: int = 32,
+                 nn_epochs: int = 10, nn_lr: float = 1e-3, verbose: bool = False):
+        self.K, self.r, self.sigma, self.option_type = K, r, sigma, option_type
+        self.lsm_poly_degree, self.seed = lsm_poly_degree, seed
+        self.use_heston, self.heston_params = use_heston, heston_params
+        self.nn_hidden, self.nn_epochs, self.nn_lr, self.verbose = nn_hidden, nn_epochs, nn_lr, verbose
+        self.last_result: Optional[dict] = None
+
+    def price_american_option(self, S0: float, T: float, num_simulations: int = 10000,
+                              num_time_steps: int = 50, plot_paths: bool = False) -> float:
+        if S0 <= 0 or self.K <= 0 or T <= 0 or (self.sigma is None and not self.use_heston):
+            raise ValueError("S0, K, T, and sigma must be positive.")
+        if self.r < 0:
+            raise ValueError("r must be non-negative.")
+        if num_simulations <= 0 or num_time_steps <= 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        if not isinstance(self.lsm_poly_degree, int) or self.lsm_poly_degree < 0:
+            raise ValueError("lsm_poly_degree must be a non-negative integer.")
+        if self.option_type not in ("call", "put"):
+            raise ValueError("option_type must be 'call' or 'put'.")
+        M = int(num_simulations) // 2 * 2
+        if M == 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        if self.use_heston and self.heston_params is not None:
+            kw = dict(model="heston", **heston_defaults(self.sigma, self.heston_params))
+        else:
+            kw = dict(model="gbm")
+        p = _ffi.make_params(is_put=(self.option_type == "put"), semantics="reference", n_paths=M,
+                             n_steps=int(num_time_steps), S0=S0, K=self.K, r=self.r,
+                             sigma=self.sigma or 0.0, T=T, seed=int(self.seed), stream=0, **kw)
+        out = _ffi.default_context().price_american(p)
+        self.last_result = out
+        if self.verbose:
+            logging.info(f"Probability option expires worthless: {out['zero_prob']:.2%}")
+            logging.info(f"Estimated American {self.option_type} price: ${out['price']:.4f} "
+                         f"(S0={S0}, K={self.K}, T={T}, r={self.r}, sigma={self.sigma}, "
+                         f"simulations={num_simulations}, steps={num_time_steps}, heston={self.use_heston})")
+        return out["price"]
+
+    def compute_curve_for_S0(self, S0: float, intervals_per_day: int, total_points: int,
+                             num_simulations: int, plot_paths: bool) -> List[Dict[str, Any]]:
+        records = []
+        for i in range(total_points, 0, -1):
+            d = i / intervals_per_day
+            steps = max(10, min(130, int(math.ceil(d))))
+            price = self.price_american_option(S0, d / 365, num_simulations, steps, plot_paths)
+            records.append({"S0": S0, "Days to Expiry": d, "Option Value": price})
+        return records
+
+
+def compute_curve_worker(S0, K, r, sigma, option_type, lsm_poly_degree, seed, intervals_per_day,
+                         total_points, num_simulations, plot_paths, use_heston, heston_params,
+                         nn_hidden=32, nn_epochs=10, nn_lr=1e-3, verbose=False):
+    """Never raises (returns []), like the reference worker (options_model_2.py:455-457)."""
+    try:
+        pricer = OptionPricer(K, r, sigma, option_type, lsm_poly_degree, seed, use_heston,
+                              heston_params, nn_hidden=nn_hidden, nn_epochs=nn_epochs, nn_lr=nn_lr,
+                              verbose=verbose)
+        return pricer.compute_curve_for_S0(S0, intervals_per_day, total_points, num_simulations,
+                                           plot_paths)
+    except Exception as e:  # noqa: BLE001
+        logging.error(f"Error in worker for S0={S0}: {e}")
+        return []

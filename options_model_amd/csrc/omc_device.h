@@ -88,6 +88,35 @@ __device__ __forceinline__ double block_reduce8(const double (&acc)[kNQ], double
     return s;
 }
 
+// ------------------------------------------------------------------ wave reduction
+// Same job for ONE wave, no workgroup barrier: the 64 lanes transpose their 8 accumulators
+// through a wave-private LDS patch (DS instructions of a wave execute in order), each lane
+// then owns 1/8 of one quantity, and three xor-shuffles finish inside groups of 8 lanes.
+// ~8 ds_write_b64 + 8 ds_read_b64 + 3 shuffles instead of 48 shuffles.  Row stride 72 doubles
+// puts the (q, sub) read pattern on distinct banks.  Every lane returns the total of quantity
+// lane >> 3.
+constexpr int kWaveRedStride = 72;
+constexpr int kWaveRedDoubles = kNQ * kWaveRedStride;
+
+__device__ __forceinline__ double wave_reduce8(const double (&acc)[kNQ], double* wl)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) wl[q * kWaveRedStride + lane] = acc[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double* p = wl + (lane >> 3) * kWaveRedStride + (lane & 7);
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += p[8 * i];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    __builtin_amdgcn_wave_barrier();
+    return s;
+}
+
 // ------------------------------------------------------------------ 3x3 OLS solve
 // y ~ b0 + b1 u + b2 u^2 from m = {n, Su, Su2, Su3, Su4, Sy, Suy, Su2y}; centred LDL^T,
 // degree reduced to n-1 for n < 3 or when a pivot is not safely positive.

@@ -93,6 +93,26 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(StepArgs a)
         for (int k = tid; k <= N; k += kBlock) sh_D[k] = a.D[k];
     }
 
+    // Issue this thread's first row/state loads BEFORE the prologue: their HBM latency then
+    // overlaps the partial-moment reduction and the 3x3 solve.
+    const float* St = a.S + (int64_t)t * a.ld;
+    const float* Sm = a.S + (int64_t)(t - 1) * a.ld;
+    const int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
+    int64_t j = ((int64_t)blockIdx.x * kBlock + tid) * VEC;
+    float st[VEC], sm[VEC], sx[VEC];
+    int32_t tex[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { st[v] = sm[v] = sx[v] = 0.f; tex[v] = 0; }
+    auto load_chunk = [&](int64_t jj) {
+        loadf<VEC>(St + jj, st);
+        if (do_mom) loadf<VEC>(Sm + jj, sm);
+        if (!init) {
+            loadf<VEC>(a.sx + jj, sx);
+            loadi<VEC>(a.tex + jj, tex);
+        }
+    };
+    if (j < a.M) load_chunk(j);
+
     double b0 = 0.0, b1 = 0.0, b2 = 0.0, nfit = 0.0;
     if (do_apply) {
         if (a.external) {
@@ -137,23 +157,13 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(StepArgs a)
     const double Dm = do_mom ? a.D[N - (t - 1)] : 0.0;
     const double K = a.K, invK = a.invK;
     const int is_put = a.is_put;
-    const float* St = a.S + (int64_t)t * a.ld;
-    const float* Sm = a.S + (int64_t)(t - 1) * a.ld;
     const bool fit_ok = do_apply && nfit > 0.5;
-    const int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
-    for (int64_t j = ((int64_t)blockIdx.x * kBlock + tid) * VEC; j < a.M; j += stride) {
-        float st[VEC], sm[VEC], sx[VEC];
-        int32_t tex[VEC];
-        loadf<VEC>(St + j, st);
-        if (do_mom) loadf<VEC>(Sm + j, sm);
+    while (j < a.M) {
         bool changed = false;
         if (init) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { sx[v] = st[v]; tex[v] = N; }
             changed = true;
-        } else {
-            loadf<VEC>(a.sx + j, sx);
-            loadi<VEC>(a.tex + j, tex);
         }
         if (fit_ok) {
 #pragma unroll
@@ -182,6 +192,8 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(StepArgs a)
                 }
             }
         }
+        j += stride;
+        if (j < a.M) load_chunk(j);
     }
     if (do_mom) {
         const double s = block_reduce8(acc, red);
@@ -222,46 +234,72 @@ struct Pass1Args {
 };
 
 // Pass 1 (options_model_3.py:482-516): no decisions, so every time step is independent.
-// grid = (path tiles, step chunks).  Targets are the discounted TERMINAL payoffs.
-template <int VEC>
+// Work item = one WAVE x (TPW tiles of 64*VEC paths) x (a chunk of time steps); waves never
+// meet at a workgroup barrier.  Per step a lane folds TPW*VEC paths into its 8 accumulators,
+// the wave reduces them through its private LDS patch and writes one partial per quantity.
+// The next step's rows are loaded before the current one is reduced.
+// Targets are the discounted TERMINAL payoffs.
+template <int VEC, int TPW>
 __global__ __launch_bounds__(kBlock) void lsm_pass1_kernel(Pass1Args a)
 {
-    __shared__ double red[2][kNQ * kRedStride];
-    const int tid = threadIdx.x;
-    const int64_t tile = blockIdx.x;
-    const int64_t j = (tile * kBlock + tid) * VEC;
-    const bool valid = j < a.M;
+    __shared__ double wl[kBlock / 64][kWaveRedDoubles];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tg = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    if (tg >= a.ntiles) return;  // whole wave leaves; no workgroup barrier below
+    const int64_t base = tg * (64 * VEC * TPW) + (int64_t)lane * VEC;
     const int t0 = 1 + blockIdx.y * a.tchunk;
     const int t1 = min(t0 + a.tchunk, a.N);
     const double K = a.K, invK = a.invK;
     const int is_put = a.is_put;
-    double pN[VEC];
-    if (valid) {
+    double pN[TPW][VEC];
+    bool valid[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int64_t j = base + (int64_t)k * 64 * VEC;
+        valid[k] = j < a.M;
         float sn[VEC];
-        loadf<VEC>(a.S + (int64_t)a.N * a.ld + j, sn);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) sn[v] = 0.f;
+        if (valid[k]) loadf<VEC>(a.S + (int64_t)a.N * a.ld + j, sn);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const double p = payoff_d(sn[v], K, is_put);
-            pN[v] = p > 0.0 ? p : 0.0;
+            pN[k][v] = (valid[k] && p > 0.0) ? p : 0.0;
         }
     }
+    float cur[TPW][VEC], nxt[TPW][VEC];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) cur[k][v] = nxt[k][v] = 0.f;
+        if (valid[k] && t0 < t1) loadf<VEC>(a.S + (int64_t)t0 * a.ld + base + (int64_t)k * 64 * VEC, cur[k]);
+    }
     for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) {
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
+                if (valid[k]) loadf<VEC>(a.S + (int64_t)(t + 1) * a.ld + base + (int64_t)k * 64 * VEC, nxt[k]);
+        }
         double acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-        if (valid) {
-            float st[VEC];
-            loadf<VEC>(a.S + (int64_t)t * a.ld + j, st);
-            const double d = a.D[a.N - t];
+        const double d = a.D[a.N - t];
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const double imm = payoff_d(st[v], K, is_put);
-                if (imm > 0.0) accumulate_moments(acc, fma((double)st[v], invK, -1.0), pN[v] * d);
+                const double imm = payoff_d(cur[k][v], K, is_put);
+                if (valid[k] && imm > 0.0)
+                    accumulate_moments(acc, fma((double)cur[k][v], invK, -1.0), pN[k][v] * d);
             }
         }
-        const double s = block_reduce8(acc, red[(t - t0) & 1]);
-        if (tid < 64 && (tid & 7) == 0)
-            a.part1[((size_t)t * 8 + (tid >> 3)) * a.ntiles + tile] = s;
+        const double s = wave_reduce8(acc, wl[wave]);
+        if ((lane & 7) == 0) a.part1[((size_t)t * 8 + (lane >> 3)) * a.ntiles + tg] = s;
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) cur[k][v] = nxt[k][v];
+        }
     }
 }
 
@@ -492,12 +530,13 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
     a.K = p.K; a.invK = 1.0 / p.K; a.D = w.D; a.part1 = w.part1;
     const bool v4 = vec4_ok(p);
-    const int vec = v4 ? 4 : 1;
-    a.ntiles = (p.M + (int64_t)kBlock * vec - 1) / ((int64_t)kBlock * vec);
+    constexpr int kTpw = 4;
+    const int64_t per_wave = 64 * (int64_t)(v4 ? 4 : 1) * kTpw;  // paths per wave per step
+    a.ntiles = (p.M + per_wave - 1) / per_wave;
     a.tchunk = 16;
-    const dim3 grid((unsigned)a.ntiles, (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
-    if (v4) hipLaunchKernelGGL((lsm_pass1_kernel<4>), grid, dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((lsm_pass1_kernel<1>), grid, dim3(kBlock), 0, st, a);
+    const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
+    if (v4) hipLaunchKernelGGL((lsm_pass1_kernel<4, kTpw>), grid, dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((lsm_pass1_kernel<1, kTpw>), grid, dim3(kBlock), 0, st, a);
     hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1), dim3(kBlock), 0, st, w.part1, w.gmom,
                        a.ntiles);
     return hipGetLastError();

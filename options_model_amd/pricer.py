@@ -1,0 +1,254 @@
+"""Drop-in for the call surface of options_model_3/options_model_3.py (the reference's CPU
+pricer): same names, argument order, defaults, error messages and return types, with the hot
+path (paths -> backward induction -> mean) on the MI355X through libomc.so.
+
+Mirrored symbols (reference file:line):
+    welford_batch_update, monte_carlo_price_streaming   options_model_3.py:33-63
+    RNGManager                                          options_model_3.py:69-79
+    BlackScholesGreeks                                  options_model_3.py:127-159
+    AdvancedOptionPricer                                options_model_3.py:339-713
+    compute_curve_worker_enhanced                       options_model_3.py:719-739
+
+What differs, by construction (DESIGN.md "Parity"):
+  * normals come from Philox4x32-10 keyed by the child seed RNGManager hands out, not from
+    numpy's PCG64 -- the master-seed draw sequence (two draws per LSM pricing, one per
+    500-path European chunk) is kept so curves consume seeds exactly as the reference does;
+  * the continuation-value regressor is OLS on [1,u,u^2] per time step (regressor="poly");
+    regressor="nn" trains the reference's SingleLSMNet on the GPU (nn_regressor.py);
+  * iv_model (local-vol paths through an IV network) is out of scope.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from . import _ffi
+from .api import heston_defaults
+
+log = logging.getLogger(__name__)
+
+
+# -- streaming statistics: Chan's parallel mean/M2 merge ------------------------------------
+def welford_batch_update(mean, m2, n, batch):
+    batch = np.asarray(batch, dtype=np.float64)
+    k = batch.size
+    if k == 0:
+        return mean, m2, n
+    bm = batch.mean()
+    bm2 = float(((batch - bm) ** 2).sum())
+    d = bm - mean
+    tot = n + k
+    return mean + d * (k / tot), m2 + bm2 + d * d * n * k / tot, tot
+
+
+def monte_carlo_price_streaming(simulator_func, total_paths, chunk_size, *sim_args, **sim_kwargs):
+    done, mean, m2 = 0, 0.0, 0.0
+    while done < total_paths:
+        b = min(chunk_size, total_paths - done)
+        mean, m2, done = welford_batch_update(mean, m2, done, simulator_func(b, *sim_args, **sim_kwargs))
+    var = m2 / (done - 1) if done > 1 else 0.0
+    return mean, (math.sqrt(var / done) if done > 0 else 0.0), done
+
+
+class RNGManager:
+    """Master PCG64 handing out child seeds in [0, 2**31-1) -- identical draw sequence to the
+    reference, so `RNGManager(42)` yields the same child seeds (tests/golden/scalars.json)."""
+
+    def __init__(self, master_seed: int = 42):
+        self.master_rng = np.random.default_rng(master_seed)
+        self.master_seed = master_seed
+
+    def get_child_rng(self) -> np.random.Generator:
+        return np.random.default_rng(self.master_rng.integers(0, 2**31 - 1))
+
+    def get_child_seed(self) -> int:
+        return int(self.master_rng.integers(0, 2**31 - 1))
+
+
+def _ncdf(x):
+    return 0.5 * math.erfc(-x / math.sqrt(2.0))
+
+
+def _npdf(x):
+    return math.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
+
+
+class BlackScholesGreeks:
+    @staticmethod
+    def _d12(S, K, T, r, sigma):
+        d1 = (math.log(S / K) + (r + 0.5 * sigma**2) * T) / (sigma * math.sqrt(T))
+        return d1, d1 - sigma * math.sqrt(T)
+
+    @staticmethod
+    def greeks(S, K, T, r, sigma, option_type="call"):
+        d1, d2 = BlackScholesGreeks._d12(S, K, T, r, sigma)
+        common = -S * _npdf(d1) * sigma / (2 * math.sqrt(T))
+        if option_type == "call":
+            delta = _ncdf(d1)
+            theta = common - r * K * math.exp(-r * T) * _ncdf(d2)
+            rho = K * T * math.exp(-r * T) * _ncdf(d2)
+        else:
+            delta = -_ncdf(-d1)
+            theta = common + r * K * math.exp(-r * T) * _ncdf(-d2)
+            rho = -K * T * math.exp(-r * T) * _ncdf(-d2)
+        return {"Delta": delta, "Gamma": _npdf(d1) / (S * sigma * math.sqrt(T)),
+                "Vega": S * _npdf(d1) * math.sqrt(T) / 100, "Theta": theta / 365, "Rho": rho / 100}
+
+    @staticmethod
+    def black_scholes_price(S, K, T, r, sigma, option_type="call"):
+        d1, d2 = BlackScholesGreeks._d12(S, K, T, r, sigma)
+        if option_type == "call":
+            return S * _ncdf(d1) - K * math.exp(-r * T) * _ncdf(d2)
+        return K * math.exp(-r * T) * _ncdf(-d2) - S * _ncdf(-d1)
+
+
+class AdvancedOptionPricer:
+    def __init__(self, K: float, r: float, sigma: Optional[float], option_type: str = "call",
+                 rng_manager: Optional[RNGManager] = None, use_heston: bool = False,
+                 heston_params: Optional[Dict[str, Any]] = None, nn_hidden: int = 128,
+                 nn_epochs: int = 25, nn_lr: float = 1e-3, verbose: bool = False, iv_model=None,
+                 use_streaming: bool = True, chunk_size: int = 500,
+                 european_approximation: bool = False, use_control_variate: bool = True,
+                 # -- extensions (keyword-only in spirit; the GPU file adds nn_layers/nn_dropout
+                 #    the same way, option_model_3_gpu.py:557-561)
+                 nn_layers: int = 3, nn_dropout: float = 0.10, regressor: str = "poly",
+                 semantics: str = "two_pass", device: int = 0):
+        self.K, self.r, self.sigma, self.option_type = K, r, sigma, option_type
+        self.rng_manager = rng_manager or RNGManager()
+        self.use_heston, self.heston_params = use_heston, heston_params
+        self.nn_hidden, self.nn_epochs, self.nn_lr = nn_hidden, nn_epochs, nn_lr
+        self.nn_layers, self.nn_dropout = nn_layers, nn_dropout
+        self.verbose, self.iv_model = verbose, iv_model
+        self.use_streaming, self.chunk_size = use_streaming, chunk_size
+        self.european_approximation = european_approximation
+        self.use_control_variate = use_control_variate
+        self.regressor, self.semantics, self.device = regressor, semantics, device
+        self._calls = 0
+        self.last_result: Optional[dict] = None
+
+    # -- helpers
+    def _ctx(self):
+        return _ffi.default_context(self.device)
+
+    def _payoff(self, S: np.ndarray) -> np.ndarray:
+        return np.maximum(S - self.K, 0) if self.option_type == "call" else np.maximum(self.K - S, 0)
+
+    def _model_kw(self):
+        if self.iv_model is not None:
+            raise NotImplementedError("iv_model (local-vol paths) is outside the accelerated hot "
+                                      "path; see SURVEY.md section 8 row f-4")
+        if self.use_heston and self.heston_params is not None:
+            return dict(model="heston", **heston_defaults(self.sigma, self.heston_params))
+        if self.sigma is None:
+            raise ValueError("sigma is None: provide sigma, iv_model, or heston configuration")
+        return dict(model="gbm")
+
+    def _params(self, S0, T, M, N, seed, semantics):
+        sem = {"two_pass": "two_pass", "per_step": "reference", "textbook": "textbook"}[semantics]
+        return _ffi.make_params(is_put=(self.option_type == "put"), semantics=sem, n_paths=M,
+                                n_steps=N, S0=S0, K=self.K, r=self.r, sigma=self.sigma or 0.0, T=T,
+                                seed=seed, stream=0, **self._model_kw())
+
+    # -- European (options_model_3.py:382-437)
+    def price_european_streaming(self, S0: float, T: float, num_simulations: int = 10000,
+                                 num_time_steps: int = 50) -> float:
+        kw = self._model_kw()
+        # the reference draws one child RNG per chunk_size-path chunk; consume the same number
+        # of master draws and key the single fused launch with the first of them
+        n_chunks = max(1, -(-int(num_simulations) // int(self.chunk_size)))
+        seeds = [self.rng_manager.get_child_seed() for _ in range(n_chunks)]
+        M = int(num_simulations) // 2 * 2
+        if M <= 0:
+            return 0.0
+        p = _ffi.make_params(is_put=(self.option_type == "put"), n_paths=M, n_steps=int(num_time_steps),
+                             S0=S0, K=self.K, r=self.r, sigma=self.sigma or 0.0, T=T, seed=seeds[0],
+                             stream=1, **kw)
+        out = self._ctx().price_european(p)
+        if self.verbose:
+            var = max(out["sumsq"] / M - out["price"] ** 2, 0.0)
+            print(f"European streaming MC: {out['price']:.4f} ± {math.sqrt(var / M):.4f} (n={M})")
+        return out["price"]
+
+    # -- American LSM (options_model_3.py:439-651)
+    def price_american_enhanced_lsm(self, S0: float, T: float, num_simulations: int = 10000,
+                                    num_time_steps: int = 50) -> float:
+        if S0 <= 0 or self.K <= 0 or T <= 0:
+            raise ValueError("S0, K, T must be positive.")
+        if self.r < 0:
+            raise ValueError("r must be non-negative.")
+        if num_simulations <= 0 or num_time_steps <= 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        path_seed = self.rng_manager.get_child_seed()   # reference: rng = get_child_rng()
+        torch_seed = self.rng_manager.get_child_seed()  # reference: torch.manual_seed(...)
+        M = int(num_simulations) // 2 * 2
+        if M == 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        self._calls += 1
+        if self.regressor == "nn":
+            from . import nn_regressor
+            res = nn_regressor.price_two_pass_nn(self, S0, T, M, int(num_time_steps), path_seed, torch_seed)
+            self.last_result = res
+            return res["price"]
+        if self.regressor != "poly":
+            raise ValueError("regressor must be 'poly' or 'nn'.")
+        out = self._ctx().price_american(self._params(S0, T, M, int(num_time_steps), path_seed,
+                                                      self.semantics))
+        self.last_result = out
+        return out["price"]
+
+    # -- default wrapper (options_model_3.py:653-677); see SURVEY.md F10 for what it really is
+    def price_american_with_control_variate(self, S0: float, T: float, num_simulations: int = 10000,
+                                            num_time_steps: int = 50) -> float:
+        american = self.price_american_enhanced_lsm(S0, T, num_simulations, num_time_steps)
+        if not self.use_control_variate or self.sigma is None:
+            return american
+        european_mc = self.price_european_streaming(S0, T, num_simulations, num_time_steps)
+        european_bs = BlackScholesGreeks.black_scholes_price(S0, self.K, T, self.r, self.sigma,
+                                                            self.option_type)
+        cv = american + 1.0 * (european_bs - european_mc)
+        if self.verbose:
+            print(f"American: {american:.4f}, European MC: {european_mc:.4f}, "
+                  f"European Analytical: {european_bs:.4f}, CV Adjusted: {cv:.4f}")
+        return cv
+
+    def price_american_option(self, S0: float, T: float, num_simulations: int = 10000,
+                              num_time_steps: int = 50, plot_paths: bool = False) -> float:
+        if self.use_streaming and self.european_approximation:
+            if self.verbose:
+                print("WARNING: Using European approximation for American option (streaming mode)")
+            return self.price_european_streaming(S0, T, num_simulations, num_time_steps)
+        if self.use_control_variate and self.sigma is not None:
+            return self.price_american_with_control_variate(S0, T, num_simulations, num_time_steps)
+        return self.price_american_enhanced_lsm(S0, T, num_simulations, num_time_steps)
+
+    def compute_curve_for_S0(self, S0: float, intervals_per_day: int, total_points: int,
+                             num_simulations: int, plot_paths: bool) -> List[Dict[str, Any]]:
+        records = []
+        for i in range(total_points, 0, -1):
+            d = i / intervals_per_day
+            steps = max(10, min(130, int(math.ceil(d))))
+            price = self.price_american_option(S0, d / 365, num_simulations, steps, plot_paths)
+            records.append({"S0": S0, "Days to Expiry": d, "Option Value": price})
+        return records
+
+
+def compute_curve_worker_enhanced(S0, K, r, sigma, option_type, worker_seed, intervals_per_day,
+                                  total_points, num_simulations, plot_paths, use_heston,
+                                  heston_params, nn_hidden=128, nn_epochs=25, nn_lr=1e-3,
+                                  verbose=False, european_approximation=False,
+                                  use_control_variate=True):
+    """Never raises: logs and returns [] like the reference worker (options_model_3.py:737-739)."""
+    try:
+        pricer = AdvancedOptionPricer(K, r, sigma, option_type, RNGManager(worker_seed), use_heston,
+                                      heston_params, nn_hidden=nn_hidden, nn_epochs=nn_epochs,
+                                      nn_lr=nn_lr, verbose=verbose,
+                                      european_approximation=european_approximation,
+                                      use_control_variate=use_control_variate)
+        return pricer.compute_curve_for_S0(S0, intervals_per_day, total_points, num_simulations,
+                                           plot_paths)
+    except Exception as e:  # noqa: BLE001
+        logging.error(f"Error in enhanced worker for S0={S0}: {e}")
+        return []

@@ -25,7 +25,8 @@
  *   reference is not reproduced; identical-normals parity goes through the
  *   *_from_normals entry points.
  *
- * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp)
+ * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp); path loops and the LSM sweeps
+ * are OpenMP-parallel over paths (static schedule: sums are reproducible for a given thread count).
  */
 #include <math.h>
 #include <stdint.h>
@@ -79,7 +80,7 @@ void orc_normals4(uint64_t seed, uint64_t pair, uint32_t block, uint32_t stream,
 void orc_gbm_normals_f32(float *Z, int64_t ldz, int64_t n_pairs, int n_steps, uint64_t seed,
                          uint32_t stream, uint64_t pair_offset)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n_pairs * (int64_t)n_steps >= 1000000)
     for (int64_t p = 0; p < n_pairs; ++p) {
         float z[4];
         for (int t = 0; t < n_steps; ++t) {
@@ -102,7 +103,7 @@ void orc_gbm_paths_f32(float *S, int64_t ld, int64_t n_paths, int n_steps, doubl
     const float a = (float)((r - 0.5 * sigma * sigma) * dt * L2E);
     const float b = (float)(sigma * sqrt(dt) * L2E);
     const int64_t P = antithetic ? n_paths / 2 : n_paths;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (P * (int64_t)n_steps >= 1000000)
     for (int64_t p = 0; p < P; ++p) {
         float s0 = (float)S0, s1 = (float)S0, z[4];
         S[p] = s0;
@@ -131,7 +132,7 @@ void orc_gbm_paths_from_normals_f32(float *S, int64_t ld, int64_t n_paths, int n
     const float a = (float)((r - 0.5 * sigma * sigma) * dt * L2E);
     const float b = (float)(sigma * sqrt(dt) * L2E);
     const int64_t P = antithetic ? n_paths / 2 : n_paths;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (P * (int64_t)n_steps >= 1000000)
     for (int64_t p = 0; p < P; ++p) {
         float s0 = (float)S0, s1 = (float)S0;
         S[p] = s0;
@@ -192,7 +193,7 @@ void orc_heston_paths_f32(float *S, int64_t ld, int64_t n_paths, int n_steps, do
 {
     const heston_consts c = heston_make(r, T, n_steps, kappa, theta, xi, rho);
     const int64_t P = n_paths / 2;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (P * (int64_t)n_steps >= 1000000)
     for (int64_t p = 0; p < P; ++p) {
         float s0 = (float)S0, s1 = (float)S0, va = (float)v0, vb = (float)v0, z[4];
         S[p] = s0;
@@ -215,7 +216,7 @@ void orc_heston_paths_from_normals_f32(float *S, int64_t ld, int64_t n_paths, in
 {
     const heston_consts c = heston_make(r, T, n_steps, kappa, theta, xi, rho);
     const int64_t P = n_paths / 2;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (P * (int64_t)n_steps >= 1000000)
     for (int64_t p = 0; p < P; ++p) {
         float s0 = (float)S0, s1 = (float)S0, va = (float)v0, vb = (float)v0;
         S[p] = s0;
@@ -295,16 +296,18 @@ int orc_lsm_poly(const float *S, int64_t ld, int64_t n_paths, int n_steps, doubl
     if (semantics == 2) { /* pass 1: targets are discounted terminal payoffs, no decisions */
         for (int t = N - 1; t >= 1; --t) {
             const float *St = S + (int64_t)t * ld;
-            double m[8] = {0};
+            double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : m0, m1, m2, m3, m4, m5, m6, m7) if (M >= 262144)
             for (int64_t j = 0; j < M; ++j) {
                 double imm = payoff_d((double)St[j], K, is_put);
                 if (!(imm > 0.0)) continue;
                 double pN = payoff_d((double)SN[j], K, is_put);
                 double y = (pN > 0.0 ? pN : 0.0) * D[N - t];
                 double u = fma((double)St[j], invK, -1.0), u2 = u * u;
-                m[0] += 1.0; m[1] += u; m[2] += u2; m[3] += u2 * u; m[4] += u2 * u2;
-                m[5] += y; m[6] += u * y; m[7] += u2 * y;
+                m0 += 1.0; m1 += u; m2 += u2; m3 += u2 * u; m4 += u2 * u2;
+                m5 += y; m6 += u * y; m7 += u2 * y;
             }
+            double m[8] = {m0, m1, m2, m3, m4, m5, m6, m7};
             nitm[t] = (int64_t)m[0];
             solve_poly2(m, betas + 3 * t);
         }
@@ -312,7 +315,8 @@ int orc_lsm_poly(const float *S, int64_t ld, int64_t n_paths, int n_steps, doubl
     for (int t = N - 1; t >= 1; --t) {
         const float *St = S + (int64_t)t * ld;
         if (semantics != 2) {
-            double m[8] = {0};
+            double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : m0, m1, m2, m3, m4, m5, m6, m7) if (M >= 262144)
             for (int64_t j = 0; j < M; ++j) {
                 double imm = payoff_d((double)St[j], K, is_put);
                 if (!(imm > 0.0)) continue;
@@ -320,14 +324,16 @@ int orc_lsm_poly(const float *S, int64_t ld, int64_t n_paths, int n_steps, doubl
                 double p = payoff_d((double)sx[j], K, is_put);
                 double y = (p > 0.0 ? p : 0.0) * D[tex[j] - t];
                 double u = fma((double)St[j], invK, -1.0), u2 = u * u;
-                m[0] += 1.0; m[1] += u; m[2] += u2; m[3] += u2 * u; m[4] += u2 * u2;
-                m[5] += y; m[6] += u * y; m[7] += u2 * y;
+                m0 += 1.0; m1 += u; m2 += u2; m3 += u2 * u; m4 += u2 * u2;
+                m5 += y; m6 += u * y; m7 += u2 * y;
             }
+            double m[8] = {m0, m1, m2, m3, m4, m5, m6, m7};
             nitm[t] = (int64_t)m[0];
             solve_poly2(m, betas + 3 * t);
         }
         if (nitm[t] == 0) continue;
         const double *b = betas + 3 * t;
+#pragma omp parallel for schedule(static) if (M >= 262144)
         for (int64_t j = 0; j < M; ++j) {
             double imm = payoff_d((double)St[j], K, is_put);
             if (!(imm > 0.0)) continue;
@@ -341,6 +347,7 @@ int orc_lsm_poly(const float *S, int64_t ld, int64_t n_paths, int n_steps, doubl
     const int tval = (semantics == 1) ? 0 : 1;
     double sum = 0.0, sumsq = 0.0;
     int64_t nex = 0, nzero = 0, snitm = 0;
+#pragma omp parallel for schedule(static) reduction(+ : sum, sumsq, nex, nzero) if (M >= 262144)
     for (int64_t j = 0; j < M; ++j) {
         double p = payoff_d((double)sx[j], K, is_put);
         double cf = (p > 0.0 ? p : 0.0) * D[tex[j] - tval];

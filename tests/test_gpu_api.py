@@ -1,0 +1,148 @@
+"""GPU tests of the host-side drop-in surfaces (same names/arguments/returns as the reference's
+Python API) -- they read like calls into the reference, and the numbers are checked against
+the CPU oracle driven with the same seeds."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import cpu as orc
+from oracle import reference_flow as rf
+
+pytestmark = pytest.mark.gpu
+
+K, R, SIG, T = 100.0, 0.05, 0.2, 1.0
+HP = dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(ctx):
+    return ctx
+
+
+# ---------------------------------------------------------------- north-star facade
+@pytest.mark.parametrize("sem,osem", [("two_pass", "two_pass"), ("per_step", "reference"),
+                                      ("textbook", "textbook")])
+def test_facade_gbm_put(sem, osem):
+    from options_model_amd import price_american_option
+    res = price_american_option(100.0, K, R, SIG, T, 50_000, 50, model="GBM", option_type="put",
+                                semantics=sem, seed=42)
+    ref = orc.lsm_poly(orc.gbm_paths(50_000, 50, 100.0, R, SIG, T, 42), K, R, T, True, osem)
+    assert abs(res.price - ref["price"]) <= 1e-3 * ref["price"]
+    assert float(res) == res.price and res.n_paths == 50_000 and res.stderr > 0
+    assert res.model == "gbm" and res.timings_ms["paths"] > 0
+
+
+def test_facade_heston_call_config4_shape():
+    from options_model_amd import price_american_option
+    res = price_american_option(100.0, K, R, SIG, T, 40_000, 50, model="Heston", option_type="call",
+                                heston_params=HP, seed=7)
+    ref = orc.lsm_poly(orc.heston_paths(40_000, 50, 100.0, R, T, seed=7, **HP), K, R, T, False, "two_pass")
+    assert abs(res.price - ref["price"]) <= 1e-3 * ref["price"]
+
+
+def test_facade_odd_path_count_drops_one_path():
+    from options_model_amd import price_american_option
+    a = price_american_option(100.0, K, R, SIG, T, 10_001, 20, seed=1)  # options_model_3.py:458
+    b = price_american_option(100.0, K, R, SIG, T, 10_000, 20, seed=1)
+    assert a.n_paths == 10_000 and a.price == b.price
+
+
+def test_facade_validation_messages():
+    from options_model_amd import price_american_option
+    with pytest.raises(ValueError, match="S0, K, T must be positive"):
+        price_american_option(100.0, K, R, SIG, 0.0, 1000, 10)
+    with pytest.raises(ValueError, match="r must be non-negative"):
+        price_american_option(100.0, K, -0.1, SIG, T, 1000, 10)
+    with pytest.raises(ValueError, match="positive integers"):
+        price_american_option(100.0, K, R, SIG, T, 1000, 0)
+    with pytest.raises(ValueError, match="option_type"):
+        price_american_option(100.0, K, R, SIG, T, 1000, 10, option_type="straddle")
+    with pytest.raises(ValueError, match="model"):
+        price_american_option(100.0, K, R, SIG, T, 1000, 10, model="SABR")
+
+
+# ---------------------------------------------------------------- options_model_3 surface
+def test_advanced_pricer_consumes_master_seeds_like_reference(golden):
+    from options_model_amd import AdvancedOptionPricer, RNGManager
+    seeds = golden["scalars"]["rng_manager_42_child_seeds"]
+    pricer = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put",
+                                  rng_manager=RNGManager(42), use_control_variate=False)
+    price = pricer.price_american_option(100.0, 1.0, 10000, 50)
+    assert isinstance(price, float)
+    # two master draws per LSM pricing (options_model_3.py:454-455): the next one is #3
+    assert pricer.rng_manager.get_child_seed() == seeds[2]
+    ref = orc.lsm_poly(orc.gbm_paths(10000, 50, 100.0, R, SIG, T, seeds[0]), K, R, T, True, "two_pass")
+    assert abs(price - ref["price"]) <= 1e-3 * ref["price"]
+
+
+def test_advanced_pricer_default_adds_bs_minus_european(golden):
+    """default return = LSM + (Black-Scholes - independent European MC), SURVEY F10."""
+    from options_model_amd import AdvancedOptionPricer, RNGManager
+    seeds = golden["scalars"]["rng_manager_42_child_seeds"]
+    p_cv = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(42))
+    total = p_cv.price_american_option(100.0, 1.0, 2000, 20)
+    p_a = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(42), use_control_variate=False)
+    lsm = p_a.price_american_option(100.0, 1.0, 2000, 20)
+    eur = p_a.price_european_streaming(100.0, 1.0, 2000, 20)  # continues the same master stream
+    bs = rf.black_scholes_price(100, 100, 1, 0.05, 0.2, "put")
+    assert total == pytest.approx(lsm + (bs - eur), rel=1e-12)
+    # 2000 paths / 500 per chunk = 4 master draws for the European leg
+    assert p_cv.rng_manager.get_child_seed() == p_a.rng_manager.get_child_seed()
+    s, _ = orc.european_from_paths(orc.gbm_paths(2000, 20, 100.0, R, SIG, T, seeds[2], 1), K, R, T, True)
+    assert eur == pytest.approx(s / 2000, rel=1e-4)
+
+
+def test_advanced_pricer_heston_and_errors():
+    from options_model_amd import AdvancedOptionPricer, RNGManager
+    p = AdvancedOptionPricer(100, 0.05, 0.2, "call", RNGManager(1), use_heston=True, heston_params=HP,
+                             use_control_variate=False)
+    v = p.price_american_option(100.0, 1.0, 20000, 50)
+    assert 9.0 < v < 13.0 and p.last_result["n_paths"] == 20000
+    with pytest.raises(ValueError, match="S0, K, T must be positive"):
+        p.price_american_enhanced_lsm(-1.0, 1.0)
+    q = AdvancedOptionPricer(100, 0.05, None, "call", use_control_variate=False)
+    with pytest.raises(ValueError, match="sigma is None"):
+        q.price_american_option(100.0, 1.0, 1000, 10)
+    e = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(3), european_approximation=True)
+    assert abs(e.price_american_option(100.0, 1.0, 400_000, 10) - rf.black_scholes_price(100, 100, 1, .05, .2, "put")) < 0.05
+
+
+def test_curve_worker_records_and_never_raises():
+    from options_model_amd.pricer import compute_curve_worker_enhanced
+    recs = compute_curve_worker_enhanced(100.0, 100.0, 0.05, 0.2, "put", 2025, 2, 6, 4000, False, False, None)
+    assert len(recs) == 6
+    assert set(recs[0]) == {"S0", "Days to Expiry", "Option Value"}
+    assert [r["Days to Expiry"] for r in recs] == [3.0, 2.5, 2.0, 1.5, 1.0, 0.5]
+    assert all(r["Option Value"] > 0 for r in recs)
+    assert compute_curve_worker_enhanced(-5.0, 100.0, 0.05, 0.2, "put", 1, 2, 2, 100, False, False, None) == []
+
+
+# ---------------------------------------------------------------- v1 / v2 surfaces
+def test_v1_functional_surface():
+    from options_model_amd.compat.Options_model import compute_curve_for_S0, price_american_option
+    mean, std, zero = price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, 20000, 50, "put", 2, False, 42)
+    ref = orc.lsm_poly(orc.gbm_paths(20000, 50, 100.0, R, SIG, T, 42), K, R, T, True, "reference")
+    assert abs(mean - ref["price"]) <= 1e-3 * ref["price"]
+    var = ref["sumsq"] / 20000 - ref["price"] ** 2
+    assert std == pytest.approx(math.sqrt(var), rel=5e-3)
+    assert zero == pytest.approx(ref["n_zero"] / 20000, abs=2e-3)
+    with pytest.raises(ValueError, match="S0, K, T, and sigma must be positive"):
+        price_american_option(100.0, 100.0, 1.0, 0.05, 0.0)
+    with pytest.raises(ValueError, match="lsm_poly_degree"):
+        price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, lsm_poly_degree=-1)
+    recs = compute_curve_for_S0(100.0, 100.0, 0.05, 0.2, 2000, 1, 3, "call", 2, False, 2025)
+    assert set(recs[0]) == {"S0", "Days to Expiry", "Option Value", "Std Dev", "Zero Prob"}
+
+
+def test_v2_worker_surface_as_the_ui_calls_it():
+    from options_model_amd.compat.options_model_2 import OptionPricer, compute_curve_worker
+    # positional call exactly as options_model_2_ui.py:87-98 builds it
+    recs = compute_curve_worker(100.0, 100.0, 0.05, 0.2, "put", 2, 2025, 2, 4, 4000, False, True,
+                                dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7), 32, 10, 1e-3, False)
+    assert len(recs) == 4 and set(recs[0]) == {"S0", "Days to Expiry", "Option Value"}
+    assert compute_curve_worker(100.0, -1.0, 0.05, 0.2, "put", 2, 1, 2, 2, 100, False, False, None) == []
+    p = OptionPricer(100.0, 0.05, 0.2, "put", 2, 42)
+    a = p.price_american_option(100.0, 1.0, 10000, 50)
+    b = p.price_american_option(100.0, 1.0, 10000, 50)
+    assert a == b  # v2 reseeds per pricing: identical inputs, identical price
