@@ -71,6 +71,9 @@ struct omc_ctx {
     bool own_stream = false;
     DevBuf S, sx, tex, D, part, gmom, betas, part1, result, scratch;
     std::vector<double> hD;
+    int D_N = -1;
+    double D_r = 0, D_T = 0;
+    const double* D_ptr = nullptr;
     double hres[8];
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int gbm_vec = 0, heston_vec = 0, use_graph = 0;
@@ -111,7 +114,7 @@ int bind(omc_ctx* c)
 
 // workspace for the backward induction on M paths x N steps
 int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
-                omc::LsmWorkspace* w)
+                bool clear_tables, omc::LsmWorkspace* w)
 {
     int rc;
     if ((rc = c->sx.ensure(sizeof(float) * (size_t)M))) return rc;
@@ -136,15 +139,24 @@ int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
     w->gmom = (double*)c->gmom.p;
     w->betas = (double*)c->betas.p;
     w->result = (double*)c->result.p;
-    // discount table computed on the host in double (same libm exp as the oracle)
-    c->hD.resize((size_t)N + 1);
-    const double dt = T / N;
-    for (int k = 0; k <= N; ++k) c->hD[(size_t)k] = std::exp(-r * dt * (double)k);
-    HIP_TRY(hipMemcpyAsync(w->D, c->hD.data(), sizeof(double) * (size_t)(N + 1),
-                           hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(w->gmom, 0, sizeof(double) * 8 * (size_t)(N + 1), c->stream));
-    HIP_TRY(hipMemsetAsync(w->betas, 0, sizeof(double) * 4 * (size_t)(N + 1), c->stream));
-    HIP_TRY(hipMemsetAsync(w->result, 0, sizeof(double) * 8, c->stream));
+    // discount table computed on the host in double (same libm exp as the oracle); it only
+    // depends on (N, r, T), so consecutive pricings of one contract reuse the device copy
+    if (c->D_N != N || c->D_r != r || c->D_T != T || c->D_ptr != w->D) {
+        c->hD.resize((size_t)N + 1);
+        const double dt = T / N;
+        for (int k = 0; k <= N; ++k) c->hD[(size_t)k] = std::exp(-r * dt * (double)k);
+        HIP_TRY(hipMemcpyAsync(w->D, c->hD.data(), sizeof(double) * (size_t)(N + 1),
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // hD is pageable host memory
+        c->D_N = N; c->D_r = r; c->D_T = T; c->D_ptr = w->D;
+    }
+    // gmom rows 1..N-1, betas rows 1..N-1 and result[0..7] are fully written by the kernels of
+    // every flow before anything reads them; rows 0 and N are only ever copied out, so they
+    // are cleared just when the caller asked for the tables.
+    if (clear_tables) {
+        HIP_TRY(hipMemsetAsync(w->gmom, 0, sizeof(double) * 8 * (size_t)(N + 1), c->stream));
+        HIP_TRY(hipMemsetAsync(w->betas, 0, sizeof(double) * 4 * (size_t)(N + 1), c->stream));
+    }
     return 0;
 }
 
@@ -163,7 +175,7 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
         HIP_TRY(omc::lsm_pass2_apply(st, p, w, write_state));
     } else {
         const bool ext = c->hook != nullptr;
-        const int nblk = omc::lsm_step_blocks(p.M);
+        const int nblk = omc::lsm_sweep_blocks(p.M);
         for (int t = p.N; t >= 1; --t) {
             HIP_TRY(omc::lsm_step(st, p, w, semantics, t, ext));
             if (ext && t >= 2) {
@@ -457,7 +469,7 @@ int omc_lsm_poly(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     if (semantics < 0 || semantics > 2) return fail(-4, "unknown semantics.");
     if (!res) return fail(-7, "null result pointer.");
     omc::LsmWorkspace w;
-    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, semantics == OMC_SEM_TWO_PASS, &w))) return rc;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, semantics == OMC_SEM_TWO_PASS, betas_out != nullptr, &w))) return rc;
     omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if ((rc = enqueue_lsm(c, p, w, semantics, sx_out || tex_out))) return rc;
@@ -485,7 +497,7 @@ int omc_lsm_apply_frozen(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
     if (!betas || !res) return fail(-7, "null pointer.");
     omc::LsmWorkspace w;
-    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, &w))) return rc;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w))) return rc;
     HIP_TRY(hipMemcpyAsync(w.betas, betas, sizeof(double) * 4 * (size_t)(n_steps + 1),
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // `betas` is caller memory
@@ -537,7 +549,7 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
         S = (float*)c->S.p;
     }
     omc::LsmWorkspace w;
-    if ((rc = prepare_lsm(c, M, N, p->r, p->T, p->semantics == OMC_SEM_TWO_PASS, &w))) return rc;
+    if ((rc = prepare_lsm(c, M, N, p->r, p->T, p->semantics == OMC_SEM_TWO_PASS, false, &w))) return rc;
     omc::LsmProblem prob{S, ld, M, N, p->is_put ? 1 : 0, p->K, p->r, p->T};
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (p->model == OMC_MODEL_GBM)

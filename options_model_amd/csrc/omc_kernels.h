@@ -67,7 +67,8 @@ hipError_t lsm_step(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, 
                     int t, bool external_moments);
 // partials of step t -> gmom[t]  (only needed between steps when moments leave the GPU)
 hipError_t lsm_reduce_step_moments(hipStream_t st, const LsmWorkspace& w, int t, int nblk);
-int lsm_step_blocks(int64_t M);
+int lsm_step_blocks(int64_t M);   // grid of pass 2 / valuation sweeps (256-thread blocks)
+int lsm_sweep_blocks(int64_t M);  // grid of the per-step sweep (512-thread blocks)
 
 // two-pass flow (semantics 2)
 hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);

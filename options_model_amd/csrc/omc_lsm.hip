@@ -77,10 +77,37 @@ struct StepArgs {
 //             the moments of step t-1 -- one pass over S_t, S_{t-1} and the path state
 //   epilogue  per-block partial moments of step t-1 -> part[(t-1)&1]
 // SEM 0: sticky "exercised" mask (reference per-step flow).  SEM 1: textbook LSM.
-template <int SEM, int VEC>
-__global__ __launch_bounds__(kBlock) void lsm_step_kernel(StepArgs a)
+//
+// Geometry: 512-thread workgroups, at most 512 of them (2 per CU).  Every workgroup re-reduces
+// ALL partials of the previous launch in its prologue, so their count (= the grid) is kept small:
+// 512 x 64 B per workgroup is 16 MB of L2 reads per launch chip-wide, against 64 MB (6 us) with
+// a 1024-workgroup grid.
+constexpr int kStepBlock = 512;
+constexpr int kStepWaves = kStepBlock / 64;
+constexpr int kStepMaxBlocks = 512;
+
+// 8 accumulators over the whole workgroup: per-wave LDS transpose-reduce, then threads 0..7
+// add the kStepWaves wave totals of "their" quantity.  One barrier inside; returns the total
+// of quantity threadIdx.x in threads 0..7.
+__device__ __forceinline__ double step_block_reduce8(const double (&acc)[kNQ], double* wl, double* sh_w)
 {
-    __shared__ double red[kNQ * kRedStride];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double s = wave_reduce8(acc, wl + wave * kWaveRedDoubles);
+    if ((lane & 7) == 0) sh_w[wave * 8 + (lane >> 3)] = s;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < 8) {
+#pragma unroll
+        for (int w = 0; w < kStepWaves; ++w) tot += sh_w[w * 8 + threadIdx.x];
+    }
+    return tot;
+}
+
+template <int SEM, int VEC>
+__global__ __launch_bounds__(kStepBlock) void lsm_step_kernel(StepArgs a)
+{
+    __shared__ double wl[kStepWaves * kWaveRedDoubles];
+    __shared__ double sh_w[kStepWaves * 8];
     __shared__ double sh_m[8];
     __shared__ double sh_beta[4];
     extern __shared__ double sh_D[];  // SEM 1 only: [N+1]
@@ -90,15 +117,15 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(StepArgs a)
     const bool do_apply = t < N, do_mom = t >= 2, init = (t == N);
 
     if (SEM == 1 && do_mom) {
-        for (int k = tid; k <= N; k += kBlock) sh_D[k] = a.D[k];
+        for (int k = tid; k <= N; k += kStepBlock) sh_D[k] = a.D[k];
     }
 
     // Issue this thread's first row/state loads BEFORE the prologue: their HBM latency then
     // overlaps the partial-moment reduction and the 3x3 solve.
     const float* St = a.S + (int64_t)t * a.ld;
     const float* Sm = a.S + (int64_t)(t - 1) * a.ld;
-    const int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
-    int64_t j = ((int64_t)blockIdx.x * kBlock + tid) * VEC;
+    const int64_t stride = (int64_t)gridDim.x * kStepBlock * VEC;
+    int64_t j = ((int64_t)blockIdx.x * kStepBlock + tid) * VEC;
     float st[VEC], sm[VEC], sx[VEC];
     int32_t tex[VEC];
 #pragma unroll
@@ -122,12 +149,12 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(StepArgs a)
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] = 0.0;
             const double* pp = a.part + (size_t)(t & 1) * 8 * kPStride;
-            for (int i = tid; i < a.nblk; i += kBlock) {
+            if (tid < a.nblk) {  // nblk <= kStepMaxBlocks == kStepBlock: one partial per thread
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] += pp[q * kPStride + i];
+                for (int q = 0; q < 8; ++q) acc[q] = pp[q * kPStride + tid];
             }
-            const double s = block_reduce8(acc, red);
-            if (tid < 64 && (tid & 7) == 0) sh_m[tid >> 3] = s;
+            const double s = step_block_reduce8(acc, wl, sh_w);
+            if (tid < 8) sh_m[tid] = s;
         }
         __syncthreads();
         if (tid == 0) {
@@ -196,9 +223,9 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(StepArgs a)
         if (j < a.M) load_chunk(j);
     }
     if (do_mom) {
-        const double s = block_reduce8(acc, red);
-        if (tid < 64 && (tid & 7) == 0)
-            a.part[(size_t)((t - 1) & 1) * 8 * kPStride + (size_t)(tid >> 3) * kPStride + blockIdx.x] = s;
+        const double s = step_block_reduce8(acc, wl, sh_w);
+        if (tid < 8)
+            a.part[(size_t)((t - 1) & 1) * 8 * kPStride + (size_t)tid * kPStride + blockIdx.x] = s;
     }
 }
 
@@ -490,6 +517,14 @@ int lsm_step_blocks(int64_t M)
     return (int)(b > kMaxLsmBlocks ? kMaxLsmBlocks : b);
 }
 
+int lsm_sweep_blocks(int64_t M)
+{
+    const int64_t per_block = (int64_t)kStepBlock * 4;
+    int64_t b = (M + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > kStepMaxBlocks ? kStepMaxBlocks : b);
+}
+
 size_t lsm_part1_tiles(int64_t M)
 {
     // sized for the VEC=1 fallback too (4x more tiles); the kernel uses what it needs
@@ -503,8 +538,8 @@ hipError_t lsm_step(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, 
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
     a.K = p.K; a.invK = 1.0 / p.K;
     a.sx = w.sx; a.tex = w.tex; a.D = w.D; a.part = w.part; a.gmom = w.gmom; a.betas = w.betas;
-    a.t = t; a.nblk = lsm_step_blocks(p.M); a.external = external_moments ? 1 : 0;
-    const dim3 grid(a.nblk), block(kBlock);
+    a.t = t; a.nblk = lsm_sweep_blocks(p.M); a.external = external_moments ? 1 : 0;
+    const dim3 grid(a.nblk), block(kStepBlock);
     const bool v4 = vec4_ok(p);
     const size_t dyn = semantics == 1 ? sizeof(double) * (size_t)(p.N + 1) : 0;
     if (semantics == 0) {
