@@ -76,6 +76,41 @@ SIGNATURES = {
 
 _lib = None
 _lib_lock = threading.Lock()
+_hip_runtime = None
+
+
+def _preload_hip_runtime():
+    """One process must use ONE HIP runtime.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64.so.7 / libhsa-runtime64 (torch/lib); if libomc.so pulled in /opt/rocm's copy
+    first, a later `import torch` would find the GPU already owned by a different runtime and
+    report no devices.  So when that wheel is installed, its runtime is dlopen'ed (RTLD_GLOBAL,
+    without importing torch) before libomc.so, whose NEEDED libamdhip64.so.7 then resolves to
+    the already-loaded copy.  OMC_HIP_RUNTIME=system forces /opt/rocm; =<path> forces a file."""
+    global _hip_runtime
+    if _hip_runtime is not None:
+        return
+    import importlib.util
+    import sys
+    mode = os.environ.get("OMC_HIP_RUNTIME", "auto")
+    if mode == "system" or "torch" in sys.modules:
+        return
+    cand = None
+    if mode not in ("auto", "torch") and os.path.exists(mode):
+        cand = mode
+    else:
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.submodule_search_locations:
+            p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                cand = p
+    if cand:
+        try:
+            _hip_runtime = C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            _hip_runtime = None
 
 
 def load_library(build_if_missing: bool = True):
@@ -94,6 +129,7 @@ def load_library(build_if_missing: bool = True):
                 if not os.path.exists(_build.LIB):
                     raise OmcError(f"libomc.so is missing and cannot be built: {e}") from e
                 path = _build.LIB
+        _preload_hip_runtime()
         lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError = symbol missing = broken build

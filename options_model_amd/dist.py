@@ -66,10 +66,14 @@ class ShardedPricer:
         self.world = dist.get_world_size(group)
         torch.cuda.set_device(local_rank)
         self.device = torch.device("cuda", local_rank)
-        # kernels and RCCL collectives are ordered on torch's current stream: no host syncs
-        self.ctx = _ffi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        # One explicit (non-null) stream shared by the HIP kernels and, through torch's
+        # "current stream", by the RCCL collectives: everything is stream-ordered, no host
+        # syncs between a moment kernel, its all-reduce and the kernels that consume it.
+        self.stream = torch.cuda.Stream(self.device)
+        self.ctx = _ffi.Context(local_rank, stream=self.stream.cuda_stream)
         self._ffi = _ffi
-        self._sums = torch.zeros(len(SUM_KEYS), dtype=torch.float64, device=self.device)
+        with torch.cuda.stream(self.stream):
+            self._sums = torch.zeros(len(SUM_KEYS), dtype=torch.float64, device=self.device)
         if self.world > 1:
             self.ctx.set_allreduce_hook(self._allreduce_device)
 
@@ -88,8 +92,9 @@ class ShardedPricer:
         anti = kw.get("antithetic", True)
         n_local, off = shard(n_paths_global, self.world, self.rank, anti)
         p = self._ffi.make_params(n_paths=n_local, pair_offset=off, **kw)
-        local = self.ctx.price_american(p)
-        out = merge(local, self._allreduce_host)
+        with self.torch.cuda.stream(self.stream):  # the hook's all_reduce sees this stream as current
+            local = self.ctx.price_american(p)
+            out = merge(local, self._allreduce_host)
         out["local"] = local
         return out
 

@@ -1,0 +1,297 @@
+"""NN continuation-value regressor (BASELINE config 5): the reference's own v3 scheme --
+ONE global MLP on 7 features, trained on every in-the-money (t, path) of pass 1, then a sticky
+pass 2 -- run on the MI355X.  This is the only part of the product that uses PyTorch-ROCm
+(north_star: "PyTorch-ROCm only for the optional NN continuation-value regressor"); paths still
+come from the hand-written HIP kernels, written straight into the torch tensor.
+
+Reference lines mirrored (options_model_3/options_model_3.py):
+    SingleLSMNet                         :85-103   (Linear/ReLU/Dropout stacks, 3 hidden layers)
+    create_regression_features           :105-121  [1, x, x^2, x^3, max(x-1,0), s, x*s]
+    pass 1: rows = every ITM (t, path), target = discounted TERMINAL payoff      :482-516
+    target / feature normalisation (population std, zero std -> 1)               :550-563
+    Adam(lr, wd 1e-5), MSE, ReduceLROnPlateau(pat 5, x0.5, min 1e-6), <= nn_epochs,
+    early stop after 8 non-improving epochs (delta 1e-6), best-weights restore    :565-613
+    pass 2: sticky mask, strict >, dropout still ACTIVE (no .eval())   :615-649
+    mean of cash-flows valued at t = dt                                          :651
+
+Deviations, all forced by scale and stated in the result dict:
+  * minibatch size: the reference's min(256, R) is kept while R <= 2**18 rows; above that the
+    batch grows so an epoch stays ~1024 optimizer steps (the reference's own GPU draft does
+    the same thing with 512..8192, option_model_3_gpu.py:751-755).  At config 5, R ~ 1.15e8.
+  * pass 2 evaluates the net densely on all M paths per step and masks, instead of gathering
+    the active subset: no host sync inside the time loop.
+  * torch's GPU generator replaces the CPU generator: same distributions, different streams.
+"""
+from __future__ import annotations
+
+import copy
+import math
+import time
+
+from . import _ffi
+from .api import heston_defaults
+
+_ctx_cache = {}
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _ffi.OmcError("regressor='nn' needs PyTorch-ROCm with a visible GPU")
+    return torch
+
+
+def _ctx_on_torch_stream(device: int):
+    torch = _torch()
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    c = _ctx_cache.get(key)
+    if c is None:
+        c = _ffi.Context(device, stream=key[1] or None)
+        _ctx_cache[key] = c
+    return c
+
+
+def make_net(input_dim=7, hidden_dim=128, num_layers=3, dropout=0.1):
+    torch = _torch()
+    nn = torch.nn
+    layers = [nn.Linear(input_dim, hidden_dim), nn.ReLU(), nn.Dropout(dropout)]
+    for _ in range(num_layers - 1):
+        layers += [nn.Linear(hidden_dim, hidden_dim), nn.ReLU(), nn.Dropout(dropout)]
+    layers.append(nn.Linear(hidden_dim, 1))
+
+    class SingleLSMNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = nn.Sequential(*layers)
+
+        def forward(self, x):
+            return self.net(x)
+
+    return SingleLSMNet()
+
+
+def features(x, s_t):
+    """x = S/K (float64 tensor [n]); s_t = sqrt(max(T - t*dt, 1e-6)), scalar or tensor [n]."""
+    torch = _torch()
+    s = s_t if torch.is_tensor(s_t) else torch.full_like(x, float(s_t))
+    return torch.stack([torch.ones_like(x), x, x * x, x * x * x, torch.clamp(x - 1, min=0), s, x * s], dim=1)
+
+
+def generate_paths(ctx, S, model_kw, S0, r, sigma, T, seed, stream=0):
+    """Fill the torch tensor S [N+1, M] (float32, contiguous) with the HIP path kernels."""
+    torch = _torch()
+    N, M = S.shape[0] - 1, S.shape[1]
+    assert S.is_contiguous() and S.dtype == torch.float32
+    # the library call is host-synchronous on its own stream; make sure torch has no pending
+    # work on the (possibly recycled) block behind S before the kernel writes into it
+    torch.cuda.synchronize(S.device)
+    if model_kw.get("model", "gbm") == "heston":
+        hp = {k: model_kw[k] for k in ("v0", "kappa", "theta", "xi", "rho")}
+        _ffi._check(ctx.lib, ctx.lib.omc_heston_paths_f32(ctx.handle, S.data_ptr(), M, M, N, S0, r, T,
+                                                           hp["v0"], hp["kappa"], hp["theta"], hp["xi"],
+                                                           hp["rho"], seed, stream, 0, 0))
+    else:
+        _ffi._check(ctx.lib, ctx.lib.omc_gbm_paths_f32(ctx.handle, S.data_ptr(), M, M, N, S0, r, sigma,
+                                                        T, seed, stream, 0, 1))
+
+
+def collect_rows(S, K, r, T, is_put, step_chunk=32):
+    """Pass 1 (:482-516): x = S/K, step index and target for every ITM (t, path), t = N-1..1."""
+    torch = _torch()
+    N, M = S.shape[0] - 1, S.shape[1]
+    dt = T / N
+    payT = (K - S[N].double()).clamp_(min=0) if is_put else (S[N].double() - K).clamp_(min=0)
+    xs, ts, ys = [], [], []
+    for hi in range(N - 1, 0, -step_chunk):  # reference order: later steps first
+        lo = max(1, hi - step_chunk + 1)
+        blk = S[lo:hi + 1].flip(0).double()  # rows hi, hi-1, .., lo
+        mask = ((K - blk) if is_put else (blk - K)) > 0
+        ti, ji = mask.nonzero(as_tuple=True)
+        t_abs = hi - ti
+        xs.append(blk[mask] / K)
+        ts.append(t_abs.to(torch.int32))
+        ys.append(payT[ji] * torch.exp(-r * dt * (N - t_abs).double()))
+    if not xs:
+        return None
+    return torch.cat(xs), torch.cat(ts), torch.cat(ys), payT
+
+
+def normalisers(x, t, y, T, dt, chunk=1 << 24):
+    """:550-563 in float64: population std; zero feature std -> 1; zero target std -> 1."""
+    torch = _torch()
+    R = x.numel()
+    s1 = torch.zeros(7, dtype=torch.float64, device=x.device)
+    s2 = torch.zeros(7, dtype=torch.float64, device=x.device)
+    for o in range(0, R, chunk):
+        st = torch.sqrt(torch.clamp(T - t[o:o + chunk].double() * dt, min=1e-6))
+        f = features(x[o:o + chunk], st)
+        s1 += f.sum(0)
+        s2 += (f * f).sum(0)
+    # tensor / tensor is a true IEEE division; tensor / python-scalar is lowered to a multiply
+    # by the reciprocal on the GPU, which turns the mean of the constant column into 1 - 2^-53
+    # and its "zero" std into 1e-16 instead of the exact 0 the reference tests for (:562)
+    Rt = torch.tensor(float(R), dtype=torch.float64, device=x.device)
+    fm = s1 / Rt
+    # two-pass variance for accuracy (features are O(1), R up to 1e8)
+    v = torch.zeros(7, dtype=torch.float64, device=x.device)
+    for o in range(0, R, chunk):
+        st = torch.sqrt(torch.clamp(T - t[o:o + chunk].double() * dt, min=1e-6))
+        d = features(x[o:o + chunk], st) - fm
+        v += (d * d).sum(0)
+    fs = torch.sqrt(v / Rt)
+    fs = torch.where(fs == 0, torch.ones_like(fs), fs)
+    ym = y.sum() / Rt
+    ysd = torch.sqrt(((y - ym) ** 2).sum() / Rt)
+    if not float(ysd) > 0:
+        ysd = torch.ones_like(ysd)
+    return fm, fs, ym, ysd
+
+
+def pick_batch(R, nn_batch=None):
+    if nn_batch:
+        return int(min(R, nn_batch))
+    if R <= (1 << 18):
+        return int(min(256, R))  # the reference's choice
+    return int(min(R, 1 << max(8, math.ceil(math.log2(R / 1024)))))
+
+
+def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbose=False):
+    """:565-613.  Features are rebuilt per minibatch from (x, t): the [R,7] matrix never exists."""
+    torch = _torch()
+    R = x.numel()
+    bs = pick_batch(R, nn_batch)
+    opt = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=5, factor=0.5, min_lr=1e-6)
+    loss_fn = torch.nn.MSELoss()
+    best, best_state, bad, steps = float("inf"), None, 0, 0
+    net.train()
+    for epoch in range(epochs):
+        perm = torch.randperm(R, device=x.device)
+        tot = torch.zeros((), dtype=torch.float64, device=x.device)
+        nb = 0
+        for o in range(0, R, bs):
+            idx = perm[o:o + bs]
+            xb, tb = x[idx], t[idx]
+            st = torch.sqrt(torch.clamp(T - tb.double() * dt, min=1e-6))
+            fb = ((features(xb, st) - fm) / fs).float()
+            yb = ((y[idx] - ym) / ysd).float().unsqueeze(1)
+            loss = loss_fn(net(fb), yb)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            tot += loss.detach().double()
+            nb += 1
+        steps += nb
+        avg = float(tot) / max(nb, 1)  # one host sync per epoch
+        sched.step(avg)
+        if avg < best - 1e-6:
+            best, best_state, bad = avg, copy.deepcopy(net.state_dict()), 0
+        else:
+            bad += 1
+            if bad >= 8:
+                if verbose:
+                    print(f"Early stopping at epoch {epoch + 1}, restoring best weights")
+                break
+    if best_state is not None:
+        net.load_state_dict(best_state)
+    return dict(batch=bs, optimizer_steps=steps, epochs_run=epoch + 1, best_loss=best)
+
+
+def pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, path_chunk=1 << 20):
+    """:615-651, dense over paths: sticky mask, strict >, mean valued at t = dt."""
+    torch = _torch()
+    N, M = S.shape[0] - 1, S.shape[1]
+    dt = T / N
+    disc = math.exp(-r * dt)
+    net.train(dropout_on)  # the reference never calls .eval() on this net
+    payf = (lambda s: (K - s).clamp(min=0)) if is_put else (lambda s: (s - K).clamp(min=0))
+    cf = payf(S[N].double())
+    exercised = torch.zeros(M, dtype=torch.bool, device=S.device)
+    ym_f, ys_f = float(ym), float(ysd)
+    with torch.no_grad():
+        for t in range(N - 1, 0, -1):
+            cf *= disc
+            st = S[t].double()
+            imm = payf(st)
+            itm = (imm > 0) & ~exercised
+            s_t = math.sqrt(max(T - t * dt, 1e-6))
+            cont = torch.empty(M, dtype=torch.float64, device=S.device)
+            for o in range(0, M, path_chunk):
+                fb = ((features(st[o:o + path_chunk] / K, s_t) - fm) / fs).float()
+                cont[o:o + path_chunk] = net(fb).squeeze(1).double() * ys_f + ym_f
+            ex = itm & (imm > cont)
+            cf = torch.where(ex, imm, cf)
+            exercised |= ex
+    return cf, exercised
+
+
+def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3, nn_dropout=0.1,
+                     nn_epochs=25, nn_lr=1e-3, nn_batch=None, inference_dropout=True, verbose=False):
+    """The whole v3 NN flow on a device path matrix S (torch float32 [N+1, M])."""
+    torch = _torch()
+    N, M = S.shape[0] - 1, S.shape[1]
+    dt = T / N
+    torch.manual_seed(int(torch_seed))  # :455
+    t0 = time.perf_counter()
+    rows = collect_rows(S, K, r, T, is_put)
+    if rows is None:  # :518-519 nothing ever in the money
+        payT = (K - S[N].double()).clamp_(min=0) if is_put else (S[N].double() - K).clamp_(min=0)
+        cf = payT * math.exp(-r * dt * (N - 1))
+        return dict(price=float(cf.mean()), R=0, n_paths=M, n_exercised=0)
+    x, t, y, _ = rows
+    fm, fs, ym, ysd = normalisers(x, t, y, T, dt)
+    net = make_net(7, nn_hidden, nn_layers, nn_dropout).to(S.device)
+    t1 = time.perf_counter()
+    info = train(net, x, t, y, fm, fs, ym, ysd, T, dt, nn_epochs, nn_lr, nn_batch, verbose)
+    torch.cuda.synchronize(S.device)
+    t2 = time.perf_counter()
+    cf, ex = pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
+    price = float(cf.mean())
+    t3 = time.perf_counter()
+    var = float(((cf - price) ** 2).mean())
+    info.update(price=price, std=math.sqrt(var), stderr=math.sqrt(var / M), R=int(x.numel()), n_paths=M,
+                n_exercised=int(ex.sum()), zero_prob=float((cf == 0).double().mean()),
+                Y_mean=float(ym), Y_std=float(ysd), seconds_collect=t1 - t0, seconds_train=t2 - t1,
+                seconds_pass2=t3 - t2, net=net, feat_mean=fm, feat_std=fs)
+    return info
+
+
+def price_two_pass_nn(pricer, S0, T, M, N, path_seed, torch_seed):
+    """Backend of AdvancedOptionPricer(regressor='nn').price_american_enhanced_lsm."""
+    torch = _torch()
+    dev = torch.device("cuda", pricer.device)
+    with torch.cuda.device(dev):
+        ctx = _ctx_on_torch_stream(pricer.device)
+        S = torch.empty((N + 1, M), dtype=torch.float32, device=dev)
+        generate_paths(ctx, S, pricer._model_kw(), S0, pricer.r, pricer.sigma or 0.0, T, path_seed)
+        out = price_with_paths(S, pricer.K, pricer.r, T, pricer.option_type == "put", torch_seed,
+                               nn_hidden=pricer.nn_hidden, nn_layers=pricer.nn_layers,
+                               nn_dropout=pricer.nn_dropout, nn_epochs=pricer.nn_epochs,
+                               nn_lr=pricer.nn_lr, verbose=pricer.verbose)
+    out.pop("net", None)
+    return out
+
+
+def price_american_option_nn(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", option_type="put",
+                             heston_params=None, seed=42, stream=0, device=0, nn_hidden=64,
+                             nn_layers=2, nn_dropout=0.1, nn_epochs=25, nn_lr=1e-3, nn_batch=None,
+                             inference_dropout=True):
+    """Facade backend for regressor='nn' (BASELINE config 5 names a 2x64 MLP)."""
+    from .api import PriceResult, _validate
+    torch = _torch()
+    model_l = str(model).lower()
+    _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
+    M = int(n_paths) // 2 * 2
+    dev = torch.device("cuda", device)
+    kw = dict(model=model_l, **heston_defaults(sigma, heston_params))
+    with torch.cuda.device(dev):
+        ctx = _ctx_on_torch_stream(device)
+        S = torch.empty((int(n_steps) + 1, M), dtype=torch.float32, device=dev)
+        generate_paths(ctx, S, kw, S0, r, sigma or 0.0, T, seed, stream)
+        out = price_with_paths(S, K, r, T, option_type == "put", seed + 1, nn_hidden, nn_layers,
+                               nn_dropout, nn_epochs, nn_lr, nn_batch, inference_dropout)
+    return PriceResult(price=out["price"], stderr=out.get("stderr", 0.0), std=out.get("std", 0.0),
+                       zero_prob=out.get("zero_prob", 0.0), n_paths=M,
+                       n_exercised=out.get("n_exercised", 0), sum_nitm=out.get("R", 0), model=model_l,
+                       semantics="two_pass", option_type=option_type,
+                       timings_ms={k: 1e3 * v for k, v in out.items() if k.startswith("seconds_")})

@@ -1,0 +1,114 @@
+"""GPU tests of the multi-GPU plumbing that can run on ONE card: the C-ABI all-reduce hook, the
+torch tensor aliasing of the device moment table, stream ordering, and the two-shard algebra
+(shard A's moments injected into shard B's all-reduce and vice versa == unsharded pricing).
+The real 8-GPU RCCL run is the driver's; tests/test_dist_cpu.py covers the gloo side."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K, R, SIG, T = 100.0, 0.05, 0.2, 1.0
+
+
+@pytest.fixture(scope="module")
+def tctx():
+    import torch
+
+    from options_model_amd import _ffi
+    from options_model_amd.dist import _DevPtr
+
+    assert torch.cuda.is_available()
+    stream = torch.cuda.Stream()
+    c = _ffi.Context(0, stream=stream.cuda_stream)
+    yield torch, stream, c, _DevPtr
+    c.close()
+
+
+def test_identity_hook_matches_hookless_run(tctx, ctx):
+    """hook = in-place no-op through a torch alias: exercises the external-moments code path
+    of every flow (per-step flows read gmom[t] instead of the launch partials)."""
+    torch, stream, c, DevPtr = tctx
+    from options_model_amd import _ffi
+    calls = []
+
+    def hook(dptr, count):
+        t = torch.as_tensor(DevPtr(dptr, count), device="cuda")
+        t.add_(0.0)
+        calls.append(count)
+
+    for sem, ncalls in (("two_pass", 1), ("reference", 29), ("textbook", 29)):
+        p = _ffi.make_params(semantics=sem, n_paths=20000, n_steps=30, seed=5)
+        base = ctx.price_american(p)
+        calls.clear()
+        c.set_allreduce_hook(hook)
+        with torch.cuda.stream(stream):
+            out = c.price_american(p)
+        c.set_allreduce_hook(None)
+        assert len(calls) == ncalls and set(calls) == ({8 * 31} if sem == "two_pass" else {8})
+        assert out["price"] == pytest.approx(base["price"], rel=1e-12)
+        assert (out["n_exercised"], out["n_zero"], out["sum_nitm"]) == (
+            base["n_exercised"], base["n_zero"], base["sum_nitm"])
+
+
+def test_two_shard_emulation_equals_unsharded(tctx, ctx):
+    torch, stream, c, DevPtr = tctx
+    from options_model_amd import _ffi
+    from options_model_amd import dist as omc_dist
+    M, N = 16384, 24
+    shards = [omc_dist.shard(M, 2, r) for r in range(2)]
+    mom = {}
+
+    def capture(key):
+        def h(dptr, count):
+            mom[key] = torch.as_tensor(DevPtr(dptr, count), device="cuda").clone()
+        return h
+
+    def inject(other):
+        def h(dptr, count):
+            torch.as_tensor(DevPtr(dptr, count), device="cuda").add_(mom[other])
+        return h
+
+    def run(rank, hook):
+        n, off = shards[rank]
+        c.set_allreduce_hook(hook)
+        with torch.cuda.stream(stream):
+            out = c.price_american(_ffi.make_params(semantics="two_pass", n_paths=n, n_steps=N, seed=9,
+                                                    pair_offset=off))
+        c.set_allreduce_hook(None)
+        return out
+
+    run(0, capture(0))
+    run(1, capture(1))
+    a = run(0, inject(1))
+    b = run(1, inject(0))
+    merged = omc_dist.merge(a, lambda v: [x + y for x, y in zip(v, [float(b[k]) for k in omc_dist.SUM_KEYS])])
+    full = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=M, n_steps=N, seed=9))
+    assert merged["n_paths"] == M
+    assert merged["price"] == pytest.approx(full["price"], rel=1e-12)
+    assert merged["n_exercised"] == full["n_exercised"] and merged["n_zero"] == full["n_zero"]
+
+
+def test_sharded_pricer_world_size_one():
+    """ShardedPricer end to end with a 1-rank gloo+nccl-free group is not possible; with
+    world_size 1 over nccl it must reduce to the plain pricing."""
+    import os
+
+    import torch
+    import torch.distributed as td
+
+    from options_model_amd import _ffi
+    from options_model_amd import dist as omc_dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sp = omc_dist.ShardedPricer(0)
+        out = sp.price_american(50_000, semantics="two_pass", n_steps=40, seed=3)
+        ref = _ffi.Context(0)
+        base = ref.price_american(_ffi.make_params(semantics="two_pass", n_paths=50_000, n_steps=40, seed=3))
+        ref.close()
+        assert out["price"] == pytest.approx(base["price"], rel=1e-12)
+        assert out["n_paths"] == 50_000 and out["stderr"] > 0
+        sp.close()
+    finally:
+        td.destroy_process_group()
