@@ -131,8 +131,10 @@ int omc_lsm_apply_frozen(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_pat
  * cross GPUs.  `hook(user, dptr, count)` must all-reduce (sum) `count` DEVICE doubles in place,
  * ordered on the context's stream (RCCL via torch.distributed on the host side).  It is called
  * ONCE with the whole [n_steps+1][8] moment table for the two-pass flow (decision-independent
- * moments), and once per time step with 8 doubles for the per-step flows.  The returned
- * omc_result carries LOCAL sums; the caller all-reduces {sum, sumsq, counts}. */
+ * moments), once per time step with 8 doubles for the per-step flows, and finally with the 8
+ * result sums {sum, sumsq, n_exercised, n_zero, sum_nitm, ..}.  With a hook installed the
+ * returned omc_result therefore carries GLOBAL sums and is normalised by
+ * n_paths * world_size (omc_set_option(ctx, "world_size", W); shards are equal). */
 typedef int (*omc_allreduce_fn)(void* user, double* dptr, int count);
 int omc_set_allreduce_hook(omc_ctx* ctx, omc_allreduce_fn fn, void* user);
 

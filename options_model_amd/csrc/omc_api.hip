@@ -77,6 +77,7 @@ struct omc_ctx {
     double hres[8];
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int gbm_vec = 0, heston_vec = 0, use_graph = 0;
+    int world = 1;  // ranks whose sums the hook adds up (equal shards)
     omc_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
 };
@@ -185,6 +186,10 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
             }
         }
         HIP_TRY(omc::lsm_final_reduce(st, p, w, semantics == OMC_SEM_TEXTBOOK ? 0 : 1));
+    }
+    if (c->hook) {  // {sum, sumsq, n_exercised, n_zero, sum_nitm, ..} -> global sums
+        int rc = c->hook(c->hook_user, w.result, 8);
+        if (rc) return fail(998, "all-reduce hook failed");
     }
     return 0;
 }
@@ -341,6 +346,7 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     if (!strcmp(key, "gbm_vec")) c->gbm_vec = (int)value;
     else if (!strcmp(key, "heston_vec")) c->heston_vec = (int)value;
     else if (!strcmp(key, "use_graph")) c->use_graph = (int)value;
+    else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
     else return fail(-4, "unknown option key.");
     return 0;
 }
@@ -478,7 +484,7 @@ int omc_lsm_poly(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     if ((rc = copy_outputs(c, w, n_paths, n_steps, betas_out, sx_out, tex_out))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     memset(res, 0, sizeof *res);
-    fill_result(res, c->hres, n_paths);
+    fill_result(res, c->hres, c->hook ? n_paths * c->world : n_paths);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     res->ms_lsm = ms;
@@ -565,7 +571,7 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memset(res, 0, sizeof *res);
-    fill_result(res, c->hres, M);
+    fill_result(res, c->hres, c->hook ? M * c->world : M);  // hook: sums are global
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     res->ms_paths = ms;

@@ -72,20 +72,19 @@ class ShardedPricer:
         self.stream = torch.cuda.Stream(self.device)
         self.ctx = _ffi.Context(local_rank, stream=self.stream.cuda_stream)
         self._ffi = _ffi
-        with torch.cuda.stream(self.stream):
-            self._sums = torch.zeros(len(SUM_KEYS), dtype=torch.float64, device=self.device)
+        self._alias = {}
         if self.world > 1:
+            # the library calls the hook for the moment table(s) AND for its 8 result sums, and
+            # normalises by n_local * world_size: the returned omc_result is already global
             self.ctx.set_allreduce_hook(self._allreduce_device)
+            self.ctx.set_option("world_size", self.world)
 
     def _allreduce_device(self, dptr: int, count: int):
-        t = self.torch.as_tensor(_DevPtr(dptr, count), device=self.device)
+        t = self._alias.get((dptr, count))
+        if t is None:  # workspace pointers are stable across pricings of one size
+            t = self.torch.as_tensor(_DevPtr(dptr, count), device=self.device)
+            self._alias[(dptr, count)] = t
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-
-    def _allreduce_host(self, vals):
-        self._sums.copy_(self.torch.tensor(vals, dtype=self.torch.float64))
-        if self.world > 1:
-            self.dist.all_reduce(self._sums, op=self.dist.ReduceOp.SUM, group=self.group)
-        return self._sums.tolist()
 
     def price_american(self, n_paths_global: int, **kw) -> dict:
         """kw: arguments of _ffi.make_params except n_paths / pair_offset."""
@@ -93,9 +92,10 @@ class ShardedPricer:
         n_local, off = shard(n_paths_global, self.world, self.rank, anti)
         p = self._ffi.make_params(n_paths=n_local, pair_offset=off, **kw)
         with self.torch.cuda.stream(self.stream):  # the hook's all_reduce sees this stream as current
-            local = self.ctx.price_american(p)
-            out = merge(local, self._allreduce_host)
-        out["local"] = local
+            res = self.ctx.price_american(p)
+        # with world > 1 the sums in `res` are global already (see __init__)
+        out = merge(res, lambda v: v)
+        out["local"] = res
         return out
 
     def close(self):

@@ -36,7 +36,8 @@ def test_identity_hook_matches_hookless_run(tctx, ctx):
         t.add_(0.0)
         calls.append(count)
 
-    for sem, ncalls in (("two_pass", 1), ("reference", 29), ("textbook", 29)):
+    # moments: once (two-pass) or once per step t = N-1..1 (per-step flows); + the 8 result sums
+    for sem, ncalls in (("two_pass", 2), ("reference", 30), ("textbook", 30)):
         p = _ffi.make_params(semantics=sem, n_paths=20000, n_steps=30, seed=5)
         base = ctx.price_american(p)
         calls.clear()
@@ -44,7 +45,7 @@ def test_identity_hook_matches_hookless_run(tctx, ctx):
         with torch.cuda.stream(stream):
             out = c.price_american(p)
         c.set_allreduce_hook(None)
-        assert len(calls) == ncalls and set(calls) == ({8 * 31} if sem == "two_pass" else {8})
+        assert len(calls) == ncalls and set(calls) == ({8 * 31, 8} if sem == "two_pass" else {8})
         assert out["price"] == pytest.approx(base["price"], rel=1e-12)
         assert (out["n_exercised"], out["n_zero"], out["sum_nitm"]) == (
             base["n_exercised"], base["n_zero"], base["sum_nitm"])
@@ -60,12 +61,14 @@ def test_two_shard_emulation_equals_unsharded(tctx, ctx):
 
     def capture(key):
         def h(dptr, count):
-            mom[key] = torch.as_tensor(DevPtr(dptr, count), device="cuda").clone()
+            if count == 8 * (N + 1):  # the moment table (the 8 result sums stay local here)
+                mom[key] = torch.as_tensor(DevPtr(dptr, count), device="cuda").clone()
         return h
 
     def inject(other):
         def h(dptr, count):
-            torch.as_tensor(DevPtr(dptr, count), device="cuda").add_(mom[other])
+            if count == 8 * (N + 1):
+                torch.as_tensor(DevPtr(dptr, count), device="cuda").add_(mom[other])
         return h
 
     def run(rank, hook):
@@ -86,6 +89,30 @@ def test_two_shard_emulation_equals_unsharded(tctx, ctx):
     assert merged["n_paths"] == M
     assert merged["price"] == pytest.approx(full["price"], rel=1e-12)
     assert merged["n_exercised"] == full["n_exercised"] and merged["n_zero"] == full["n_zero"]
+
+
+def test_world_size_normalisation_with_doubling_hook(tctx, ctx):
+    """Two identical 'ranks': an all-reduce that doubles every buffer.  Moments x2 give the same
+    fits; the library's own result sums go through the hook too and are normalised by
+    n_local * world_size, so the price is unchanged and the counts double."""
+    torch, stream, c, DevPtr = tctx
+    from options_model_amd import _ffi
+
+    def hook(dptr, count):
+        torch.as_tensor(DevPtr(dptr, count), device="cuda").mul_(2.0)
+
+    for sem in ("two_pass", "reference"):
+        p = _ffi.make_params(semantics=sem, n_paths=30000, n_steps=20, seed=8)
+        base = ctx.price_american(p)
+        c.set_allreduce_hook(hook)
+        c.set_option("world_size", 2)
+        with torch.cuda.stream(stream):
+            out = c.price_american(p)
+        c.set_allreduce_hook(None)
+        c.set_option("world_size", 1)
+        assert out["n_paths"] == 60000 and out["n_exercised"] == 2 * base["n_exercised"]
+        assert out["price"] == pytest.approx(base["price"], rel=1e-12)
+        assert out["std"] == pytest.approx(base["std"], rel=1e-9)
 
 
 def test_sharded_pricer_world_size_one():

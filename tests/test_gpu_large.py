@@ -1,0 +1,95 @@
+"""BASELINE-size checks through size-independent properties (the oracle is too slow to rerun at
+these sizes inside a test): martingale of the generators, shard-count invariance through the
+real all-reduce hook, determinism, flow ordering and agreement between sizes."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HP = dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7)
+
+
+def _last_row(ctx, S, M, N):
+    last = np.empty(M, np.float32)
+    ctx.lib.omc_memcpy_d2h(ctx.handle, last.ctypes.data, S.ptr + 4 * M * N, 4 * M)
+    return last.astype(np.float64)
+
+
+def test_config4_heston_martingale_and_european_consistency(ctx):
+    """4M x 252 Heston paths (config 4 size): E[S_T] = S0 e^{rT}; the stored-path terminal row
+    and the register-only European kernel see the same paths (same Philox stream)."""
+    from options_model_amd import _ffi
+    M, N = 4_000_000, 252
+    S = ctx.heston_paths(M, N, 100.0, 0.05, 1.0, seed=21, stream=1, **HP)
+    x = _last_row(ctx, S, M, N)
+    S.free()
+    assert abs(x.mean() - 100 * math.exp(0.05)) < 5 * x.std() / math.sqrt(M)
+    call = np.maximum(x - 100.0, 0) * math.exp(-0.05)
+    eu = ctx.price_european(_ffi.make_params(model="heston", is_put=False, n_paths=M, n_steps=N, seed=21,
+                                             stream=1, **HP))
+    assert eu["price"] == pytest.approx(call.mean(), rel=1e-6)
+
+
+def test_config2_flows_are_ordered_and_reproducible(ctx):
+    """1M x 252 GBM put: textbook LSM sits at the binomial anchor (~6.09, low-biased), the
+    reference's sticky flows sit where SURVEY F2-F4 says (per-step below, two-pass above),
+    European < textbook; the same call twice is bit-identical."""
+    from options_model_amd import _ffi
+    M, N = 1_000_000, 252
+    out = {}
+    for sem in ("two_pass", "reference", "textbook"):
+        p = _ffi.make_params(semantics=sem, n_paths=M, n_steps=N, seed=1234)
+        a = ctx.price_american(p)
+        b = ctx.price_american(p)
+        assert a["price"] == b["price"] and a["sumsq"] == b["sumsq"] and a["n_exercised"] == b["n_exercised"]
+        out[sem] = a
+    eu = ctx.price_european(_ffi.make_params(n_paths=M, n_steps=N, seed=1234))
+    assert 6.02 < out["textbook"]["price"] < 6.12
+    assert eu["price"] < out["textbook"]["price"] < out["two_pass"]["price"]
+    assert abs(eu["price"] - 5.573526022256971) < 0.03
+    assert out["two_pass"]["sum_nitm"] > out["reference"]["sum_nitm"]  # sticky mask shrinks the sets
+    # the 8M-path config-3 shard agrees with the 1M-path run within Monte-Carlo error
+    big = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=8_000_000, n_steps=N, seed=99))
+    se = math.sqrt(out["two_pass"]["std"] ** 2 / M + big["std"] ** 2 / 8e6)
+    assert abs(big["price"] - out["two_pass"]["price"]) < 5 * se + 0.01
+
+
+def test_config3_style_shard_invariance_at_full_row_length(ctx):
+    """2 x 500k-path shards with the moment tables exchanged through the hook == one 1M run."""
+    import torch
+
+    from options_model_amd import _ffi
+    from options_model_amd import dist as omc_dist
+    from options_model_amd.dist import _DevPtr
+    M, N = 1_000_000, 252
+    stream = torch.cuda.Stream()
+    c = _ffi.Context(0, stream=stream.cuda_stream)
+    mom = {}
+
+    def run(rank, mode):
+        n, off = omc_dist.shard(M, 2, rank)
+
+        def h(dptr, count):
+            if count != 8 * (N + 1):
+                return
+            t = torch.as_tensor(_DevPtr(dptr, count), device="cuda")
+            if mode == "capture":
+                mom[rank] = t.clone()
+            else:
+                t.add_(mom[1 - rank])
+
+        c.set_allreduce_hook(h)
+        with torch.cuda.stream(stream):
+            out = c.price_american(_ffi.make_params(semantics="two_pass", n_paths=n, n_steps=N, seed=5,
+                                                    pair_offset=off))
+        c.set_allreduce_hook(None)
+        return out
+
+    run(0, "capture"), run(1, "capture")
+    a, b = run(0, "inject"), run(1, "inject")
+    c.close()
+    full = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=M, n_steps=N, seed=5))
+    assert (a["sum"] + b["sum"]) / M == pytest.approx(full["price"], rel=1e-12)
+    assert a["n_exercised"] + b["n_exercised"] == full["n_exercised"]
