@@ -270,62 +270,88 @@ template <int VEC, int TPW>
 __global__ __launch_bounds__(kBlock) void lsm_pass1_kernel(Pass1Args a)
 {
     __shared__ double wl[kBlock / 64][kWaveRedDoubles];
+    __shared__ double shD[kBlock / 64][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tg = (int64_t)blockIdx.x * (kBlock / 64) + wave;
     if (tg >= a.ntiles) return;  // whole wave leaves; no workgroup barrier below
     const int64_t base = tg * (64 * VEC * TPW) + (int64_t)lane * VEC;
     const int t0 = 1 + blockIdx.y * a.tchunk;
     const int t1 = min(t0 + a.tchunk, a.N);
+    if (t0 >= t1) return;
     const double K = a.K, invK = a.invK;
     const int is_put = a.is_put;
+    // The chunk's discount factors go through the wave's LDS patch: a vector-memory load of
+    // D[N-t] inside the loop would sit behind the row prefetch in the in-order vmcnt queue
+    // and expose the prefetch latency every step.
+    if (lane < t1 - t0) shD[wave][lane] = a.D[a.N - (t0 + lane)];
+    // Padding columns (beyond M) read column 0 and are masked out: every load below is
+    // unconditional, so the compiler can count outstanding loads instead of draining them.
+    const float* colp[TPW];
     double pN[TPW][VEC];
     bool valid[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         const int64_t j = base + (int64_t)k * 64 * VEC;
         valid[k] = j < a.M;
+        colp[k] = a.S + (valid[k] ? j : 0);
         float sn[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) sn[v] = 0.f;
-        if (valid[k]) loadf<VEC>(a.S + (int64_t)a.N * a.ld + j, sn);
+        loadf<VEC>(colp[k] + (int64_t)a.N * a.ld, sn);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const double p = payoff_d(sn[v], K, is_put);
             pN[k][v] = (valid[k] && p > 0.0) ? p : 0.0;
         }
     }
-    float cur[TPW][VEC], nxt[TPW][VEC];
+    auto load_rows = [&](float (&buf)[TPW][VEC], int t) {
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) cur[k][v] = nxt[k][v] = 0.f;
-        if (valid[k] && t0 < t1) loadf<VEC>(a.S + (int64_t)t0 * a.ld + base + (int64_t)k * 64 * VEC, cur[k]);
-    }
-    for (int t = t0; t < t1; ++t) {
-        if (t + 1 < t1) {
-#pragma unroll
-            for (int k = 0; k < TPW; ++k)
-                if (valid[k]) loadf<VEC>(a.S + (int64_t)(t + 1) * a.ld + base + (int64_t)k * 64 * VEC, nxt[k]);
-        }
+        for (int k = 0; k < TPW; ++k) loadf<VEC>(colp[k] + (int64_t)t * a.ld, buf[k]);
+    };
+    // Branch-free accumulation: an out-of-the-money (or padding) path contributes u = 0, p = 0
+    // (adding +0.0 is exact, so the sums are those of the masked loop, bit for bit), the set
+    // size is counted in integers, and the step's discount factor multiplies the three target
+    // sums once per lane instead of once per path.
+    auto process = [&](const float (&buf)[TPW][VEC], int t) {
         double acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-        const double d = a.D[a.N - t];
+        int cnt = 0;
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const double imm = payoff_d(cur[k][v], K, is_put);
-                if (valid[k] && imm > 0.0)
-                    accumulate_moments(acc, fma((double)cur[k][v], invK, -1.0), pN[k][v] * d);
+                const double sd = (double)buf[k][v];
+                const double imm = is_put ? K - sd : sd - K;
+                const bool itm = valid[k] && imm > 0.0;
+                const double u = itm ? fma(sd, invK, -1.0) : 0.0;
+                const double p = itm ? pN[k][v] : 0.0;
+                const double u2 = u * u;
+                cnt += itm ? 1 : 0;
+                acc[1] += u;
+                acc[2] += u2;
+                acc[3] = fma(u2, u, acc[3]);
+                acc[4] = fma(u2, u2, acc[4]);
+                acc[5] += p;
+                acc[6] = fma(u, p, acc[6]);
+                acc[7] = fma(u2, p, acc[7]);
             }
         }
+        const double d = shD[wave][t - t0];
+        acc[0] = (double)cnt;
+        acc[5] *= d;
+        acc[6] *= d;
+        acc[7] *= d;
         const double s = wave_reduce8(acc, wl[wave]);
         if ((lane & 7) == 0) a.part1[((size_t)t * 8 + (lane >> 3)) * a.ntiles + tg] = s;
-#pragma unroll
-        for (int k = 0; k < TPW; ++k) {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) cur[k][v] = nxt[k][v];
+    };
+    // two register buffers, rows fetched one step ahead of their use
+    float bufA[TPW][VEC], bufB[TPW][VEC];
+    load_rows(bufA, t0);
+    for (int t = t0; t < t1; t += 2) {
+        load_rows(bufB, min(t + 1, t1 - 1));
+        process(bufA, t);
+        if (t + 1 < t1) {
+            load_rows(bufA, min(t + 2, t1 - 1));
+            process(bufB, t + 1);
         }
     }
 }
@@ -334,18 +360,19 @@ __global__ __launch_bounds__(kBlock) void lsm_reduce_pass1_kernel(const double* 
                                                                   double* __restrict__ gmom,
                                                                   int64_t ntiles)
 {
-    __shared__ double red[kNQ * kRedStride];
+    // one workgroup per (step, quantity): 8x more workgroups than one per step, each with a
+    // short strided sum -- the slab read is latency-bound, so parallelism is what it needs
+    __shared__ double sh[kBlock / 64];
     const int tid = threadIdx.x;
-    const int t = blockIdx.x + 1;
-    double acc[8];
+    const int t = blockIdx.x + 1, q = blockIdx.y;
+    const double* pp = part1 + ((size_t)t * 8 + q) * ntiles;
+    double s = 0.0;
+    for (int64_t i = tid; i < ntiles; i += kBlock) s += pp[i];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        acc[q] = 0.0;
-        const double* pp = part1 + ((size_t)t * 8 + q) * ntiles;
-        for (int64_t i = tid; i < ntiles; i += kBlock) acc[q] += pp[i];
-    }
-    const double s = block_reduce8(acc, red);
-    if (tid < 64 && (tid & 7) == 0) gmom[(size_t)t * 8 + (tid >> 3)] = s;
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) gmom[(size_t)t * 8 + q] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 __global__ void lsm_solve_all_kernel(const double* __restrict__ gmom, double* __restrict__ betas,
@@ -384,7 +411,13 @@ __global__ __launch_bounds__(kBlock) void lsm_pass2_kernel(Pass2Args a)
     extern __shared__ double sh_b[];  // [N+1][4]
     const int tid = threadIdx.x;
     const int N = a.N;
-    for (int k = tid; k < (N + 1) * 4; k += kBlock) sh_b[k] = (k >= 4 && k < N * 4) ? a.betas[k] : 0.0;
+    // a step with an empty regression set never exercises: give it an infinite continuation
+    // value instead of a branch in the sweep
+    for (int k = tid; k < (N + 1) * 4; k += kBlock) {
+        const int t = k >> 2;
+        const bool fit = t >= 1 && t < N && a.betas[(size_t)t * 4 + 3] > 0.5;
+        sh_b[k] = fit ? a.betas[k] : ((k & 3) == 0 ? __builtin_huge_val() : 0.0);
+    }
     __syncthreads();
     const double K = a.K, invK = a.invK;
     const int is_put = a.is_put;
@@ -398,31 +431,41 @@ __global__ __launch_bounds__(kBlock) void lsm_pass2_kernel(Pass2Args a)
         loadf<VEC>(a.S + (int64_t)N * a.ld + j, sx);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) tex[v] = N;
-        int live = VEC;
-        constexpr int U = 4;
-        for (int tb = N - 1; tb >= 1 && live > 0; tb -= U) {
+        // One row of decisions, branch-free: a path that has already exercised (tex != N), is
+        // out of the money, or sits below the fitted continuation value keeps its state.
+        auto decide = [&](const float (&row)[VEC], int t) {
+            const double b0 = sh_b[4 * t], b1 = sh_b[4 * t + 1], b2 = sh_b[4 * t + 2];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double sd = (double)row[v];
+                const double imm = is_put ? K - sd : sd - K;
+                const double u = fma(sd, invK, -1.0);
+                const double cont = fma(u, fma(u, b2, b1), b0);
+                const bool ex = (tex[v] == N) & (imm > 0.0) & (imm > cont);
+                sx[v] = ex ? row[v] : sx[v];
+                tex[v] = ex ? t : tex[v];
+            }
+        };
+        auto live = [&]() {
+            bool l = false;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) l |= (tex[v] == N);
+            return l;
+        };
+        constexpr int U = 8;  // full blocks of U rows: U unconditional 16-byte loads in flight per lane
+        int t = N - 1;
+        const float* col = a.S + j;
+        for (; t >= U && live(); t -= U) {
             float st[U][VEC];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                if (tb - k >= 1) loadf<VEC>(a.S + (int64_t)(tb - k) * a.ld + j, st[k]);
-            }
+            for (int k = 0; k < U; ++k) loadf<VEC>(col + (int64_t)(t - k) * a.ld, st[k]);
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const int t = tb - k;
-                if (t < 1) break;
-                const double* b = sh_b + 4 * t;
-                if (!(b[3] > 0.5)) continue;
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    if (tex[v] != N) continue;
-                    const double imm = payoff_d(st[k][v], K, is_put);
-                    if (imm > 0.0) {
-                        const double u = fma((double)st[k][v], invK, -1.0);
-                        const double cont = fma(u, fma(u, b[2], b[1]), b[0]);
-                        if (imm > cont) { sx[v] = st[k][v]; tex[v] = t; --live; }
-                    }
-                }
-            }
+            for (int k = 0; k < U; ++k) decide(st[k], t - k);
+        }
+        for (; t >= 1 && live(); --t) {
+            float st[VEC];
+            loadf<VEC>(col + (int64_t)t * a.ld, st);
+            decide(st, t);
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -565,14 +608,20 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
     a.K = p.K; a.invK = 1.0 / p.K; a.D = w.D; a.part1 = w.part1;
     const bool v4 = vec4_ok(p);
-    constexpr int kTpw = 4;
-    const int64_t per_wave = 64 * (int64_t)(v4 ? 4 : 1) * kTpw;  // paths per wave per step
+    // tuning knobs (defaults measured on MI355X): tiles per wave, steps per block
+    static const int tpw_env = getenv("OMC_PASS1_TPW") ? atoi(getenv("OMC_PASS1_TPW")) : 0;
+    static const int tch_env = getenv("OMC_PASS1_TCHUNK") ? atoi(getenv("OMC_PASS1_TCHUNK")) : 0;
+    const int tpw = (v4 && (tpw_env == 1 || tpw_env == 2 || tpw_env == 8)) ? tpw_env : 4;
+    const int64_t per_wave = 64 * (int64_t)(v4 ? 4 : 1) * tpw;  // paths per wave per step
     a.ntiles = (p.M + per_wave - 1) / per_wave;
-    a.tchunk = 16;
+    a.tchunk = (tch_env >= 2 && tch_env <= 64) ? tch_env : 16;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
-    if (v4) hipLaunchKernelGGL((lsm_pass1_kernel<4, kTpw>), grid, dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((lsm_pass1_kernel<1, kTpw>), grid, dim3(kBlock), 0, st, a);
-    hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1), dim3(kBlock), 0, st, w.part1, w.gmom,
+    if (!v4) hipLaunchKernelGGL((lsm_pass1_kernel<1, 4>), grid, dim3(kBlock), 0, st, a);
+    else if (tpw == 1) hipLaunchKernelGGL((lsm_pass1_kernel<4, 1>), grid, dim3(kBlock), 0, st, a);
+    else if (tpw == 2) hipLaunchKernelGGL((lsm_pass1_kernel<4, 2>), grid, dim3(kBlock), 0, st, a);
+    else if (tpw == 8) hipLaunchKernelGGL((lsm_pass1_kernel<4, 8>), grid, dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((lsm_pass1_kernel<4, 4>), grid, dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1, 8), dim3(kBlock), 0, st, w.part1, w.gmom,
                        a.ntiles);
     return hipGetLastError();
 }
