@@ -148,6 +148,16 @@ int omc_price_american(omc_ctx* ctx, const omc_params* p, omc_result* res, float
  * price_european_streaming options_model_3.py:382-437; sums2 host {sum, sumsq} */
 int omc_price_european(omc_ctx* ctx, const omc_params* p, omc_result* res);
 
+/* ---- many small pricings in one go ------------------------------------------------------- */
+/* replaces the curve loops compute_curve_for_S0 (options_model_3.py:697-713, Options_model.py:
+ * 190-211, options_model_2.py:336-355) and their ProcessPoolExecutor fan-out: n independent
+ * problems (each its own S0, T, n_steps, n_paths, seed ...) run as ONE set of launches with
+ * the batch index on the grid.  All problems of a call share model, semantics, antithetic and
+ * Heston scheme; results are identical to n calls of omc_price_american / omc_price_european.
+ * Whole-batch kernel times are reported in res[0]. */
+int omc_price_american_batch(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
+int omc_price_european_batch(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
+
 #ifdef __cplusplus
 }
 #endif

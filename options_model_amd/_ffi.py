@@ -72,6 +72,8 @@ SIGNATURES = {
     "omc_set_allreduce_hook": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "omc_price_american": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result), _P, _I64]),
     "omc_price_european": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result)]),
+    "omc_price_american_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
+    "omc_price_european_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
 }
 
 _lib = None
@@ -348,6 +350,26 @@ class Context:
         res = Result()
         _check(self.lib, self.lib.omc_price_european(self.handle, C.byref(params), C.byref(res)))
         return res.as_dict()
+
+    # -- many small pricings as one set of launches (all share model/semantics/antithetic)
+    MAX_BATCH = 65535
+
+    def _batch(self, fn, params_list):
+        out = []
+        for lo in range(0, len(params_list), self.MAX_BATCH):
+            chunk = params_list[lo:lo + self.MAX_BATCH]
+            n = len(chunk)
+            arr = (Params * n)(*chunk)
+            res = (Result * n)()
+            _check(self.lib, fn(self.handle, arr, n, res))
+            out.extend(r.as_dict() for r in res)
+        return out
+
+    def price_american_batch(self, params_list):
+        return self._batch(self.lib.omc_price_american_batch, list(params_list))
+
+    def price_european_batch(self, params_list):
+        return self._batch(self.lib.omc_price_european_batch, list(params_list))
 
 
 def make_params(model="gbm", is_put=True, semantics="reference", antithetic=True,

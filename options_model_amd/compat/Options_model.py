@@ -37,12 +37,31 @@ def price_american_option(S0, K, T, r, sigma, num_simulations=10000, num_time_st
 
 def compute_curve_for_S0(S0, K, r, sigma, num_simulations, intervals_per_day, total_points,
                          option_type, lsm_poly_degree, plot_paths, seed):
-    records = []
+    """Options_model.py:190-211.  All points share `seed` (the reference reseeds per pricing),
+    are independent, and therefore run as one batched set of launches."""
+    points = []
     for i in range(total_points, 0, -1):
         d = i / intervals_per_day
-        steps = max(10, min(130, int(math.ceil(d))))
-        price, std, zero = price_american_option(S0, K, d / 365, r, sigma, num_simulations, steps,
-                                                 option_type, lsm_poly_degree, plot_paths, seed)
-        records.append({"S0": S0, "Days to Expiry": d, "Option Value": price, "Std Dev": std,
-                        "Zero Prob": zero})
-    return records
+        points.append((d, d / 365, max(10, min(130, int(math.ceil(d))))))
+    if not points:
+        return []
+    # same validation (and messages) as the per-point call
+    if S0 <= 0 or K <= 0 or sigma <= 0:
+        raise ValueError("S0, K, T, and sigma must be positive.")
+    if r < 0:
+        raise ValueError("r must be non-negative.")
+    if num_simulations <= 0:
+        raise ValueError("num_simulations and num_time_steps must be positive integers.")
+    if not isinstance(lsm_poly_degree, int) or lsm_poly_degree < 0:
+        raise ValueError("lsm_poly_degree must be a non-negative integer.")
+    if option_type not in ("call", "put"):
+        raise ValueError("option_type must be 'call' or 'put'.")
+    M = int(num_simulations) // 2 * 2
+    if M == 0:
+        raise ValueError("num_simulations and num_time_steps must be positive integers.")
+    params = [_ffi.make_params(model="gbm", is_put=(option_type == "put"), semantics="reference",
+                               n_paths=M, n_steps=steps, S0=S0, K=K, r=r, sigma=sigma, T=T,
+                               seed=int(seed), stream=0) for _, T, steps in points]
+    outs = _ffi.default_context().price_american_batch(params)
+    return [{"S0": S0, "Days to Expiry": d, "Option Value": o["price"], "Std Dev": o["std"],
+             "Zero Prob": o["zero_prob"]} for (d, _, _), o in zip(points, outs)]

@@ -40,14 +40,7 @@ class OptionPricer:
         M = int(num_simulations) // 2 * 2
         if M == 0:
             raise ValueError("num_simulations and num_time_steps must be positive integers.")
-        if self.use_heston and self.heston_params is not None:
-            kw = dict(model="heston", **heston_defaults(self.sigma, self.heston_params))
-        else:
-            kw = dict(model="gbm")
-        p = _ffi.make_params(is_put=(self.option_type == "put"), semantics="reference", n_paths=M,
-                             n_steps=int(num_time_steps), S0=S0, K=self.K, r=self.r,
-                             sigma=self.sigma or 0.0, T=T, seed=int(self.seed), stream=0, **kw)
-        out = _ffi.default_context().price_american(p)
+        out = _ffi.default_context().price_american(self._params(S0, T, M, num_time_steps))
         self.last_result = out
         if self.verbose:
             logging.info(f"Probability option expires worthless: {out['zero_prob']:.2%}")
@@ -56,15 +49,41 @@ class OptionPricer:
                          f"simulations={num_simulations}, steps={num_time_steps}, heston={self.use_heston})")
         return out["price"]
 
+    def _params(self, S0, T, M, steps):
+        if self.use_heston and self.heston_params is not None:
+            kw = dict(model="heston", **heston_defaults(self.sigma, self.heston_params))
+        else:
+            kw = dict(model="gbm")
+        return _ffi.make_params(is_put=(self.option_type == "put"), semantics="reference", n_paths=M,
+                                n_steps=int(steps), S0=S0, K=self.K, r=self.r,
+                                sigma=self.sigma or 0.0, T=T, seed=int(self.seed), stream=0, **kw)
+
     def compute_curve_for_S0(self, S0: float, intervals_per_day: int, total_points: int,
                              num_simulations: int, plot_paths: bool) -> List[Dict[str, Any]]:
-        records = []
+        """options_model_2.py:336-355: independent points, every one reseeded with self.seed ->
+        one batched set of launches instead of a loop of pricings."""
+        points = []
         for i in range(total_points, 0, -1):
             d = i / intervals_per_day
-            steps = max(10, min(130, int(math.ceil(d))))
-            price = self.price_american_option(S0, d / 365, num_simulations, steps, plot_paths)
-            records.append({"S0": S0, "Days to Expiry": d, "Option Value": price})
-        return records
+            points.append((d, d / 365, max(10, min(130, int(math.ceil(d))))))
+        if not points:
+            return []
+        if S0 <= 0 or self.K <= 0 or (self.sigma is None and not self.use_heston):
+            raise ValueError("S0, K, T, and sigma must be positive.")
+        if self.r < 0:
+            raise ValueError("r must be non-negative.")
+        if num_simulations <= 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        if not isinstance(self.lsm_poly_degree, int) or self.lsm_poly_degree < 0:
+            raise ValueError("lsm_poly_degree must be a non-negative integer.")
+        if self.option_type not in ("call", "put"):
+            raise ValueError("option_type must be 'call' or 'put'.")
+        M = int(num_simulations) // 2 * 2
+        if M == 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        outs = _ffi.default_context().price_american_batch([self._params(S0, T, M, st) for _, T, st in points])
+        self.last_result = outs[-1]
+        return [{"S0": S0, "Days to Expiry": d, "Option Value": o["price"]} for (d, _, _), o in zip(points, outs)]
 
 
 def compute_curve_worker(S0, K, r, sigma, option_type, lsm_poly_degree, seed, intervals_per_day,

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/omc.h"
+#include "omc_batch.h"
 #include "omc_kernels.h"
 
 namespace {
@@ -70,6 +71,9 @@ struct omc_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf S, sx, tex, D, part, gmom, betas, part1, result, scratch;
+    DevBuf bslab, btable, bres, bdisc;  // batched path: problem slab, table, results, discounts
+    std::vector<char> h_table;
+    std::vector<double> h_disc, h_bres;
     std::vector<double> hD;
     int D_N = -1;
     double D_r = 0, D_T = 0;
@@ -283,7 +287,7 @@ int omc_ctx_destroy(omc_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
-                      &c->result, &c->scratch})
+                      &c->result, &c->scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc})
         b->release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -610,6 +614,93 @@ int omc_price_european(omc_ctx* c, const omc_params* p, omc_result* res)
     res->ms_paths = ms;
     res->ms_total = ms;
     return 0;
+}
+
+// ------------------------------------------------------------------ batched small pricings
+static int check_batch(const omc_params* p, int n)
+{
+    if (!p || n <= 0) return fail(-7, "empty batch.");
+    if (n > 65535) return fail(-3, "batch too large (max 65535 problems per call).");
+    for (int i = 0; i < n; ++i) {
+        int rc = check_params(&p[i]);
+        if (rc) return rc;
+        if (p[i].model != p[0].model || p[i].semantics != p[0].semantics ||
+            p[i].antithetic != p[0].antithetic || p[i].heston_scheme != p[0].heston_scheme)
+            return fail(-4, "a batch must share model, semantics, antithetic and Heston scheme.");
+    }
+    return 0;
+}
+
+static int generator_id(const omc_params* p)
+{
+    if (p->model == OMC_MODEL_GBM) return p->antithetic ? 0 : 1;
+    return p->heston_scheme == 0 ? 2 : 3;
+}
+
+static int run_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res, bool american)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_batch(p, n))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    if (c->hook) return fail(-4, "batched pricing is single-GPU (no all-reduce hook).");
+    const bool two_pass = p[0].semantics == OMC_SEM_TWO_PASS;
+    const size_t slab = omc::batch_slab_bytes(p, n, american, two_pass);
+    const size_t nd = american ? omc::batch_discount_doubles(p, n) : 0;
+    if ((rc = c->bslab.ensure(slab))) return rc;
+    if ((rc = c->btable.ensure(omc::batch_table_bytes(n)))) return rc;
+    if ((rc = c->bres.ensure(sizeof(double) * 8 * (size_t)n))) return rc;
+    if ((rc = c->bdisc.ensure(sizeof(double) * (nd ? nd : 1)))) return rc;
+    c->h_table.resize(omc::batch_table_bytes(n));
+    c->h_disc.resize(nd ? nd : 1);
+    c->h_bres.resize(8 * (size_t)n);
+    omc::BatchExtents e;
+    omc::batch_build(p, n, american, two_pass, (char*)c->bslab.p, (double*)c->bres.p,
+                     (double*)c->bdisc.p, c->h_table.data(), c->h_disc.data(), &e);
+    HIP_TRY(hipMemcpyAsync(c->btable.p, c->h_table.data(), c->h_table.size(), hipMemcpyHostToDevice,
+                           c->stream));
+    if (nd)
+        HIP_TRY(hipMemcpyAsync(c->bdisc.p, c->h_disc.data(), sizeof(double) * nd, hipMemcpyHostToDevice,
+                               c->stream));
+    if (!american) HIP_TRY(hipMemsetAsync(c->bslab.p, 0, slab, c->stream));  // unused partial rows
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    const int gen = generator_id(&p[0]);
+    if (american) {
+        HIP_TRY(omc::batch_paths(c->stream, c->btable.p, n, e, gen));
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        HIP_TRY(omc::batch_lsm(c->stream, c->btable.p, n, e, p[0].semantics));
+    } else {
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        HIP_TRY(omc::batch_terminal(c->stream, c->btable.p, n, e, gen));
+    }
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_bres.data(), c->bres.p, sizeof(double) * 8 * (size_t)n,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms_a = 0, ms_b = 0;
+    HIP_TRY(hipEventElapsedTime(&ms_a, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms_b, c->ev[1], c->ev[2]));
+    for (int i = 0; i < n; ++i) {
+        double* h = c->h_bres.data() + 8 * (size_t)i;
+        if (!american) { h[2] = 0.0; h[4] = 0.0; }
+        memset(&res[i], 0, sizeof res[i]);
+        fill_result(&res[i], h, p[i].n_paths);
+    }
+    // whole-batch times are reported on the first entry
+    res[0].ms_paths = american ? ms_a : ms_b;
+    res[0].ms_lsm = american ? ms_b : 0.0;
+    res[0].ms_total = ms_a + ms_b;
+    return 0;
+}
+
+int omc_price_american_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res)
+{
+    return run_batch(c, p, n, res, true);
+}
+
+int omc_price_european_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res)
+{
+    return run_batch(c, p, n, res, false);
 }
 
 }  // extern "C"

@@ -1,0 +1,34 @@
+// omc_batch.h -- host interface of the batched (many small problems) launch path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/omc.h"
+
+namespace omc {
+
+using BatchItem = omc_params;  // one problem = one omc_params
+
+struct BatchExtents {  // launch extents = maxima over the problems of a batch
+    int max_steps;
+    int64_t path_blocks;  // 256-thread blocks at one pair per thread
+    int sweep_blocks;     // per-step sweep (512-thread blocks)
+    int block_blocks;     // pass 2 / valuation (256-thread blocks)
+    int64_t tile_blocks;  // pass 1 tile groups / 4
+    int term_blocks;      // terminal-only kernel
+    int vec4;             // every problem admits 16-byte accesses
+};
+
+size_t batch_slab_bytes(const BatchItem* items, int n, bool american, bool two_pass);
+size_t batch_table_bytes(int n);
+size_t batch_discount_doubles(const BatchItem* items, int n);
+void batch_build(const BatchItem* items, int n, bool american, bool two_pass, char* slab,
+                 double* results_dev, double* disc_dev, void* table_host, double* disc_host,
+                 BatchExtents* ext);
+// gen: 0 GBM antithetic, 1 GBM plain, 2 Heston reference clamp, 3 Heston full truncation
+hipError_t batch_paths(hipStream_t st, const void* table_dev, int n, const BatchExtents& e, int gen);
+hipError_t batch_lsm(hipStream_t st, const void* table_dev, int n, const BatchExtents& e, int semantics);
+hipError_t batch_terminal(hipStream_t st, const void* table_dev, int n, const BatchExtents& e, int gen);
+
+}  // namespace omc

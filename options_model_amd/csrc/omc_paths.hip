@@ -7,132 +7,19 @@
 // variance) in registers for the whole time loop, draws its normals from a counter RNG
 // (no state, no reads) and streams the [step][path] matrix out with 4*VEC-byte stores.
 // The kernel is pure HBM write traffic: (n_steps+1) * n_paths * 4 bytes.
-#include "omc_device.h"
-#include "omc_kernels.h"
+#include "omc_paths_dev.h"
 
 namespace omc {
 
-template <int VEC> struct VecT;
-template <> struct VecT<1> { using type = float; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<4> { using type = float4; };
-
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
-{
-    if constexpr (VEC == 1) {
-        *p = v[0];
-    } else if constexpr (VEC == 2) {
-        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
-    } else {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-}
-
-// ------------------------------------------------------------------ GBM
-// ANTI: pair p -> columns p and p + P (partner of column j is j + M/2, as the reference
-// lays it out).  !ANTI: P independent paths, one column each.
+// ------------------------------------------------------------------ __global__ entry points
 template <int VEC, bool ANTI>
-__global__ __launch_bounds__(kBlock) void gbm_paths_kernel(float* __restrict__ S, int64_t ld,
-                                                           int64_t P, int n_steps, float s_init,
-                                                           float a, float b, uint32_t k0,
-                                                           uint32_t k1, uint32_t stream,
-                                                           uint64_t pair_offset)
-{
-    const int64_t p0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
-    if (p0 >= P) return;
-    float s[VEC], sa[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) s[v] = sa[v] = s_init;
-    float* row = S + p0;
-    store_vec<VEC>(row, s);
-    if (ANTI) store_vec<VEC>(row + P, sa);
+__global__ __launch_bounds__(kBlock) void gbm_paths_kernel(PathArgs g) { gbm_paths_body<VEC, ANTI>(g); }
 
-    const int nblk = (n_steps + 3) >> 2;
-    int t = 0;
-    for (int blk = 0; blk < nblk; ++blk) {
-        float z[VEC][4];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-            normals4(pair_offset + (uint64_t)(p0 + v), (uint32_t)blk, stream, k0, k1, z[v]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (++t > n_steps) break;
-            row += ld;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) s[v] = s[v] * fast_exp2(__builtin_fmaf(b, z[v][i], a));
-            store_vec<VEC>(row, s);
-            if (ANTI) {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    sa[v] = sa[v] * fast_exp2(__builtin_fmaf(-b, z[v][i], a));
-                store_vec<VEC>(row + P, sa);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------ Heston
-struct HestonC {
-    float dtf, kdt, theta, xi, rho, rho2, rdt_l2, hdt_l2, l2e;
-};
-
-// one Euler step; the operation order is part of the numerics contract that the
-// test-side CPU restatement follows as well
-template <int SCHEME>
-__device__ __forceinline__ void heston_step(const HestonC& c, float z1, float z2, float& s, float& v)
-{
-    const float vp = fmaxf(v, 0.0f);
-    const float sq = __builtin_amdgcn_sqrtf(vp * c.dtf);
-    const float w2 = __builtin_fmaf(c.rho, z1, c.rho2 * z2);
-    const float base = SCHEME ? v : vp;
-    const float vn = __builtin_fmaf(c.xi * sq, w2, __builtin_fmaf(c.kdt, c.theta - vp, base));
-    const float arg = __builtin_fmaf(sq * c.l2e, z1, __builtin_fmaf(-c.hdt_l2, vp, c.rdt_l2));
-    s = s * fast_exp2(arg);
-    v = SCHEME ? vn : fmaxf(vn, 0.0f);
-}
-
-// One Philox block per pair per TWO steps: words (0,1) -> (z1,z2) of the odd step,
-// words (2,3) -> (z1,z2) of the even step.  The variance never leaves registers.
 template <int VEC, int SCHEME>
-__global__ __launch_bounds__(kBlock) void heston_paths_kernel(float* __restrict__ S, int64_t ld,
-                                                              int64_t P, int n_steps, float s_init,
-                                                              float v_init, HestonC c, uint32_t k0,
-                                                              uint32_t k1, uint32_t stream,
-                                                              uint64_t pair_offset)
-{
-    const int64_t p0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
-    if (p0 >= P) return;
-    float s[VEC], sa[VEC], va[VEC], vb[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        s[v] = sa[v] = s_init;
-        va[v] = vb[v] = v_init;
-    }
-    float* row = S + p0;
-    store_vec<VEC>(row, s);
-    store_vec<VEC>(row + P, sa);
-    const int nblk = (n_steps + 1) >> 1;
-    int t = 0;
-    for (int blk = 0; blk < nblk; ++blk) {
-        float z[VEC][4];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-            normals4(pair_offset + (uint64_t)(p0 + v), (uint32_t)blk, stream, k0, k1, z[v]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (++t > n_steps) break;
-            row += ld;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                heston_step<SCHEME>(c, z[v][2 * i], z[v][2 * i + 1], s[v], va[v]);
-                heston_step<SCHEME>(c, -z[v][2 * i], -z[v][2 * i + 1], sa[v], vb[v]);
-            }
-            store_vec<VEC>(row, s);
-            store_vec<VEC>(row + P, sa);
-        }
-    }
-}
+__global__ __launch_bounds__(kBlock) void heston_paths_kernel(PathArgs g) { heston_paths_body<VEC, SCHEME>(g); }
+
+template <int MODEL, bool ANTI>
+__global__ __launch_bounds__(kBlock) void terminal_kernel(TermArgs a) { terminal_body<MODEL, ANTI>(a); }
 
 // ------------------------------------------------------------------ injected normals
 // Parity mode: the normals come from HBM (Zhalf [n_steps][ldz], row t-1 drives step t,
@@ -179,65 +66,6 @@ __global__ __launch_bounds__(kBlock) void heston_from_normals_kernel(
     }
 }
 
-// ------------------------------------------------------------------ terminal-only (European)
-// Replaces price_european_streaming (options_model_3.py:382-437): the reference builds the
-// whole [N+1][chunk] matrix per 500-path chunk to read its last row; here S lives in
-// registers and only block partial sums {sum, sumsq, n_zero} of the discounted payoff leave.
-struct TermArgs {
-    int64_t P;
-    int n_steps, is_put;
-    float s_init, a, b, v_init;
-    HestonC hc;
-    uint32_t k0, k1, stream;
-    uint64_t pair_offset;
-    double K, df;
-    double* part;  // [8][kMaxLsmBlocks]
-};
-
-__device__ __forceinline__ void add_payoff(double (&acc)[8], float s, double K, int is_put, double df)
-{
-    double p = payoff_d(s, K, is_put);
-    p = p > 0.0 ? p * df : 0.0;
-    acc[0] += p;
-    acc[1] += p * p;
-    acc[3] += (p == 0.0) ? 1.0 : 0.0;
-}
-
-// MODEL 0 GBM (ANTI selectable), MODEL 1/2 Heston scheme 0/1 (always antithetic)
-template <int MODEL, bool ANTI>
-__global__ __launch_bounds__(kBlock) void terminal_kernel(TermArgs a)
-{
-    __shared__ double red[kNQ * kRedStride];
-    double acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < a.P; p += stride) {
-        float s = a.s_init, sa = a.s_init, va = a.v_init, vb = a.v_init, z[4];
-        if (MODEL == 0) {
-            for (int t = 0; t < a.n_steps; ++t) {
-                if ((t & 3) == 0)
-                    normals4(a.pair_offset + (uint64_t)p, (uint32_t)(t >> 2), a.stream, a.k0, a.k1, z);
-                s = s * fast_exp2(__builtin_fmaf(a.b, z[t & 3], a.a));
-                if (ANTI) sa = sa * fast_exp2(__builtin_fmaf(-a.b, z[t & 3], a.a));
-            }
-        } else {
-            for (int t = 0; t < a.n_steps; ++t) {
-                const int i = t & 1;
-                if (i == 0)
-                    normals4(a.pair_offset + (uint64_t)p, (uint32_t)(t >> 1), a.stream, a.k0, a.k1, z);
-                heston_step<MODEL - 1>(a.hc, z[2 * i], z[2 * i + 1], s, va);
-                heston_step<MODEL - 1>(a.hc, -z[2 * i], -z[2 * i + 1], sa, vb);
-            }
-        }
-        add_payoff(acc, s, a.K, a.is_put, a.df);
-        if (ANTI) add_payoff(acc, sa, a.K, a.is_put, a.df);
-    }
-    const double r = block_reduce8(acc, red);
-    if (threadIdx.x < 64 && (threadIdx.x & 7) == 0)
-        a.part[(size_t)(threadIdx.x >> 3) * kMaxLsmBlocks + blockIdx.x] = r;
-}
-
 // ------------------------------------------------------------------ RNG test taps
 __global__ void philox_kat_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n)
 {
@@ -266,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void gbm_normals_kernel(float* __restrict__
 }
 
 // ------------------------------------------------------------------ host launchers
-static inline HestonC make_heston(double r, double T, int n_steps, double kappa, double theta,
+HestonC make_heston(double r, double T, int n_steps, double kappa, double theta,
                                   double xi, double rho)
 {
     const double dt = T / n_steps, L2E = 1.4426950408889634074;
@@ -303,10 +131,12 @@ hipError_t launch_gbm_paths(hipStream_t st, float* S, int64_t ld, int64_t n_path
     int vec = vec_hint > 0 ? vec_hint : 4;
     // VEC-wide stores need every row start (and the antithetic half) aligned
     while (vec > 1 && !((P % vec) == 0 && (ld % vec) == 0 && ((uintptr_t)S % (4 * vec)) == 0)) vec >>= 1;
-    const float s0 = (float)S0;
+    PathArgs g{};
+    g.S = S; g.ld = ld; g.P = P; g.n_steps = n_steps; g.s_init = (float)S0; g.a = a; g.b = b;
+    g.k0 = k0; g.k1 = k1; g.stream = stream; g.pair_offset = pair_offset;
 #define OMC_LAUNCH_GBM(V, A)                                                                       \
     hipLaunchKernelGGL((gbm_paths_kernel<V, A>), dim3(grid_for((P + V - 1) / V)), dim3(kBlock), 0, \
-                       st, S, ld, P, n_steps, s0, a, b, k0, k1, stream, pair_offset)
+                       st, g)
     if (antithetic) {
         if (vec == 4) OMC_LAUNCH_GBM(4, true);
         else if (vec == 2) OMC_LAUNCH_GBM(2, true);
@@ -331,11 +161,12 @@ hipError_t launch_heston_paths(hipStream_t st, float* S, int64_t ld, int64_t n_p
     if (P <= 0) return hipSuccess;
     int vec = vec_hint > 0 ? vec_hint : 4;
     while (vec > 1 && !((P % vec) == 0 && (ld % vec) == 0 && ((uintptr_t)S % (4 * vec)) == 0)) vec >>= 1;
-    const float s0 = (float)S0, v0f = (float)v0;
+    PathArgs g{};
+    g.S = S; g.ld = ld; g.P = P; g.n_steps = n_steps; g.s_init = (float)S0; g.v_init = (float)v0;
+    g.hc = c; g.k0 = k0; g.k1 = k1; g.stream = stream; g.pair_offset = pair_offset;
 #define OMC_LAUNCH_HES(V, SC)                                                                     \
     hipLaunchKernelGGL((heston_paths_kernel<V, SC>), dim3(grid_for((P + V - 1) / V)),             \
-                       dim3(kBlock), 0, st, S, ld, P, n_steps, s0, v0f, c, k0, k1, stream,        \
-                       pair_offset)
+                       dim3(kBlock), 0, st, g)
     if (scheme == 0) {
         if (vec == 4) OMC_LAUNCH_HES(4, 0);
         else if (vec == 2) OMC_LAUNCH_HES(2, 0);
@@ -404,6 +235,7 @@ hipError_t launch_terminal(hipStream_t st, double* part, int* nblk_out, int mode
     if (nb < 1) nb = 1;
     if (nb > kMaxLsmBlocks) nb = kMaxLsmBlocks;
     *nblk_out = (int)nb;
+    a.nblk = (int)nb; a.pstride = kMaxLsmBlocks;
     const dim3 grid((unsigned)nb), block(kBlock);
     if (model == 0) {
         if (antithetic) hipLaunchKernelGGL((terminal_kernel<0, true>), grid, block, 0, st, a);

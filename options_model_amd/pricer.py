@@ -226,12 +226,54 @@ class AdvancedOptionPricer:
 
     def compute_curve_for_S0(self, S0: float, intervals_per_day: int, total_points: int,
                              num_simulations: int, plot_paths: bool) -> List[Dict[str, Any]]:
-        records = []
+        """options_model_3.py:697-713.  The points of a curve are independent pricings, so they
+        run as ONE batched set of launches (omc_price_american_batch); child seeds are drawn in
+        exactly the order the sequential loop would draw them, so the result equals calling
+        price_american_option point by point."""
+        points = []
         for i in range(total_points, 0, -1):
             d = i / intervals_per_day
-            steps = max(10, min(130, int(math.ceil(d))))
-            price = self.price_american_option(S0, d / 365, num_simulations, steps, plot_paths)
+            points.append((d, d / 365, max(10, min(130, int(math.ceil(d))))))
+        batchable = (self.regressor == "poly" and self.iv_model is None
+                     and not (self.use_streaming and self.european_approximation))
+        if not batchable:
+            return [{"S0": S0, "Days to Expiry": d,
+                     "Option Value": self.price_american_option(S0, T, num_simulations, steps, plot_paths)}
+                    for d, T, steps in points]
+        if S0 <= 0 or self.K <= 0:
+            raise ValueError("S0, K, T must be positive.")
+        if self.r < 0:
+            raise ValueError("r must be non-negative.")
+        if num_simulations <= 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        with_cv = self.use_control_variate and self.sigma is not None
+        kw = self._model_kw()
+        M = int(num_simulations) // 2 * 2
+        if M == 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        n_chunks = max(1, -(-int(num_simulations) // int(self.chunk_size)))
+        lsm_params, eur_params = [], []
+        for d, T, steps in points:
+            path_seed = self.rng_manager.get_child_seed()
+            self.rng_manager.get_child_seed()  # the reference's torch.manual_seed draw
+            lsm_params.append(self._params(S0, T, M, steps, path_seed, self.semantics))
+            if with_cv:
+                eseed = [self.rng_manager.get_child_seed() for _ in range(n_chunks)][0]
+                eur_params.append(_ffi.make_params(is_put=(self.option_type == "put"), n_paths=M,
+                                                   n_steps=steps, S0=S0, K=self.K, r=self.r,
+                                                   sigma=self.sigma or 0.0, T=T, seed=eseed, stream=1, **kw))
+        ctx = self._ctx()
+        lsm = ctx.price_american_batch(lsm_params)
+        eur = ctx.price_european_batch(eur_params) if with_cv else None
+        self._calls += len(points)
+        records = []
+        for k, (d, T, steps) in enumerate(points):
+            price = lsm[k]["price"]
+            if with_cv:
+                bs = BlackScholesGreeks.black_scholes_price(S0, self.K, T, self.r, self.sigma, self.option_type)
+                price = price + 1.0 * (bs - eur[k]["price"])
             records.append({"S0": S0, "Days to Expiry": d, "Option Value": price})
+        self.last_result = lsm[-1]
         return records
 
 
