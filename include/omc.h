@@ -42,7 +42,11 @@ enum {
     OMC_SEM_TWO_PASS = 2   /* v3 flow: options_model_3/options_model_3.py:482-516 + :615-651        */
 };
 enum { OMC_MODEL_GBM = 0, OMC_MODEL_HESTON = 1 };
-enum { OMC_HESTON_REFERENCE_CLAMP = 0, OMC_HESTON_FULL_TRUNCATION = 1 };
+enum {
+    OMC_HESTON_REFERENCE_CLAMP = 0, /* options_model_3.py:230-233                                 */
+    OMC_HESTON_FULL_TRUNCATION = 1, /* Lord et al. (named by BASELINE.json)                       */
+    OMC_HESTON_CALIBRATOR = 2       /* heston_calibration.py:242-255: floor 1e-8, arithmetic Euler */
+};
 
 typedef struct {
     int32_t model;         /* OMC_MODEL_*                                               */
@@ -147,6 +151,16 @@ int omc_price_american(omc_ctx* ctx, const omc_params* p, omc_result* res, float
 /* European discounted payoff from terminal values only (no path matrix): replaces
  * price_european_streaming options_model_3.py:382-437; sums2 host {sum, sumsq} */
 int omc_price_european(omc_ctx* ctx, const omc_params* p, omc_result* res);
+
+/* ---- calibrator inner loop -------------------------------------- */
+/* replaces HestonPricer.price_options_batch / price_european_option
+ * (options_model_3/heston_calibration.py:259-312) for ONE expiry: simulate n_paths antithetic
+ * Heston paths (terminal spots only, no path matrix), then the discounted mean payoff of every
+ * strike.  strikes / prices / stderrs are host arrays of n_strikes (stderrs may be NULL). */
+int omc_heston_price_strikes(omc_ctx* ctx, int64_t n_paths, int n_steps, double S0, double r,
+                             double T, double v0, double kappa, double theta, double xi, double rho,
+                             uint64_t seed, uint64_t stream, int scheme, const double* strikes,
+                             int n_strikes, int is_put, double* prices, double* stderrs);
 
 /* ---- many small pricings in one go ------------------------------------------------------- */
 /* replaces the curve loops compute_curve_for_S0 (options_model_3.py:697-713, Options_model.py:

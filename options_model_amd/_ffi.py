@@ -16,7 +16,7 @@ ABI_VERSION = 1
 
 SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
 MODELS = {"gbm": 0, "heston": 1}
-HESTON_SCHEMES = {"reference": 0, "clamp": 0, "full_truncation": 1}
+HESTON_SCHEMES = {"reference": 0, "clamp": 0, "full_truncation": 1, "calibrator": 2}
 
 
 class OmcError(RuntimeError):
@@ -72,6 +72,7 @@ SIGNATURES = {
     "omc_set_allreduce_hook": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "omc_price_american": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result), _P, _I64]),
     "omc_price_european": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result)]),
+    "omc_heston_price_strikes": (C.c_int, [_P, _I64, _I] + [_D] * 8 + [_U64, _U64, _I, _P, _I, _I, _P, _P]),
     "omc_price_american_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_price_european_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
 }
@@ -350,6 +351,18 @@ class Context:
         res = Result()
         _check(self.lib, self.lib.omc_price_european(self.handle, C.byref(params), C.byref(res)))
         return res.as_dict()
+
+    def heston_price_strikes(self, n_paths, n_steps, S0, r, T, v0, kappa, theta, xi, rho, strikes,
+                             is_put=False, seed=42, stream=0, scheme=2):
+        """One expiry, many strikes (the calibrator's inner call) -> (prices, stderrs)."""
+        k = np.ascontiguousarray(strikes, np.float64)
+        prices = np.empty_like(k)
+        errs = np.empty_like(k)
+        _check(self.lib, self.lib.omc_heston_price_strikes(
+            self.handle, int(n_paths), int(n_steps), S0, r, T, v0, kappa, theta, xi, rho, int(seed),
+            int(stream), int(scheme), k.ctypes.data, k.size, int(is_put), prices.ctypes.data,
+            errs.ctypes.data))
+        return prices, errs
 
     # -- many small pricings as one set of launches (all share model/semantics/antithetic)
     MAX_BATCH = 65535

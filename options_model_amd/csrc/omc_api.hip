@@ -393,7 +393,7 @@ int omc_heston_paths_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, int 
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
     if (n_paths & 1) return fail(-3, "antithetic layout needs an even n_paths.");
-    if (scheme != 0 && scheme != 1) return fail(-4, "unknown Heston scheme.");
+    if (scheme < 0 || scheme > 2) return fail(-4, "unknown Heston scheme.");
     HIP_TRY(omc::launch_heston_paths(c->stream, S, ld, n_paths, n_steps, S0, r, T, v0, kappa, theta,
                                      xi, rho, seed, (uint32_t)stream, pair_offset, scheme,
                                      c->heston_vec));
@@ -432,7 +432,7 @@ int omc_heston_paths_from_normals_f32(omc_ctx* c, float* S, int64_t ld, int64_t 
     if (!Z1 || !Z2) return fail(-7, "null normals pointer.");
     if (n_paths & 1) return fail(-3, "antithetic layout needs an even n_paths.");
     if (ldz < n_paths / 2) return fail(-6, "ldz too small.");
-    if (scheme != 0 && scheme != 1) return fail(-4, "unknown Heston scheme.");
+    if (scheme < 0 || scheme > 2) return fail(-4, "unknown Heston scheme.");
     HIP_TRY(omc::launch_heston_from_normals(c->stream, S, ld, n_paths, n_steps, S0, r, T, v0, kappa,
                                             theta, xi, rho, Z1, Z2, ldz, scheme));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -532,7 +532,7 @@ static int check_params(const omc_params* p)
         if (!(p->sigma > 0)) return fail(-5, "S0, K, T, and sigma must be positive.");
     } else if (p->model == OMC_MODEL_HESTON) {
         if (!(p->rho >= -1.0 && p->rho <= 1.0) || !(p->v0 >= 0)) return fail(-5, "invalid Heston parameters.");
-        if (p->heston_scheme != 0 && p->heston_scheme != 1) return fail(-4, "unknown Heston scheme.");
+        if (p->heston_scheme < 0 || p->heston_scheme > 2) return fail(-4, "unknown Heston scheme.");
         if (!p->antithetic) return fail(-4, "Heston paths are always antithetic.");
     } else {
         return fail(-4, "unknown model.");
@@ -613,6 +613,43 @@ int omc_price_european(omc_ctx* c, const omc_params* p, omc_result* res)
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     res->ms_paths = ms;
     res->ms_total = ms;
+    return 0;
+}
+
+// ------------------------------------------------------------------ calibrator inner loop
+int omc_heston_price_strikes(omc_ctx* c, int64_t n_paths, int n_steps, double S0, double r, double T,
+                             double v0, double kappa, double theta, double xi, double rho,
+                             uint64_t seed, uint64_t stream, int scheme, const double* strikes,
+                             int n_strikes, int is_put, double* prices, double* stderrs)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if (n_paths & 1) return fail(-3, "antithetic layout needs an even n_paths.");
+    if (scheme < 0 || scheme > 2) return fail(-4, "unknown Heston scheme.");
+    if (!(rho >= -1.0 && rho <= 1.0) || !(v0 >= 0)) return fail(-5, "invalid Heston parameters.");
+    if (!strikes || !prices || n_strikes <= 0) return fail(-7, "bad strike arguments.");
+    const size_t st_bytes = sizeof(float) * (size_t)n_paths;
+    const size_t k_bytes = sizeof(double) * (size_t)n_strikes;
+    if ((rc = c->scratch.ensure(st_bytes + 256 + 3 * k_bytes))) return rc;
+    float* ST = (float*)c->scratch.p;
+    double* Kd = (double*)((char*)c->scratch.p + (st_bytes + 255) / 256 * 256);
+    double* out = Kd + n_strikes;
+    HIP_TRY(hipMemcpyAsync(Kd, strikes, k_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(omc::launch_heston_terminal_store(c->stream, ST, n_paths, n_steps, S0, r, T, v0, kappa, theta,
+                                              xi, rho, seed, (uint32_t)stream, 0, scheme));
+    HIP_TRY(omc::launch_payoff_means(c->stream, ST, n_paths, Kd, n_strikes, is_put ? 1 : 0, out));
+    std::vector<double> h(2 * (size_t)n_strikes);
+    HIP_TRY(hipMemcpyAsync(h.data(), out, 2 * k_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double df = std::exp(-r * T), M = (double)n_paths;
+    for (int k = 0; k < n_strikes; ++k) {
+        const double mean = h[2 * (size_t)k] / M;
+        const double var = h[2 * (size_t)k + 1] / M - mean * mean;
+        prices[k] = df * mean;
+        if (stderrs) stderrs[k] = df * std::sqrt((var > 0 ? var : 0.0) / M);
+    }
     return 0;
 }
 

@@ -20,6 +20,14 @@ hipError_t launch_heston_from_normals(hipStream_t st, float* S, int64_t ld, int6
                                       int n_steps, double S0, double r, double T, double v0,
                                       double kappa, double theta, double xi, double rho,
                                       const float* Z1, const float* Z2, int64_t ldz, int scheme);
+// calibrator inner loop: terminal spots only (ST device [n_paths]), then one mean per strike
+hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_paths, int n_steps,
+                                        double S0, double r, double T, double v0, double kappa,
+                                        double theta, double xi, double rho, uint64_t seed,
+                                        uint32_t stream, uint64_t pair_offset, int scheme);
+// out_dev [n_strikes][2] = {sum, sumsq} of max(+-(S_T - K), 0)
+hipError_t launch_payoff_means(hipStream_t st, const float* ST, int64_t n_paths, const double* K_dev,
+                               int n_strikes, int is_put, double* out_dev);
 hipError_t launch_philox_kat(hipStream_t st, const uint32_t* in, uint32_t* out, int n);
 hipError_t launch_gbm_normals(hipStream_t st, float* Z, int64_t ldz, int64_t n_pairs, int n_steps,
                               uint64_t seed, uint32_t stream, uint64_t pair_offset);

@@ -108,6 +108,9 @@ HestonC make_heston(double r, double T, int n_steps, double kappa, double theta,
     c.rdt_l2 = (float)(r * dt * L2E);
     c.hdt_l2 = (float)(0.5 * dt * L2E);
     c.l2e = (float)L2E;
+    c.sqdt = (float)sqrt(dt);
+    c.rdt = (float)(r * dt);
+    c.xi_sqdt = (float)(xi * sqrt(dt));
     return c;
 }
 
@@ -171,10 +174,14 @@ hipError_t launch_heston_paths(hipStream_t st, float* S, int64_t ld, int64_t n_p
         if (vec == 4) OMC_LAUNCH_HES(4, 0);
         else if (vec == 2) OMC_LAUNCH_HES(2, 0);
         else OMC_LAUNCH_HES(1, 0);
-    } else {
+    } else if (scheme == 1) {
         if (vec == 4) OMC_LAUNCH_HES(4, 1);
         else if (vec == 2) OMC_LAUNCH_HES(2, 1);
         else OMC_LAUNCH_HES(1, 1);
+    } else {
+        if (vec == 4) OMC_LAUNCH_HES(4, 2);
+        else if (vec == 2) OMC_LAUNCH_HES(2, 2);
+        else OMC_LAUNCH_HES(1, 2);
     }
 #undef OMC_LAUNCH_HES
     return hipGetLastError();
@@ -209,9 +216,78 @@ hipError_t launch_heston_from_normals(hipStream_t st, float* S, int64_t ld, int6
     if (scheme == 0)
         hipLaunchKernelGGL((heston_from_normals_kernel<0>), dim3(grid_for(P)), dim3(kBlock), 0, st,
                            S, ld, P, n_steps, (float)S0, (float)v0, c, Z1, Z2, ldz);
-    else
+    else if (scheme == 1)
         hipLaunchKernelGGL((heston_from_normals_kernel<1>), dim3(grid_for(P)), dim3(kBlock), 0, st,
                            S, ld, P, n_steps, (float)S0, (float)v0, c, Z1, Z2, ldz);
+    else
+        hipLaunchKernelGGL((heston_from_normals_kernel<2>), dim3(grid_for(P)), dim3(kBlock), 0, st,
+                           S, ld, P, n_steps, (float)S0, (float)v0, c, Z1, Z2, ldz);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ calibrator inner loop
+// HestonPricer.price_options_batch (heston_calibration.py:283-312): one simulation per expiry,
+// then one mean payoff per strike.  Terminal spots of all paths go to a small buffer (4 bytes
+// per path, no path matrix); a second launch reduces one strike per workgroup over it.
+template <int SCHEME>
+__global__ __launch_bounds__(kBlock) void heston_terminal_store_kernel(float* __restrict__ ST, PathArgs g)
+{
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= g.P) return;
+    float s = g.s_init, sa = g.s_init, va = g.v_init, vb = g.v_init, z[4];
+    for (int t = 0; t < g.n_steps; ++t) {
+        const int i = t & 1;
+        if (i == 0) normals4(g.pair_offset + (uint64_t)p, (uint32_t)(t >> 1), g.stream, g.k0, g.k1, z);
+        heston_step<SCHEME>(g.hc, z[2 * i], z[2 * i + 1], s, va);
+        heston_step<SCHEME>(g.hc, -z[2 * i], -z[2 * i + 1], sa, vb);
+    }
+    ST[p] = s;
+    ST[p + g.P] = sa;
+}
+
+__global__ __launch_bounds__(kBlock) void payoff_means_kernel(const float* __restrict__ ST, int64_t M,
+                                                              const double* __restrict__ K, int is_put,
+                                                              double* __restrict__ out)
+{
+    __shared__ double red[kNQ * kRedStride];
+    const double k = K[blockIdx.x];
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    for (int64_t j = threadIdx.x; j < M; j += kBlock) {
+        double p = payoff_d(ST[j], k, is_put);
+        p = p > 0.0 ? p : 0.0;
+        acc[0] += p;
+        acc[1] += p * p;
+    }
+    const double s = block_reduce8(acc, red);
+    if (threadIdx.x < 64 && (threadIdx.x & 7) == 0 && (threadIdx.x >> 3) < 2)
+        out[2 * (size_t)blockIdx.x + (threadIdx.x >> 3)] = s;
+}
+
+hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_paths, int n_steps,
+                                        double S0, double r, double T, double v0, double kappa,
+                                        double theta, double xi, double rho, uint64_t seed,
+                                        uint32_t stream, uint64_t pair_offset, int scheme)
+{
+    PathArgs g{};
+    g.P = n_paths / 2; g.n_steps = n_steps; g.s_init = (float)S0; g.v_init = (float)v0;
+    g.hc = make_heston(r, T, n_steps, kappa, theta, xi, rho);
+    g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.stream = stream; g.pair_offset = pair_offset;
+    if (g.P <= 0) return hipSuccess;
+    const dim3 grid(grid_for(g.P)), block(kBlock);
+    if (scheme == 0) hipLaunchKernelGGL((heston_terminal_store_kernel<0>), grid, block, 0, st, ST, g);
+    else if (scheme == 1) hipLaunchKernelGGL((heston_terminal_store_kernel<1>), grid, block, 0, st, ST, g);
+    else hipLaunchKernelGGL((heston_terminal_store_kernel<2>), grid, block, 0, st, ST, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_payoff_means(hipStream_t st, const float* ST, int64_t n_paths, const double* K_dev,
+                               int n_strikes, int is_put, double* out_dev)
+{
+    if (n_strikes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(payoff_means_kernel, dim3(n_strikes), dim3(kBlock), 0, st, ST, n_paths, K_dev,
+                       is_put, out_dev);
     return hipGetLastError();
 }
 

@@ -30,6 +30,7 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
 // lays it out).  !ANTI: P independent paths, one column each.
 struct HestonC {
     float dtf, kdt, theta, xi, rho, rho2, rdt_l2, hdt_l2, l2e;
+    float sqdt, rdt, xi_sqdt;  // calibrator scheme: sqrt(dt), r*dt, xi*sqrt(dt)
 };
 
 // one argument block for both generators (Heston ignores a/b, GBM ignores v_init/hc)
@@ -91,6 +92,17 @@ __device__ __forceinline__ void gbm_paths_body(const PathArgs& g)
 template <int SCHEME>
 __device__ __forceinline__ void heston_step(const HestonC& c, float z1, float z2, float& s, float& v)
 {
+    if constexpr (SCHEME == 2) {
+        // The calibrator's own scheme (heston_calibration.py:242-255): variance floored at 1e-8
+        // before use and at store, ARITHMETIC Euler for S (S may cross zero; so be it).
+        const float vp = fmaxf(v, 1e-8f);
+        const float sq = __builtin_amdgcn_sqrtf(vp);
+        const float w2 = __builtin_fmaf(c.rho, z1, c.rho2 * z2);
+        const float vn = __builtin_fmaf(c.xi_sqdt * sq, w2, __builtin_fmaf(c.kdt, c.theta - vp, vp));
+        s = __builtin_fmaf(s, __builtin_fmaf(sq * c.sqdt, z1, c.rdt), s);
+        v = fmaxf(vn, 1e-8f);
+        return;
+    }
     const float vp = fmaxf(v, 0.0f);
     const float sq = __builtin_amdgcn_sqrtf(vp * c.dtf);
     const float w2 = __builtin_fmaf(c.rho, z1, c.rho2 * z2);

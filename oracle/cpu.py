@@ -54,6 +54,7 @@ def lib():
         _lib.orc_lsm_apply_frozen.restype = C.c_int
         _lib.orc_lsm_pass1_moments.argtypes = [f32p, i64, i64, i32, dbl, dbl, dbl, i32, C.c_void_p]
         _lib.orc_solve_poly2.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_heston_terminal_f32.argtypes = [f32p, i64, i32] + [dbl] * 8 + [u64, u32, u64, i32]
         _lib.orc_european_from_paths.argtypes = [f32p, i64, i64, i32, dbl, dbl, dbl, i32,
                                                  C.c_void_p, C.c_void_p]
     return _lib
@@ -170,3 +171,11 @@ def solve_poly2(moments):
         out[t, :3] = b
         out[t, 3] = row[0]
     return out
+
+
+def heston_terminal(n_paths, n_steps, S0, r, T, v0, kappa, theta, xi, rho, seed, stream=0,
+                    pair_offset=0, scheme=2):
+    ST = np.empty(n_paths, np.float32)
+    lib().orc_heston_terminal_f32(_p(ST), n_paths, n_steps, S0, r, T, v0, kappa, theta, xi, rho, seed,
+                                  stream, pair_offset, scheme)
+    return ST

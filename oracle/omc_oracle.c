@@ -152,6 +152,7 @@ void orc_gbm_paths_from_normals_f32(float *S, int64_t ld, int64_t n_paths, int n
 /* ---------------------------------------------------------------- Heston paths */
 typedef struct {
     float dtf, kdt, theta, xi, rho, rho2, rdt_l2, hdt_l2, l2e;
+    float sqdt, rdt, xi_sqdt; /* scheme 2 (calibrator): sqrt(dt), r*dt, xi*sqrt(dt) */
 } heston_consts;
 
 static heston_consts heston_make(double r, double T, int n_steps, double kappa, double theta,
@@ -168,6 +169,9 @@ static heston_consts heston_make(double r, double T, int n_steps, double kappa, 
     c.rdt_l2 = (float)(r * dt * L2E);
     c.hdt_l2 = (float)(0.5 * dt * L2E);
     c.l2e = (float)L2E;
+    c.sqdt = (float)sqrt(dt);
+    c.rdt = (float)(r * dt);
+    c.xi_sqdt = (float)(xi * sqrt(dt));
     return c;
 }
 
@@ -176,6 +180,15 @@ static heston_consts heston_make(double r, double T, int n_steps, double kappa, 
 static inline void heston_step(const heston_consts *c, int scheme, float z1, float z2, float *s,
                                float *v)
 {
+    if (scheme == 2) { /* options_model_3/heston_calibration.py:242-255 */
+        float vp = fmaxf(*v, 1e-8f);
+        float sq = sqrtf(vp);
+        float w2 = fmaf(c->rho, z1, c->rho2 * z2);
+        float vn = fmaf(c->xi_sqdt * sq, w2, fmaf(c->kdt, c->theta - vp, vp));
+        *s = fmaf(*s, fmaf(sq * c->sqdt, z1, c->rdt), *s);
+        *v = fmaxf(vn, 1e-8f);
+        return;
+    }
     float vp = fmaxf(*v, 0.0f);
     float sq = sqrtf(vp * c->dtf);
     float w2 = fmaf(c->rho, z1, c->rho2 * z2);
@@ -444,3 +457,25 @@ void orc_lsm_pass1_moments(const float *S, int64_t ld, int64_t n_paths, int n_st
 }
 
 void orc_solve_poly2(const double m[8], double beta[3]) { solve_poly2(m, beta); }
+
+
+/* terminal spots only (the calibrator's inner simulation), same Philox layout as the paths */
+void orc_heston_terminal_f32(float *ST, int64_t n_paths, int n_steps, double S0, double r, double T,
+                             double v0, double kappa, double theta, double xi, double rho,
+                             uint64_t seed, uint32_t stream, uint64_t pair_offset, int scheme)
+{
+    const heston_consts c = heston_make(r, T, n_steps, kappa, theta, xi, rho);
+    const int64_t P = n_paths / 2;
+#pragma omp parallel for schedule(static) if (P * (int64_t)n_steps >= 1000000)
+    for (int64_t p = 0; p < P; ++p) {
+        float s0 = (float)S0, s1 = (float)S0, va = (float)v0, vb = (float)v0, z[4];
+        for (int t = 0; t < n_steps; ++t) {
+            int i = t & 1;
+            if (i == 0) orc_normals4(seed, pair_offset + (uint64_t)p, (uint32_t)(t >> 1), stream, z);
+            heston_step(&c, scheme, z[2 * i], z[2 * i + 1], &s0, &va);
+            heston_step(&c, scheme, -z[2 * i], -z[2 * i + 1], &s1, &vb);
+        }
+        ST[p] = s0;
+        ST[p + P] = s1;
+    }
+}

@@ -69,6 +69,38 @@ def heston_paths_from_normals(z1_half, z2_half, S0, r, T, v0, kappa, theta, xi, 
     return S
 
 
+def heston_calibrator_paths_from_normals(z1, z2_indep, S0, r, T, v0, kappa, theta, xi, rho):
+    """options_model_3/heston_calibration.py:204-257 on recorded normals: z1, z2_indep are
+    [n_sim][n_steps]; antithetic stacking AFTER the rho-mix (:230-234); variance floored at 1e-8
+    before use and at store; arithmetic Euler for S.  Returns S, V as [n_paths][n_steps+1]."""
+    z1 = np.asarray(z1, np.float64)
+    z2 = rho * z1 + np.sqrt(1 - rho**2) * np.asarray(z2_indep, np.float64)
+    Z1 = np.vstack([z1, -z1])
+    Z2 = np.vstack([z2, -z2])
+    n_paths, N = Z1.shape
+    dt = T / N
+    S = np.zeros((n_paths, N + 1))
+    V = np.zeros((n_paths, N + 1))
+    S[:, 0], V[:, 0] = S0, v0
+    sqrt_dt = np.sqrt(dt)
+    for t in range(N):
+        V_pos = np.maximum(V[:, t], 1e-8)
+        sqrt_V = np.sqrt(V_pos)
+        dV = kappa * (theta - V_pos) * dt + xi * sqrt_V * sqrt_dt * Z2[:, t]
+        V[:, t + 1] = np.maximum(V_pos + dV, 1e-8)
+        dS = r * S[:, t] * dt + sqrt_V * S[:, t] * sqrt_dt * Z1[:, t]
+        S[:, t + 1] = S[:, t] + dS
+    return S, V
+
+
+def strike_prices(S_T, strikes, r, T, is_put=False):
+    """heston_calibration.py:301-306: discounted mean payoff per strike."""
+    S_T = np.asarray(S_T, np.float64)
+    df = np.exp(-r * T)
+    return np.array([df * np.mean(np.maximum(K - S_T, 0) if is_put else np.maximum(S_T - K, 0))
+                     for K in strikes])
+
+
 # -- payoff / features ------------------------------------------------------------------
 def payoff(S, K, is_put):
     """options_model_3.py:376-380."""

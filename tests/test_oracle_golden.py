@@ -184,3 +184,19 @@ def test_philox_paths_statistics():
     a = orc.gbm_paths(1000, 8, 100.0, R, SIG, T, 1, 0, 0)
     b = orc.gbm_paths(500, 8, 100.0, R, SIG, T, 1, 0, 250)
     assert np.array_equal(b[:, :250], a[:, 250:500]) and np.array_equal(b[:, 250:], a[:, 750:])
+
+
+@pytest.mark.parametrize("tag", ["feller", "floor"])
+def test_calibrator_heston_scheme_bit_exact(tag):
+    """Row f-3: heston_calibration.py:204-312 restated; fixtures from the real HestonPricer."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "calibrator.npz"))
+    prm = g[f"{tag}_params"]
+    S, V = rf.heston_calibrator_paths_from_normals(g[f"{tag}_z1"], g[f"{tag}_z2i"], *prm)
+    assert np.array_equal(S, g[f"{tag}_S"]) and np.array_equal(V, g[f"{tag}_V"])
+    Sb, _ = rf.heston_calibrator_paths_from_normals(g[f"{tag}_batch_z1"], g[f"{tag}_batch_z2i"], *prm)
+    assert np.array_equal(rf.strike_prices(Sb[:, -1], g[f"{tag}_batch_K"], prm[1], prm[2]), g[f"{tag}_batch_prices"])
+    assert rf.strike_prices(Sb[:, -1], [100.0], prm[1], prm[2], True)[0] == g[f"{tag}_put100"]
+    # float32 C oracle (the GPU's arithmetic contract) on the same normals, [step][pair] layout
+    S32 = orc.heston_paths_from_normals(g[f"{tag}_z1"].T.copy(), g[f"{tag}_z2i"].T.copy(), *prm, scheme=2)
+    assert np.abs(S32.T / g[f"{tag}_S"] - 1).max() < 5e-6
