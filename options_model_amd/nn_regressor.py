@@ -155,32 +155,108 @@ def pick_batch(R, nn_batch=None):
     return int(min(R, 1 << max(8, math.ceil(math.log2(R / 1024)))))
 
 
-def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbose=False):
-    """:565-613.  Features are rebuilt per minibatch from (x, t): the [R,7] matrix never exists."""
+def build_training_matrix(x, t, y, fm, fs, ym, ysd, T, dt, chunk=1 << 23):
+    """[R, 8] float32 = 7 normalised features + normalised target (the reference's
+    X_all_norm / Y_all_scaled after their .float() cast, :563-571), built once in chunks."""
+    torch = _torch()
+    R = x.numel()
+    data = torch.empty((R, 8), dtype=torch.float32, device=x.device)
+    for o in range(0, R, chunk):
+        st = torch.sqrt(torch.clamp(T - t[o:o + chunk].double() * dt, min=1e-6))
+        data[o:o + chunk, :7] = ((features(x[o:o + chunk], st) - fm) / fs).float()
+        data[o:o + chunk, 7] = ((y[o:o + chunk] - ym) / ysd).float()
+    return data
+
+
+class _GraphedStep:
+    """One optimizer step (forward, MSE, backward, Adam) captured in a HIP graph and replayed:
+    at batch 256 an eager step is ~40 launches of microsecond kernels, i.e. pure launch latency.
+    Falls back to eager execution if capture is not possible."""
+
+    def __init__(self, net, opt, loss_fn, bs, device):
+        torch = _torch()
+        self.torch, self.net, self.opt, self.loss_fn = torch, net, opt, loss_fn
+        self.buf = torch.zeros((bs, 8), dtype=torch.float32, device=device)
+        self.loss = torch.zeros((), dtype=torch.float32, device=device)
+        self.graph = None
+        try:
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):  # warm-up off the capture stream, as torch requires
+                for _ in range(3):
+                    self._eager(self.buf)
+            torch.cuda.current_stream(device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                out = self.loss_fn(net(self.buf[:, :7]), self.buf[:, 7:])
+                out.backward()
+                opt.step()
+                self.loss.copy_(out.detach())
+            self.graph = g
+        except Exception:  # noqa: BLE001
+            self.graph = None
+
+    def _eager(self, batch):
+        loss = self.loss_fn(self.net(batch[:, :7]), batch[:, 7:])
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def __call__(self, batch):
+        if self.graph is not None and batch.shape[0] == self.buf.shape[0]:
+            self.buf.copy_(batch)
+            self.graph.replay()
+            return self.loss
+        return self._eager(batch)
+
+
+def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbose=False,
+          use_graph=True):
+    """:565-613: Adam(lr, wd 1e-5), MSE, shuffled minibatches, ReduceLROnPlateau on the epoch-mean
+    loss, early stop after 8 non-improving epochs, best-weights restore."""
     torch = _torch()
     R = x.numel()
     bs = pick_batch(R, nn_batch)
-    opt = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-5)
-    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=5, factor=0.5, min_lr=1e-6)
+    dev = x.device
+    data = build_training_matrix(x, t, y, fm, fs, ym, ysd, T, dt)
+    # state snapshots for the warm-up steps of the graph capture must not leak into training
+    init_state = copy.deepcopy(net.state_dict())
+    lr_t = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+    opt = torch.optim.Adam(net.parameters(), lr=lr_t, weight_decay=1e-5, capturable=True)
     loss_fn = torch.nn.MSELoss()
-    best, best_state, bad, steps = float("inf"), None, 0, 0
     net.train()
+    step = _GraphedStep(net, opt, loss_fn, bs, dev) if use_graph else None
+    graphed = step is not None and step.graph is not None
+    if step is not None:
+        # The warm-up steps of the capture moved the weights and the Adam moments.  The graph
+        # holds those very tensors, so reset them IN PLACE: training starts from the initial
+        # weights with a pristine optimizer, exactly as without the graph.
+        net.load_state_dict(init_state)
+        for st_ in opt.state.values():
+            for v_ in st_.values():
+                if torch.is_tensor(v_):
+                    v_.zero_()
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=5, factor=0.5, min_lr=1e-6)
+    best, best_state, bad, steps = float("inf"), None, 0, 0
     for epoch in range(epochs):
-        perm = torch.randperm(R, device=x.device)
-        tot = torch.zeros((), dtype=torch.float64, device=x.device)
+        perm = torch.randperm(R, device=dev)
+        shuf = data[perm]
+        tot = torch.zeros((), dtype=torch.float64, device=dev)
         nb = 0
         for o in range(0, R, bs):
-            idx = perm[o:o + bs]
-            xb, tb = x[idx], t[idx]
-            st = torch.sqrt(torch.clamp(T - tb.double() * dt, min=1e-6))
-            fb = ((features(xb, st) - fm) / fs).float()
-            yb = ((y[idx] - ym) / ysd).float().unsqueeze(1)
-            loss = loss_fn(net(fb), yb)
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            opt.step()
-            tot += loss.detach().double()
+            batch = shuf[o:o + bs]
+            loss = step(batch) if step is not None else None
+            if loss is None:
+                l_ = loss_fn(net(batch[:, :7]), batch[:, 7:])
+                opt.zero_grad(set_to_none=True)
+                l_.backward()
+                opt.step()
+                loss = l_.detach()
+            tot += loss.double()
             nb += 1
+        del shuf
         steps += nb
         avg = float(tot) / max(nb, 1)  # one host sync per epoch
         sched.step(avg)
@@ -194,7 +270,7 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
                 break
     if best_state is not None:
         net.load_state_dict(best_state)
-    return dict(batch=bs, optimizer_steps=steps, epochs_run=epoch + 1, best_loss=best)
+    return dict(batch=bs, optimizer_steps=steps, epochs_run=epoch + 1, best_loss=best, graphed=graphed)
 
 
 def pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, path_chunk=1 << 20):
