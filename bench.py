@@ -14,9 +14,10 @@ same thing at 8M paths per GPU: --paths-per-gpu 8000000), moments and sums all-r
 over RCCL.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      path-generation kernel: algorithmic bytes (n_steps+1)*n_paths*4 per launch
-                / mean HIP-event duration of that launch inside the timed region, vs 8 TB/s
-  roofline_lsm  the backward induction as a whole (all its kernels), same accounting
+  roofline          the dominant kernel (largest time share): algorithmic bytes per launch / mean
+                    HIP-event duration of that launch inside the timed region, vs 8 TB/s HBM peak
+  roofline_pathgen  the path-generation kernel named by north_star: (n_steps+1)*n_paths*4 bytes
+  roofline_kernels  every big kernel of the pricing, same accounting (+ PMC traffic if profiled)
   cpu_baseline  the C oracle (oracle/, a port: the reference is Python) on this host
 """
 import argparse
@@ -119,12 +120,14 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ms_paths = ms_lsm = 0.0
+    ms_paths = ms_lsm = ms_p1 = ms_p2 = 0.0
     price = 0.0
     for i in range(a.steps):
         out, loc = one_step(i)
         ms_paths += loc["ms_paths"]
         ms_lsm += loc["ms_lsm"]
+        ms_p1 += loc.get("ms_pass1", 0.0)
+        ms_p2 += loc.get("ms_pass2", 0.0)
         price = out["price"]
     barrier()
     torch.cuda.synchronize()
@@ -137,6 +140,8 @@ def main():
 
     ms_paths /= a.steps
     ms_lsm /= a.steps
+    ms_p1 /= a.steps
+    ms_p2 /= a.steps
     b_gen = 4.0 * (N + 1) * M
     b_lsm = lsm_algorithmic_bytes(a.semantics, M, N)
     line = {
@@ -155,24 +160,40 @@ def main():
                    "rng": "Philox4x32-10 + Box-Muller, antithetic"},
         "paths_x252_per_sec_per_gpu": M * N * a.steps / elapsed / 252.0,
         "price": price,
-        "roofline": {"kernel": f"{a.model}_paths_kernel", "bound": "hbm",
-                     "achieved": b_gen / (ms_paths * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": b_gen / (ms_paths * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "bytes_per_launch": b_gen, "ms_per_launch": ms_paths, "traffic": None},
-        "roofline_lsm": {"kernel": "lsm_* (all kernels of the backward induction)", "bound": "hbm",
-                         "achieved": b_lsm / (ms_lsm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": b_lsm / (ms_lsm * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "bytes_per_pricing": b_lsm, "ms_per_pricing": ms_lsm, "traffic": None},
     }
-    # measured PMC traffic, if a profile summary for this round was committed
+
+    # ---- roofline: every big kernel of the pricing, HIP-event time per launch inside the timed
+    # region (library events on its own stream) vs its algorithmic bytes; `roofline` is the
+    # dominant one (largest time share), `roofline_pathgen` the one north_star names.
+    def rf(kernel, nbytes, ms, launches=1):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "ms_per_launch": ms,
+                "launches_per_pricing": launches, "traffic": None}
+
+    kernels = [rf(f"{a.model}_paths_kernel", b_gen, ms_paths)]
+    if a.semantics == "two_pass":
+        kernels.append(rf("lsm_pass1_kernel", 4.0 * M * N, ms_p1))  # rows 1..N-1 + terminal row
+        kernels.append(rf("lsm_pass2_kernel", 4.0 * M * N, ms_p2))  # rows N..1 (upper bound)
+    else:
+        kernels.append(rf("lsm_step_kernel", 16.0 * M, ms_lsm / N, launches=N))  # S_t, S_t-1, sx, tex
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
+    if os.path.exists(prof):  # measured HBM bytes per launch (rocprofv3 --pmc passes, see profiles/)
         try:
-            pt = json.load(open(prof))
-            line["roofline"]["traffic"] = pt.get("paths_kernel_bytes_per_launch")
-            line["roofline_lsm"]["traffic"] = pt.get(f"lsm_{a.semantics}_bytes_per_pricing")
+            pk = json.load(open(prof)).get("kernels", {})
+            for k in kernels:
+                stem = k["kernel"].replace("gbm_", "").replace("heston_", "")
+                for name, v in pk.items():
+                    if stem in name:
+                        k["traffic"] = v["read_bytes"] + v["write_bytes"]
         except Exception:
             pass
+    dominant = max(kernels, key=lambda k: k["ms_per_launch"] * k["launches_per_pricing"])
+    line["roofline"] = dominant
+    line["roofline_pathgen"] = kernels[0]
+    line["roofline_kernels"] = kernels
+    line["roofline_lsm_total"] = {"bytes_per_pricing": b_lsm, "ms_per_pricing": ms_lsm,
+                                  "achieved": b_lsm / (ms_lsm * 1e-3) / 1e9, "unit": "GB/s"}
 
     if world == 1 and not a.no_variants:
         var = {}

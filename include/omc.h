@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OMC_ABI_VERSION 1
+#define OMC_ABI_VERSION 2
 
 typedef struct omc_ctx omc_ctx;
 
@@ -70,6 +70,7 @@ typedef struct {
     double zero_prob;      /* P(cash-flow == 0), Options_model.py:155                     */
     int64_t n_paths, n_exercised, n_zero, sum_nitm;
     double ms_paths, ms_lsm, ms_total; /* HIP-event times of this call on the context's stream */
+    double ms_pass1, ms_pass2;         /* omc_price_american, two-pass flow: the two big LSM kernels */
 } omc_result;
 
 /* ---- library / context --------------------------------------------------------------- */

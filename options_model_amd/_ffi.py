@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
 MODELS = {"gbm": 0, "heston": 1}
@@ -39,7 +39,8 @@ class Result(C.Structure):
                 ("std", C.c_double), ("zero_prob", C.c_double),
                 ("n_paths", C.c_int64), ("n_exercised", C.c_int64), ("n_zero", C.c_int64),
                 ("sum_nitm", C.c_int64),
-                ("ms_paths", C.c_double), ("ms_lsm", C.c_double), ("ms_total", C.c_double)]
+                ("ms_paths", C.c_double), ("ms_lsm", C.c_double), ("ms_total", C.c_double),
+                ("ms_pass1", C.c_double), ("ms_pass2", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

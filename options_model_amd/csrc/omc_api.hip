@@ -79,7 +79,7 @@ struct omc_ctx {
     double D_r = 0, D_T = 0;
     const double* D_ptr = nullptr;
     double hres[8];
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int gbm_vec = 0, heston_vec = 0, use_graph = 0;
     int world = 1;  // ranks whose sums the hook adds up (equal shards)
     omc_allreduce_fn hook = nullptr;
@@ -561,6 +561,7 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     omc::LsmWorkspace w;
     if ((rc = prepare_lsm(c, M, N, p->r, p->T, p->semantics == OMC_SEM_TWO_PASS, false, &w))) return rc;
     omc::LsmProblem prob{S, ld, M, N, p->is_put ? 1 : 0, p->K, p->r, p->T};
+    w.ev_p1_begin = c->ev[3]; w.ev_p1_end = c->ev[4]; w.ev_p2_begin = c->ev[5]; w.ev_p2_end = c->ev[6];
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (p->model == OMC_MODEL_GBM)
         HIP_TRY(omc::launch_gbm_paths(c->stream, S, ld, M, N, p->S0, p->r, p->sigma, p->T, p->seed,
@@ -582,6 +583,12 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
     res->ms_lsm = ms;
     res->ms_total = res->ms_paths + res->ms_lsm;
+    if (p->semantics == OMC_SEM_TWO_PASS && N >= 2) {
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+        res->ms_pass1 = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[5], c->ev[6]));
+        res->ms_pass2 = ms;
+    }
     return 0;
 }
 

@@ -61,6 +61,8 @@ struct LsmWorkspace {
     double* part1;    // two-pass: [N+1][8][ntiles] partial moments of pass 1
     int64_t part1_tiles;
     double* result;   // [8] sum, sumsq, n_exercised, n_zero, sum_nitm, -, -, -
+    // optional: events recorded right around the two big kernels of the two-pass flow
+    hipEvent_t ev_p1_begin = nullptr, ev_p1_end = nullptr, ev_p2_begin = nullptr, ev_p2_end = nullptr;
 };
 
 size_t lsm_part1_tiles(int64_t M);

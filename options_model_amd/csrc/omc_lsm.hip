@@ -127,11 +127,13 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     a.ntiles = (p.M + per_wave - 1) / per_wave;
     a.tchunk = (tch_env >= 2 && tch_env <= 64) ? tch_env : 16;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
+    if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
     if (!v4) hipLaunchKernelGGL((lsm_pass1_kernel<1, 4>), grid, dim3(kBlock), 0, st, a);
     else if (tpw == 1) hipLaunchKernelGGL((lsm_pass1_kernel<4, 1>), grid, dim3(kBlock), 0, st, a);
     else if (tpw == 2) hipLaunchKernelGGL((lsm_pass1_kernel<4, 2>), grid, dim3(kBlock), 0, st, a);
     else if (tpw == 8) hipLaunchKernelGGL((lsm_pass1_kernel<4, 8>), grid, dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL((lsm_pass1_kernel<4, 4>), grid, dim3(kBlock), 0, st, a);
+    if (w.ev_p1_end) (void)hipEventRecord(w.ev_p1_end, st);
     hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1, 8), dim3(kBlock), 0, st, w.part1, w.gmom,
                        a.ntiles, p.N);
     return hipGetLastError();
@@ -155,6 +157,7 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
     a.nblk = nblk; a.pstride = kPStride;
     const size_t dyn = sizeof(double) * 4 * (size_t)(p.N + 1);
     const bool v4 = vec4_ok(p);
+    if (w.ev_p2_begin) (void)hipEventRecord(w.ev_p2_begin, st);
     if (v4) {
         if (write_state) hipLaunchKernelGGL((lsm_pass2_kernel<4, true>), dim3(nblk), dim3(kBlock), dyn, st, a);
         else hipLaunchKernelGGL((lsm_pass2_kernel<4, false>), dim3(nblk), dim3(kBlock), dyn, st, a);
@@ -162,6 +165,7 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
         if (write_state) hipLaunchKernelGGL((lsm_pass2_kernel<1, true>), dim3(nblk), dim3(kBlock), dyn, st, a);
         else hipLaunchKernelGGL((lsm_pass2_kernel<1, false>), dim3(nblk), dim3(kBlock), dyn, st, a);
     }
+    if (w.ev_p2_end) (void)hipEventRecord(w.ev_p2_end, st);
     hipLaunchKernelGGL(lsm_finalize_kernel, dim3(1), dim3(kBlock), 0, st, w.part, w.gmom, w.result,
                        nblk, p.N, kPStride);
     return hipGetLastError();
