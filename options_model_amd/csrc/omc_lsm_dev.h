@@ -271,6 +271,7 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     if (t0 >= t1) return;
     const double K = a.K, invK = a.invK;
     const int is_put = a.is_put;
+    const double sgn = is_put ? -1.0 : 1.0, Ks = is_put ? K : -K;
     // The chunk's discount factors go through the wave's LDS patch: a vector-memory load of
     // D[N-t] inside the loop would sit behind the row prefetch in the in-order vmcnt queue
     // and expose the prefetch latency every step.
@@ -311,7 +312,7 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const double sd = (double)buf[k][v];
-                const double imm = is_put ? K - sd : sd - K;
+                const double imm = fma(sgn, sd, Ks);  // put: K - sd, call: sd - K (one rounding either way)
                 const bool itm = valid[k] && imm > 0.0;
                 const double u = itm ? fma(sd, invK, -1.0) : 0.0;
                 const double p = itm ? pN[k][v] : 0.0;
@@ -334,15 +335,31 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         const double s = wave_reduce8(acc, wl[wave]);
         if ((lane & 7) == 0) a.part1[((size_t)t * 8 + (lane >> 3)) * a.ntiles + tg] = s;
     };
-    // two register buffers, rows fetched one step ahead of their use
-    float bufA[TPW][VEC], bufB[TPW][VEC];
+    // Three rotating register buffers, rows fetched TWO steps ahead of their use; row indices are
+    // clamped to the chunk, so every load is unconditional and the compiler can count them
+    // (vmcnt(7..4) in the ISA instead of vmcnt(0)).  Measured (profiles/, SQ counters): with
+    // the loads hidden this kernel is bound by float64 VALU issue -- ~320 VALU instructions per
+    // wave-step at ~8 cycles each equal the kernel's cycles -- not by HBM: halving the
+    // instruction count, not the prefetch depth, is what would move it.
+    float bufA[TPW][VEC], bufB[TPW][VEC], bufC[TPW][VEC];
+    const int tl = t1 - 1;
+    // sched_barrier: hipcc otherwise sinks the prefetch loads below the arithmetic they are
+    // meant to overlap (seen in the ISA as vmcnt(0) right before the late-issued loads)
     load_rows(bufA, t0);
-    for (int t = t0; t < t1; t += 2) {
-        load_rows(bufB, min(t + 1, t1 - 1));
+    load_rows(bufB, min(t0 + 1, tl));
+    for (int t = t0; t < t1; t += 3) {
+        load_rows(bufC, min(t + 2, tl));
+        __builtin_amdgcn_sched_barrier(0);
         process(bufA, t);
         if (t + 1 < t1) {
-            load_rows(bufA, min(t + 2, t1 - 1));
+            load_rows(bufA, min(t + 3, tl));
+            __builtin_amdgcn_sched_barrier(0);
             process(bufB, t + 1);
+        }
+        if (t + 2 < t1) {
+            load_rows(bufB, min(t + 4, tl));
+            __builtin_amdgcn_sched_barrier(0);
+            process(bufC, t + 2);
         }
     }
 }
