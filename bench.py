@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--model", default="gbm", choices=["gbm", "heston"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="go through torch.distributed/RCCL even with one rank (rehearsal of the N>1 path)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,10 +98,13 @@ def main():
     if not torch.cuda.is_available() or _ffi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_mode = world > 1 or a.force_dist
+    if dist_mode:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        pricer = omc_dist.ShardedPricer(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        pricer = omc_dist.ShardedPricer(local_rank, force_hook=a.force_dist)
         barrier = td.barrier
     else:
         pricer = None
@@ -132,7 +137,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_mode:
         import torch.distributed as td
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -195,7 +200,7 @@ def main():
     line["roofline_lsm_total"] = {"bytes_per_pricing": b_lsm, "ms_per_pricing": ms_lsm,
                                   "achieved": b_lsm / (ms_lsm * 1e-3) / 1e9, "unit": "GB/s"}
 
-    if world == 1 and not a.no_variants:
+    if not dist_mode and not a.no_variants:
         var = {}
         for sem in ("two_pass", "reference", "textbook"):
             if sem == a.semantics:
@@ -213,13 +218,13 @@ def main():
                         "price": o["price"]}
         line["variants"] = var
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not dist_mode and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(M, N, a.semantics)
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_mode:
         import torch.distributed as td
         pricer.close()
         td.destroy_process_group()

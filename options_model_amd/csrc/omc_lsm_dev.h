@@ -337,10 +337,11 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     };
     // Three rotating register buffers, rows fetched TWO steps ahead of their use; row indices are
     // clamped to the chunk, so every load is unconditional and the compiler can count them
-    // (vmcnt(7..4) in the ISA instead of vmcnt(0)).  Measured (profiles/, SQ counters): with
-    // the loads hidden this kernel is bound by float64 VALU issue -- ~320 VALU instructions per
-    // wave-step at ~8 cycles each equal the kernel's cycles -- not by HBM: halving the
-    // instruction count, not the prefetch depth, is what would move it.
+    // (vmcnt(7..4) in the ISA instead of vmcnt(0)).  Measured (SQ counters):
+    // wave-cycles split 46 % VALU issue stall / 35 % memory wait / 19 % issuing, ~320 VALU
+    // instructions per wave-step, half of them float64 (4 cycles each by tools/ubench.hip).
+    // Neither deeper prefetch nor a 15 % shorter instruction stream moved the time: the kernel
+    // sits where its float64 arithmetic and its HBM reads each cost about the same.
     float bufA[TPW][VEC], bufB[TPW][VEC], bufC[TPW][VEC];
     const int tl = t1 - 1;
     // sched_barrier: hipcc otherwise sinks the prefetch loads below the arithmetic they are

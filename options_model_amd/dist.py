@@ -55,7 +55,7 @@ class _DevPtr:
 class ShardedPricer:
     """One per rank.  Requires torch.distributed to be initialised (nccl) and a GPU."""
 
-    def __init__(self, local_rank: int, group=None):
+    def __init__(self, local_rank: int, group=None, force_hook: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -73,7 +73,7 @@ class ShardedPricer:
         self.ctx = _ffi.Context(local_rank, stream=self.stream.cuda_stream)
         self._ffi = _ffi
         self._alias = {}
-        if self.world > 1:
+        if self.world > 1 or force_hook:  # force_hook: exercise the RCCL path with one rank
             # the library calls the hook for the moment table(s) AND for its 8 result sums, and
             # normalises by n_local * world_size: the returned omc_result is already global
             self.ctx.set_allreduce_hook(self._allreduce_device)

@@ -137,5 +137,15 @@ def test_sharded_pricer_world_size_one():
         assert out["price"] == pytest.approx(base["price"], rel=1e-12)
         assert out["n_paths"] == 50_000 and out["stderr"] > 0
         sp.close()
+        # the real collective on the library's own device buffers (torch alias of a hipMalloc'ed
+        # pointer handed to RCCL), for every flow: 1-rank all-reduce is the identity
+        sp = omc_dist.ShardedPricer(0, force_hook=True)
+        for sem in ("two_pass", "reference", "textbook"):
+            out = sp.price_american(20_000, semantics=sem, n_steps=12, seed=4)
+            base = _ffi.default_context(0).price_american(
+                _ffi.make_params(semantics=sem, n_paths=20_000, n_steps=12, seed=4))
+            assert out["price"] == pytest.approx(base["price"], rel=1e-12)
+            assert out["n_exercised"] == base["n_exercised"]
+        sp.close()
     finally:
         td.destroy_process_group()
