@@ -1,0 +1,129 @@
+"""Local-volatility paths through an implied-vol network:
+drop-in for `IVModel` (options_model_3/options_model_3.py:263-298) and
+`simulate_local_vol_paths_antithetic` (:300-333) on the MI355X.
+
+Per time step the reference calls the IV network on ALL paths (2 -> 64 -> 4 x [Linear 64x64,
+LayerNorm, GELU, residual] -> 1; NN_training_stock_iv.py:109-155) through numpy <-> torch-CPU
+round trips.  Here the whole simulation stays on the GPU: normals from the library's Philox
+generator (same counter layout as the GBM kernel: `omc_gbm_normals_f32`), the network forward
+as batched GEMMs over the M paths (PyTorch-ROCm -> hipBLASLt -> MFMA: the one place in path
+generation that is GEMM-shaped), the log-Euler update fused into a few elementwise kernels.
+The resulting [step][path] float32 matrix feeds the same HIP backward-induction kernels as
+every other model (`omc_lsm_poly` on the tensor's device pointer).
+"""
+from __future__ import annotations
+
+import math
+
+from . import _ffi
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _ffi.OmcError("local-vol paths need PyTorch-ROCm with a visible GPU")
+    return torch
+
+
+def make_iv_network(hidden_dim=64, num_hidden_layers=4, epsilon=1e-4, dropout=0.1):
+    """Architecture of the reference's ImprovedIVNetwork (NN_training_stock_iv.py:109-155) with the
+    same parameter names, so a `state_dict` saved by the reference's trainer (:529-538) loads as is:
+    input_proj Linear(2,H)+GELU, L x [h += Dropout(GELU(LayerNorm(Linear(h))))], output Linear(H,1),
+    clamped at epsilon.  Attach a `scaler` (m_scale, tau_scale) before wrapping it in IVModel."""
+    torch = _torch()
+    nn, F = torch.nn, torch.nn.functional
+
+    class IVNetwork(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.epsilon = float(epsilon)
+            self.scaler = None
+            self.input_proj = nn.Linear(2, hidden_dim)
+            self.layers = nn.ModuleList(
+                nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.GELU(),
+                              nn.Dropout(dropout) if dropout > 0 else nn.Identity())
+                for _ in range(num_hidden_layers))
+            self.output = nn.Linear(hidden_dim, 1)
+
+        def forward(self, x):
+            h = F.gelu(self.input_proj(x))
+            for layer in self.layers:
+                h = h + layer(h)
+            return self.output(h).clamp(min=self.epsilon)
+
+    return IVNetwork()
+
+
+class IVModel:
+    """Same contract as the reference wrapper: takes the trained network object, which must
+    carry a fitted `scaler` with `m_scale` / `tau_scale`; evaluates sigma(K, S, tau)."""
+
+    def __init__(self, nn_model, device: int = 0):
+        torch = _torch()
+        if not hasattr(nn_model, "scaler") or nn_model.scaler is None:
+            raise ValueError("Model does not have a fitted scaler")
+        self.device = torch.device("cuda", device)
+        self.model = nn_model.eval().to(self.device)
+        self.m_scale = float(nn_model.scaler.m_scale)
+        self.tau_scale = float(nn_model.scaler.tau_scale)
+
+    def sigma_tensor(self, K: float, S, tau: float):
+        """S: float32 device tensor [n] -> sigma float32 [n] (clamped at 1e-6 like :293)."""
+        torch = _torch()
+        tau = max(float(tau), 1e-6)
+        m = torch.log(max(K, 1e-8) / torch.clamp(S.double(), min=1e-8))
+        X = torch.stack([m / self.m_scale, torch.full_like(m, tau / self.tau_scale)], dim=1).float()
+        with torch.no_grad():
+            return self.model(X).squeeze(1).clamp_min(1e-6)
+
+    def get_volatility_batch(self, K: float, S_batch, tau: float):
+        """numpy in / numpy float64 out, with the reference's input checks (:276-283)."""
+        import numpy as np
+        torch = _torch()
+        S_batch = np.asarray(S_batch, dtype=np.float64)
+        if K <= 0:
+            raise ValueError(f"K must be positive, got {K}")
+        if np.any(S_batch <= 0):
+            raise ValueError("All S_batch values must be positive")
+        s = torch.from_numpy(S_batch).to(self.device)
+        return self.sigma_tensor(K, s, tau).double().cpu().numpy()
+
+
+def simulate_local_vol_paths(S0, r, T, num_simulations, num_time_steps, iv_model: IVModel, K, seed,
+                             stream=0, z_half=None):
+    """-> float32 device tensor S [num_time_steps+1, M], M = num_simulations // 2 * 2, antithetic
+    partner of column j is j + M/2 (:306-307).  z_half (optional, [N][M/2]) injects normals."""
+    torch = _torch()
+    dev = iv_model.device
+    N = int(num_time_steps)
+    M = int(num_simulations) // 2 * 2
+    P = M // 2
+    dt = T / N
+    with torch.cuda.device(dev):
+        if z_half is None:
+            Z = torch.empty((N, P), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize(dev)
+            ctx = _ffi.default_context(dev.index or 0)
+            _ffi._check(ctx.lib, ctx.lib.omc_gbm_normals_f32(ctx.handle, Z.data_ptr(), P, P, N, int(seed),
+                                                             int(stream), 0))
+        else:
+            Z = torch.as_tensor(z_half, dtype=torch.float32, device=dev)
+            assert Z.shape == (N, P)
+        S = torch.empty((N + 1, M), dtype=torch.float32, device=dev)
+        S[0] = S0
+        sq = math.sqrt(dt)
+        for t in range(1, N + 1):
+            prev = S[t - 1]
+            tau_t = max(T - (t - 1) * dt, 1e-6)
+            sig = iv_model.sigma_tensor(K, prev, tau_t)
+            z = torch.cat([Z[t - 1], -Z[t - 1]])
+            S[t] = prev * torch.exp((r - 0.5 * sig * sig) * dt + sig * sq * z)
+    return S
+
+
+def price_american_on_paths(ctx, S, K, r, T, is_put, semantics="two_pass"):
+    """Backward induction by the HIP kernels directly on the torch tensor's memory."""
+    torch = _torch()
+    torch.cuda.synchronize(S.device)
+    sem = {"two_pass": "two_pass", "per_step": "reference", "textbook": "textbook"}[semantics]
+    return ctx.lsm_poly(S, K, r, T, is_put, sem)

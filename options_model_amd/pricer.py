@@ -15,7 +15,8 @@ What differs, by construction (DESIGN.md "Parity"):
     500-path European chunk) is kept so curves consume seeds exactly as the reference does;
   * the continuation-value regressor is OLS on [1,u,u^2] per time step (regressor="poly");
     regressor="nn" trains the reference's SingleLSMNet on the GPU (nn_regressor.py);
-  * iv_model (local-vol paths through an IV network) is out of scope.
+  * iv_model: pass an `options_model_amd.local_vol.IVModel` (same constructor contract as the
+    reference's); paths are then simulated on the GPU through the IV network (local_vol.py).
 """
 from __future__ import annotations
 
@@ -137,9 +138,6 @@ class AdvancedOptionPricer:
         return np.maximum(S - self.K, 0) if self.option_type == "call" else np.maximum(self.K - S, 0)
 
     def _model_kw(self):
-        if self.iv_model is not None:
-            raise NotImplementedError("iv_model (local-vol paths) is outside the accelerated hot "
-                                      "path; see SURVEY.md section 8 row f-4")
         if self.use_heston and self.heston_params is not None:
             return dict(model="heston", **heston_defaults(self.sigma, self.heston_params))
         if self.sigma is None:
@@ -155,7 +153,6 @@ class AdvancedOptionPricer:
     # -- European (options_model_3.py:382-437)
     def price_european_streaming(self, S0: float, T: float, num_simulations: int = 10000,
                                  num_time_steps: int = 50) -> float:
-        kw = self._model_kw()
         # the reference draws one child RNG per chunk_size-path chunk; consume the same number
         # of master draws and key the single fused launch with the first of them
         n_chunks = max(1, -(-int(num_simulations) // int(self.chunk_size)))
@@ -163,6 +160,14 @@ class AdvancedOptionPricer:
         M = int(num_simulations) // 2 * 2
         if M <= 0:
             return 0.0
+        if self.iv_model is not None:  # local-vol paths through the IV network (:394-395)
+            from . import local_vol
+            S = local_vol.simulate_local_vol_paths(S0, self.r, T, M, int(num_time_steps), self.iv_model,
+                                                   self.K, seeds[0], stream=1)
+            pay = (self.K - S[-1].double()).clamp(min=0) if self.option_type == "put" else \
+                (S[-1].double() - self.K).clamp(min=0)
+            return float(pay.mean()) * math.exp(-self.r * T)
+        kw = self._model_kw()
         p = _ffi.make_params(is_put=(self.option_type == "put"), n_paths=M, n_steps=int(num_time_steps),
                              S0=S0, K=self.K, r=self.r, sigma=self.sigma or 0.0, T=T, seed=seeds[0],
                              stream=1, **kw)
@@ -187,6 +192,22 @@ class AdvancedOptionPricer:
         if M == 0:
             raise ValueError("num_simulations and num_time_steps must be positive integers.")
         self._calls += 1
+        if self.iv_model is not None:  # :461-462: local-vol paths, then the same backward induction
+            from . import local_vol
+            S = local_vol.simulate_local_vol_paths(S0, self.r, T, M, int(num_time_steps), self.iv_model,
+                                                   self.K, path_seed)
+            if self.regressor == "nn":
+                from . import nn_regressor
+                res = nn_regressor.price_with_paths(S, self.K, self.r, T, self.option_type == "put",
+                                                    torch_seed, nn_hidden=self.nn_hidden,
+                                                    nn_layers=self.nn_layers, nn_dropout=self.nn_dropout,
+                                                    nn_epochs=self.nn_epochs, nn_lr=self.nn_lr)
+                res.pop("net", None)
+            else:
+                res = local_vol.price_american_on_paths(self._ctx(), S, self.K, self.r, T,
+                                                        self.option_type == "put", self.semantics)
+            self.last_result = res
+            return res["price"]
         if self.regressor == "nn":
             from . import nn_regressor
             res = nn_regressor.price_two_pass_nn(self, S0, T, M, int(num_time_steps), path_seed, torch_seed)
