@@ -86,7 +86,8 @@ int omc_alloc(omc_ctx* ctx, size_t bytes, void** dptr);
 int omc_free(omc_ctx* ctx, void* dptr);
 int omc_memcpy_h2d(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
 int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
-/* tuning knobs: "gbm_vec" / "heston_vec" (pairs per thread: 1,2,4), "use_graph" (0/1) */
+/* knobs: "gbm_vec" / "heston_vec" (pairs per thread: 1,2,4; 0 = auto), "world_size" (ranks behind
+ * the all-reduce hook, see below) */
 int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
 
 /* ---- path generation ------------------------------------------------------------------- */

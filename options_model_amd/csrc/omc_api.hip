@@ -80,7 +80,7 @@ struct omc_ctx {
     const double* D_ptr = nullptr;
     double hres[8];
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int gbm_vec = 0, heston_vec = 0, use_graph = 0;
+    int gbm_vec = 0, heston_vec = 0;
     int world = 1;  // ranks whose sums the hook adds up (equal shards)
     omc_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
@@ -349,7 +349,6 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     if (!c || !key) return fail(-7, "null pointer.");
     if (!strcmp(key, "gbm_vec")) c->gbm_vec = (int)value;
     else if (!strcmp(key, "heston_vec")) c->heston_vec = (int)value;
-    else if (!strcmp(key, "use_graph")) c->use_graph = (int)value;
     else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
     else return fail(-4, "unknown option key.");
     return 0;

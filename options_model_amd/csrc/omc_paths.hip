@@ -114,8 +114,6 @@ HestonC make_heston(double r, double T, int n_steps, double kappa, double theta,
     return c;
 }
 
-static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-
 static inline unsigned grid_for(int64_t work_items)
 {
     return (unsigned)((work_items + kBlock - 1) / kBlock);

@@ -8,11 +8,6 @@
 namespace omc {
 
 
-template <int VEC> struct VecT;
-template <> struct VecT<1> { using type = float; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<4> { using type = float4; };
-
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
 {
