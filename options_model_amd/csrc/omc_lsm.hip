@@ -29,8 +29,8 @@ __global__ __launch_bounds__(kBlock) void lsm_reduce_step_kernel(const double* p
     lsm_reduce_step_body(part, gmom, t, nblk, pstride);
 }
 
-template <int VEC, int TPW>
-__global__ __launch_bounds__(kBlock) void lsm_pass1_kernel(Pass1Args a) { lsm_pass1_body<VEC, TPW>(a); }
+template <int VEC, int TPW, int PUT>
+__global__ __launch_bounds__(kBlock) void lsm_pass1_kernel(Pass1Args a) { lsm_pass1_body<VEC, TPW, PUT>(a); }
 
 __global__ __launch_bounds__(kBlock) void lsm_reduce_pass1_kernel(const double* part1, double* gmom,
                                                                   int64_t ntiles, int N)
@@ -128,11 +128,17 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     a.tchunk = (tch_env >= 2 && tch_env <= 64) ? tch_env : 16;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
-    if (!v4) hipLaunchKernelGGL((lsm_pass1_kernel<1, 4>), grid, dim3(kBlock), 0, st, a);
-    else if (tpw == 1) hipLaunchKernelGGL((lsm_pass1_kernel<4, 1>), grid, dim3(kBlock), 0, st, a);
-    else if (tpw == 2) hipLaunchKernelGGL((lsm_pass1_kernel<4, 2>), grid, dim3(kBlock), 0, st, a);
-    else if (tpw == 8) hipLaunchKernelGGL((lsm_pass1_kernel<4, 8>), grid, dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((lsm_pass1_kernel<4, 4>), grid, dim3(kBlock), 0, st, a);
+    auto launch = [&](auto vec, auto tp) {
+        constexpr int V = decltype(vec)::value, T = decltype(tp)::value;
+        if (p.is_put) hipLaunchKernelGGL((lsm_pass1_kernel<V, T, 1>), grid, dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((lsm_pass1_kernel<V, T, 0>), grid, dim3(kBlock), 0, st, a);
+    };
+    using std::integral_constant;
+    if (!v4) launch(integral_constant<int, 1>{}, integral_constant<int, 4>{});
+    else if (tpw == 1) launch(integral_constant<int, 4>{}, integral_constant<int, 1>{});
+    else if (tpw == 2) launch(integral_constant<int, 4>{}, integral_constant<int, 2>{});
+    else if (tpw == 8) launch(integral_constant<int, 4>{}, integral_constant<int, 8>{});
+    else launch(integral_constant<int, 4>{}, integral_constant<int, 4>{});
     if (w.ev_p1_end) (void)hipEventRecord(w.ev_p1_end, st);
     hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1, 8), dim3(kBlock), 0, st, w.part1, w.gmom,
                        a.ntiles, p.N);

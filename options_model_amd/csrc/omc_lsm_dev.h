@@ -6,6 +6,7 @@
 #pragma once
 #include "omc_device.h"
 #include "omc_kernels.h"
+#include <type_traits>
 
 namespace omc {
 
@@ -240,6 +241,22 @@ __device__ __forceinline__ void lsm_reduce_step_body(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------ two-pass flow
+// Float32 threshold of the in-the-money test: for a float32 price s and a float64 strike K,
+// K - (double)s > 0  <=>  s < thr (put), (double)s - K > 0  <=>  s > thr (call), with thr the
+// nearest float32 at or above K (put) / at or below K (call).
+__device__ __forceinline__ float next_float(float f, bool up)
+{
+    if (f == 0.0f) return __uint_as_float(up ? 0x00000001u : 0x80000001u);
+    const uint32_t b = __float_as_uint(f);
+    return __uint_as_float(((f > 0.0f) == up) ? b + 1u : b - 1u);
+}
+__device__ __forceinline__ float itm_threshold(double K, int is_put)
+{
+    const float Kf = (float)K;
+    if (is_put) return (double)Kf < K ? next_float(Kf, true) : Kf;
+    return (double)Kf > K ? next_float(Kf, false) : Kf;
+}
+
 struct Pass1Args {
     const float* S;
     int64_t ld, M;
@@ -257,7 +274,8 @@ struct Pass1Args {
 // the wave reduces them through its private LDS patch and writes one partial per quantity.
 // The next step's rows are loaded before the current one is reduced.
 // Targets are the discounted TERMINAL payoffs.
-template <int VEC, int TPW>
+// PUT: 1 put, 0 call, -1 decided at run time (the batched launch mixes both).
+template <int VEC, int TPW, int PUT = -1>
 __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
 {
     __shared__ double wl[kBlock / 64][kWaveRedDoubles];
@@ -270,8 +288,7 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     const int t1 = min(t0 + a.tchunk, a.N);
     if (t0 >= t1) return;
     const double K = a.K, invK = a.invK;
-    const int is_put = a.is_put;
-    const double sgn = is_put ? -1.0 : 1.0, Ks = is_put ? K : -K;
+    const int is_put = PUT < 0 ? a.is_put : PUT;
     // The chunk's discount factors go through the wave's LDS patch: a vector-memory load of
     // D[N-t] inside the loop would sit behind the row prefetch in the in-order vmcnt queue
     // and expose the prefetch latency every step.
@@ -299,10 +316,18 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         for (int k = 0; k < TPW; ++k) loadf<VEC>(colp[k] + (int64_t)t * a.ld, buf[k]);
     };
     // Branch-free accumulation: an out-of-the-money (or padding) path contributes u = 0, p = 0
-    // (adding +0.0 is exact, so the sums are those of the masked loop, bit for bit), the set
-    // size is counted in integers, and the step's discount factor multiplies the three target
-    // sums once per lane instead of once per path.
-    auto process = [&](const float (&buf)[TPW][VEC], int t) {
+    // (adding +0.0 is exact, so the sums are those of the masked loop, bit for bit), and the
+    // step's discount factor multiplies the three target sums once per lane instead of once per
+    // path.  In the money means K - S > 0 (put) / S - K > 0 (call) in float64, which for a
+    // float32 S is exactly S < thr / S > thr against a float32 threshold: a 32-bit compare
+    // replaces a float64 fma + compare.  The set size is only needed per wave, so it is counted
+    // on the scalar unit (popcount of the compare mask).
+    const float thr = itm_threshold(K, is_put);
+    float thrk[TPW];  // padding tiles: a threshold no price passes
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) thrk[k] = valid[k] ? thr : (is_put ? -__builtin_inff() : __builtin_inff());
+    auto process = [&](auto put_tag, const float (&buf)[TPW][VEC], int t) {
+        constexpr bool IS_PUT = decltype(put_tag)::value;
         double acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.0;
@@ -311,13 +336,13 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         for (int k = 0; k < TPW; ++k) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const double sd = (double)buf[k][v];
-                const double imm = fma(sgn, sd, Ks);  // put: K - sd, call: sd - K (one rounding either way)
-                const bool itm = valid[k] && imm > 0.0;
-                const double u = itm ? fma(sd, invK, -1.0) : 0.0;
+                const float sf = buf[k][v];
+                const bool itm = IS_PUT ? sf < thrk[k] : sf > thrk[k];
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(itm));
+                const double u0 = fma((double)sf, invK, -1.0);
+                const double u = itm ? u0 : 0.0;
                 const double p = itm ? pN[k][v] : 0.0;
                 const double u2 = u * u;
-                cnt += itm ? 1 : 0;
                 acc[1] += u;
                 acc[2] += u2;
                 acc[3] = fma(u2, u, acc[3]);
@@ -328,7 +353,7 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
             }
         }
         const double d = shD[wave][t - t0];
-        acc[0] = (double)cnt;
+        acc[0] = lane == 0 ? (double)cnt : 0.0;
         acc[5] *= d;
         acc[6] *= d;
         acc[7] *= d;
@@ -338,31 +363,36 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     // Three rotating register buffers, rows fetched TWO steps ahead of their use; row indices are
     // clamped to the chunk, so every load is unconditional and the compiler can count them
     // (vmcnt(7..4) in the ISA instead of vmcnt(0)).  Measured (SQ counters):
-    // wave-cycles split 46 % VALU issue stall / 35 % memory wait / 19 % issuing, ~320 VALU
-    // instructions per wave-step, half of them float64 (4 cycles each by tools/ubench.hip).
-    // Neither deeper prefetch nor a 15 % shorter instruction stream moved the time: the kernel
-    // sits where its float64 arithmetic and its HBM reads each cost about the same.
+    // wave-cycles split 46 % VALU issue stall / 35 % memory wait / 19 % issuing.  Loads alone or
+    // arithmetic alone each take ~0.20 ms at C2, together ~0.27 ms; neither a deeper prefetch
+    // nor 15-20 % fewer VALU instructions (float32 threshold compare, scalar popcount) moved it.
     float bufA[TPW][VEC], bufB[TPW][VEC], bufC[TPW][VEC];
     const int tl = t1 - 1;
     // sched_barrier: hipcc otherwise sinks the prefetch loads below the arithmetic they are
     // meant to overlap (seen in the ISA as vmcnt(0) right before the late-issued loads)
-    load_rows(bufA, t0);
-    load_rows(bufB, min(t0 + 1, tl));
-    for (int t = t0; t < t1; t += 3) {
-        load_rows(bufC, min(t + 2, tl));
-        __builtin_amdgcn_sched_barrier(0);
-        process(bufA, t);
-        if (t + 1 < t1) {
-            load_rows(bufA, min(t + 3, tl));
+    auto sweep = [&](auto put_tag) {
+        load_rows(bufA, t0);
+        load_rows(bufB, min(t0 + 1, tl));
+        for (int t = t0; t < t1; t += 3) {
+            load_rows(bufC, min(t + 2, tl));
             __builtin_amdgcn_sched_barrier(0);
-            process(bufB, t + 1);
+            process(put_tag, bufA, t);
+            if (t + 1 < t1) {
+                load_rows(bufA, min(t + 3, tl));
+                __builtin_amdgcn_sched_barrier(0);
+                process(put_tag, bufB, t + 1);
+            }
+            if (t + 2 < t1) {
+                load_rows(bufB, min(t + 4, tl));
+                __builtin_amdgcn_sched_barrier(0);
+                process(put_tag, bufC, t + 2);
+            }
         }
-        if (t + 2 < t1) {
-            load_rows(bufB, min(t + 4, tl));
-            __builtin_amdgcn_sched_barrier(0);
-            process(bufC, t + 2);
-        }
-    }
+    };
+    if (PUT == 1 || (PUT < 0 && is_put))
+        sweep(std::true_type{});
+    else
+        sweep(std::false_type{});
 }
 
 __device__ __forceinline__ void lsm_reduce_pass1_body(const double* __restrict__ part1,

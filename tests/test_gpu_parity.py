@@ -205,6 +205,29 @@ def test_lsm_poly_matches_oracle_same_paths(ctx, M, N, is_put, sem):
     assert np.allclose(out["betas"][big], ref["betas"][big], rtol=1e-6, atol=1e-8)
 
 
+@pytest.mark.parametrize("is_put", [True, False])
+@pytest.mark.parametrize("strike", [100.0, 100.1, 99.99999, 1e-3, 12345.678])
+def test_lsm_in_the_money_set_at_the_strike(ctx, strike, is_put):
+    """Prices sitting exactly on the strike and one float32 ulp either side of it: the in-the-money
+    sets (K - S > 0 / S - K > 0 in float64) must be the oracle's, path for path, in every flow."""
+    rng = np.random.default_rng(5)
+    M, N = 4096, 6
+    kf = np.float32(strike)
+    near = np.array([kf, np.nextafter(kf, np.float32(0)), np.nextafter(kf, np.float32(np.inf)),
+                     np.nextafter(np.nextafter(kf, np.float32(0)), np.float32(0))], dtype=np.float32)
+    So = near[rng.integers(0, 4, size=(N + 1, M))]
+    far = rng.random((N + 1, M)) < 0.5
+    So[far] = (strike * np.exp(0.2 * rng.standard_normal((N + 1, M)))).astype(np.float32)[far]
+    S = ctx.to_device(So)
+    for sem in ("reference", "textbook", "two_pass"):
+        out = ctx.lsm_poly(S, strike, R, T, is_put, sem, want_state=True)
+        ref = orc.lsm_poly(So, strike, R, T, is_put, sem)
+        assert np.array_equal(out["nitm"][1:N], ref["nitm"][1:N]), sem
+        assert np.array_equal(out["tex"], ref["tex"]), sem
+        assert abs(out["price"] - ref["price"]) <= 1e-9 * max(ref["price"], 1e-12), sem
+    S.free()
+
+
 def test_lsm_no_itm_paths_falls_back_to_mean(ctx):
     """deep OTM put: no regression set anywhere -> price = mean terminal payoff = 0
     (options_model_3.py:518-519)."""
