@@ -164,6 +164,29 @@ int omc_heston_price_strikes(omc_ctx* ctx, int64_t n_paths, int n_steps, double 
                              uint64_t seed, uint64_t stream, int scheme, const double* strikes,
                              int n_strikes, int is_put, double* prices, double* stderrs);
 
+/* ---- NN continuation-value regressor: fused training of the network ------------------------ */
+/* replaces the minibatch loop of price_american_enhanced_lsm (options_model_3.py:565-600:
+ * SingleLSMNet(7, hidden, layers) :85-103, nn.MSELoss, optim.Adam(lr, weight_decay), shuffled
+ * minibatches) for the network BASELINE config 5 names, 7 -> 64 -> 64 -> 1 (hidden = 64,
+ * layers = 2; anything else returns -9).  One call = one epoch over `n_rows` rows of
+ * `data` ([n_rows][8] float32 device memory: 7 normalised features + normalised target):
+ * ceil(n_rows / batch) optimizer steps of float32 MFMA forward/backward + Adam.  The epoch
+ * visits the rows in a pseudo-random permutation keyed by `shuffle_key` (a Feistel network with
+ * cycle-walking, evaluated in the kernel: no randperm, no gather; 0 = storage order) --
+ * omc_mlp_shuffle_indices writes that permutation out (out[i] = row visited at position i).
+ * `params` (device, omc_mlp_param_count floats) is laid out W1|b1 as [hidden][8] (bias in
+ * column 7), W2 [hidden][hidden], b2, w3, b3; adam_m / adam_v are the moment buffers (zero
+ * them before the first epoch); *step counts optimizer steps across calls (bias correction).
+ * dropout is applied after each ReLU as in training mode (Philox bits keyed by `seed`).
+ * *mean_loss = mean over the epoch's steps of the batch-mean squared error (the value the
+ * reference feeds to ReduceLROnPlateau and its early-stopping test, :601-613). */
+int omc_mlp_param_count(int hidden, int layers);
+int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t batch, int hidden,
+                        int layers, float* params, float* adam_m, float* adam_v, int64_t* step,
+                        double lr, double beta1, double beta2, double eps, double weight_decay,
+                        double dropout, uint64_t seed, uint64_t shuffle_key, double* mean_loss);
+int omc_mlp_shuffle_indices(omc_ctx* ctx, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device);
+
 /* ---- many small pricings in one go ------------------------------------------------------- */
 /* replaces the curve loops compute_curve_for_S0 (options_model_3.py:697-713, Options_model.py:
  * 190-211, options_model_2.py:336-355) and their ProcessPoolExecutor fan-out: n independent

@@ -76,6 +76,10 @@ SIGNATURES = {
     "omc_heston_price_strikes": (C.c_int, [_P, _I64, _I] + [_D] * 8 + [_U64, _U64, _I, _P, _I, _I, _P, _P]),
     "omc_price_american_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_price_european_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
+    "omc_mlp_param_count": (C.c_int, [_I, _I]),
+    "omc_mlp_train_epoch": (C.c_int, [_P, _P, _I64, _I64, _I, _I, _P, _P, _P, C.POINTER(C.c_int64)]
+                            + [_D] * 6 + [_U64, _U64, C.POINTER(C.c_double)]),
+    "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
 }
 
 _lib = None
@@ -364,6 +368,22 @@ class Context:
             int(stream), int(scheme), k.ctypes.data, k.size, int(is_put), prices.ctypes.data,
             errs.ctypes.data))
         return prices, errs
+
+    def mlp_train_epoch(self, data_ptr, n_rows, batch, params_ptr, m_ptr, v_ptr, step, lr, dropout, seed,
+                        hidden=64, layers=2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5,
+                        shuffle_key=0):
+        """One epoch of the fused 7->64->64->1 trainer on device pointers -> (mean loss, new step).
+        shuffle_key != 0: rows are visited in the keyed pseudo-random permutation."""
+        st = C.c_int64(int(step))
+        loss = C.c_double(0.0)
+        _check(self.lib, self.lib.omc_mlp_train_epoch(
+            self.handle, int(data_ptr), int(n_rows), int(batch), int(hidden), int(layers), int(params_ptr),
+            int(m_ptr), int(v_ptr), C.byref(st), float(lr), float(beta1), float(beta2), float(eps),
+            float(weight_decay), float(dropout), int(seed), int(shuffle_key), C.byref(loss)))
+        return loss.value, st.value
+
+    def mlp_shuffle_indices(self, n_rows, shuffle_key, out_ptr):
+        _check(self.lib, self.lib.omc_mlp_shuffle_indices(self.handle, int(n_rows), int(shuffle_key), int(out_ptr)))
 
     # -- many small pricings as one set of launches (all share model/semantics/antithetic)
     MAX_BATCH = 65535

@@ -72,6 +72,7 @@ struct omc_ctx {
     bool own_stream = false;
     DevBuf S, sx, tex, D, part, gmom, betas, part1, result, scratch;
     DevBuf bslab, btable, bres, bdisc;  // batched path: problem slab, table, results, discounts
+    DevBuf mlp_part, mlp_loss;          // NN training: gradient partials, epoch loss
     std::vector<char> h_table;
     std::vector<double> h_disc, h_bres;
     std::vector<double> hD;
@@ -287,7 +288,8 @@ int omc_ctx_destroy(omc_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
-                      &c->result, &c->scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc})
+                      &c->result, &c->scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc, &c->mlp_part,
+                      &c->mlp_loss})
         b->release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -744,6 +746,53 @@ int omc_price_american_batch(omc_ctx* c, const omc_params* p, int n, omc_result*
 int omc_price_european_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res)
 {
     return run_batch(c, p, n, res, false);
+}
+
+int omc_mlp_param_count(int hidden, int layers)
+{
+    return (hidden == 64 && layers == 2) ? omc::kMlpParams : -1;
+}
+
+int omc_mlp_shuffle_indices(omc_ctx* c, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (n_rows <= 0 || !out_device) return fail(-3, "n_rows must be positive, out non-null.");
+    HIP_TRY(omc::mlp_shuffle_indices(c->stream, n_rows, shuffle_key, out_device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t batch, int hidden,
+                        int layers, float* params, float* adam_m, float* adam_v, int64_t* step,
+                        double lr, double beta1, double beta2, double eps, double weight_decay,
+                        double dropout, uint64_t seed, uint64_t shuffle_key, double* mean_loss)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (omc_mlp_param_count(hidden, layers) < 0)
+        return fail(-9, "the fused trainer supports hidden = 64, layers = 2 only.");
+    if (!data || !params || !adam_m || !adam_v || !step || !mean_loss) return fail(-7, "null pointer.");
+    if (n_rows <= 0 || batch <= 0 || *step < 0) return fail(-3, "n_rows, batch must be positive.");
+    if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
+    if (!(lr > 0.0)) return fail(-4, "learning rate must be positive.");
+    if ((rc = c->mlp_part.ensure(omc::mlp_partial_bytes()))) return rc;
+    if ((rc = c->mlp_loss.ensure(sizeof(double)))) return rc;
+    HIP_TRY(hipMemsetAsync(c->mlp_loss.p, 0, sizeof(double), c->stream));
+    omc::MlpTrainPlan t;
+    t.data = data; t.params = params; t.adam_m = adam_m; t.adam_v = adam_v;
+    t.partial = (float*)c->mlp_part.p; t.loss_acc = (double*)c->mlp_loss.p;
+    t.nrows = n_rows; t.batch = batch; t.first_step = *step;
+    t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.weight_decay = weight_decay;
+    t.dropout = dropout; t.seed = seed; t.shuffle_key = shuffle_key;
+    HIP_TRY(omc::mlp_train_steps(c->stream, t));
+    double acc = 0.0;
+    HIP_TRY(hipMemcpyAsync(&acc, c->mlp_loss.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t nb = (n_rows + batch - 1) / batch;
+    *step += nb;
+    *mean_loss = acc / (double)nb;
+    return 0;
 }
 
 }  // extern "C"

@@ -90,4 +90,26 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
 // valuation of (sx,tex): sums into w.result ; tval = 1 (reference flows) or 0 (textbook)
 hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval);
 
+// ---- continuation-value network of the NN flow (omc_mlp.hip): 7 -> 64 -> 64 -> 1
+constexpr int kMlpParams = 64 * 8 + 64 * 64 + 64 + 64 + 1;  // W1|b1 [64][8], W2 [64][64], b2, w3, b3
+constexpr int kMlpPartialStride = 4800;                    // >= kMlpParams + 1 (loss slot)
+constexpr int kMlpMaxGroups = 256;                         // one workgroup per CU
+struct MlpTrainPlan {
+    const float* data;  // [nrows][8] float32: 7 inputs + target
+    float* params;      // [kMlpParams], updated in place
+    float* adam_m;
+    float* adam_v;
+    float* partial;     // mlp_partial_bytes()
+    double* loss_acc;   // += batch-mean loss of every step
+    int64_t nrows, batch, first_step;  // optimizer steps taken before this call
+    double lr, beta1, beta2, eps, weight_decay, dropout;
+    uint64_t seed;         // dropout bits
+    uint64_t shuffle_key;  // 0: rows in storage order; else a keyed pseudo-random permutation
+};
+size_t mlp_partial_bytes();
+// the permutation the trainer walks (for tests): out[i] = stored row visited at epoch position i
+hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out);
+// one epoch: ceil(nrows / batch) optimizer steps (forward+backward kernel, reduce+Adam kernel)
+hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t);
+
 }  // namespace omc

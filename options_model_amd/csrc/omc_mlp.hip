@@ -1,0 +1,505 @@
+// omc_mlp.hip -- the continuation-value network of the NN flow as
+// hand-written gfx950 kernels: one fused forward + backward pass of the 7 -> 64 -> 64 -> 1 MLP
+// (Linear/ReLU/Dropout stacks of SingleLSMNet, options_model_3.py:85-103) over a minibatch, and
+// the gradient reduce + Adam update (options_model_3.py:565-600: Adam, weight decay, MSE).
+//
+// The minibatch GEMMs run on the matrix cores in float32 (v_mfma_f32_32x32x2_f32; the reference
+// trains in float32).  Everything is kept TRANSPOSED -- activations are [hidden][row] -- so that
+// the accumulator layout of one layer (lane <-> batch row, registers <-> hidden units) is
+// directly the B operand of the next layer's MFMA: the k-index of a matrix product may be
+// walked in any order as long as A and B agree, and the order chosen here is the one the
+// accumulator registers already have.  Only the weight-gradient products, which contract over
+// the batch rows, need the operands turned around; they go through a wave-private LDS patch.
+//
+// One wave owns a tile of 32 batch rows from load to weight gradients; a workgroup (4 waves,
+// one per SIMD, up to 512 registers each) shares the weights in LDS.  Gradients accumulate in
+// registers over all tiles of a wave, are summed over the workgroup in a fixed order and
+// written as one partial per workgroup; the Adam kernel sums the partials in index order.
+// No atomics: a training run is bitwise reproducible.
+#include "omc_device.h"
+#include "omc_kernels.h"
+
+namespace omc {
+
+namespace {
+
+constexpr int kH = 64;                 // hidden width
+constexpr int kOW1 = 0;                // [64][8]: 7 feature weights + bias in column 7
+constexpr int kOW2 = kOW1 + kH * 8;    // [64][64]
+constexpr int kOB2 = kOW2 + kH * kH;   // [64]
+constexpr int kOW3 = kOB2 + kH;        // [64]
+constexpr int kOB3 = kOW3 + kH;        // [1]
+static_assert(kOB3 + 1 == kMlpParams, "parameter layout");
+
+constexpr int kLdW1 = 9, kLdW2 = 65;   // LDS leading dimensions (odd: conflict-free column walks)
+constexpr int kLdT = 36;               // staging [unit][row]: 32 rows + pad, 16-byte aligned rows
+constexpr int kLdsWeights = kH * kLdW1 + kH * kLdW2 + kH + kH + 4;
+constexpr int kLdsWave = 2 * kH * kLdT + 8 * kLdT;
+constexpr int kLdsFloats = kLdsWeights + 4 * kLdsWave;
+static_assert(kLdsWave >= kMlpParams, "the workgroup gradient buffer aliases one staging patch");
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// hidden unit held by accumulator register r of 32x32 tile mt in half-wave h
+__device__ __forceinline__ int unit_of(int mt, int r, int h) { return 32 * mt + (r >> 2) * 8 + 4 * h + (r & 3); }
+
+__device__ __forceinline__ v16f mfma(float a, float b, v16f c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ReLU + inverted dropout on one layer's pre-activations (32 per lane), in place.
+// One Philox block per (row, half-wave, layer, step) seeds two multiply-with-carry streams
+// (x <- a * lo32(x) + hi32(x): one v_mad_u64_u32 per 32 bits); 16 bits per unit, kept if
+// below keep16.
+__device__ __forceinline__ void relu_dropout(v16f (&z)[2], uint32_t row, uint32_t step, uint32_t tag,
+                                             uint32_t keep16, float inv_keep, uint32_t k0, uint32_t k1)
+{
+    if (keep16 >= 65536u) {  // no dropout (uniform branch)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[mt][r] = fmaxf(z[mt][r], 0.0f);
+        return;
+    }
+    const U4 o = philox4x32_10(row, step, tag, 0x4d4c5031u, k0, k1);
+    uint64_t st[2] = {((uint64_t)o.x << 32) | (o.y | 1u), ((uint64_t)o.z << 32) | (o.w | 1u)};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            st[mt] = (uint64_t)4294957665u * (uint32_t)st[mt] + (st[mt] >> 32);
+            const uint32_t w = (uint32_t)st[mt];
+            const float v0 = z[mt][e], v1 = z[mt][e + 1];
+            z[mt][e] = (v0 > 0.0f && (w & 0xffffu) < keep16) ? v0 * inv_keep : 0.0f;
+            z[mt][e + 1] = (v1 > 0.0f && (w >> 16) < keep16) ? v1 * inv_keep : 0.0f;
+        }
+    }
+}
+
+// Pseudo-random permutation of [0, n): a 4-round Feistel network on ceil(log2 n) bits (the two
+// halves may differ by one bit; an even number of rounds restores their order) with
+// cycle-walking back into range.  Replaces randperm + gather: the kernel reads row perm(i).
+struct Shuffle {
+    uint64_t n;
+    uint32_t abits, bbits;  // left / right half widths, abits + bbits = ceil(log2 n) (>= 2)
+    uint32_t key[4];
+    int on;
+};
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t shuffle_index(const Shuffle& s, uint64_t i)
+{
+    if (!s.on) return i;
+    const uint32_t ma = (1u << s.abits) - 1u, mb = (1u << s.bbits) - 1u;  // widths <= 31
+    do {
+        uint32_t L = (uint32_t)(i >> s.bbits) & ma, R = (uint32_t)i & mb;
+        // (L:a, R:b) -> (R:b, L ^ F(R):a) -> ... ; after 4 rounds the widths are (a, b) again
+        uint32_t t;
+        t = L ^ (mix32(R ^ s.key[0]) & ma); L = R; R = t;  // now L:b R:a
+        t = L ^ (mix32(R ^ s.key[1]) & mb); L = R; R = t;  // now L:a R:b
+        t = L ^ (mix32(R ^ s.key[2]) & ma); L = R; R = t;
+        t = L ^ (mix32(R ^ s.key[3]) & mb); L = R; R = t;
+        i = ((uint64_t)L << s.bbits) | R;
+    } while (i >= s.n);
+    return i;
+}
+
+struct MlpTrainArgs {
+    const float* data;    // [n][8]: 7 normalised features + normalised target (the whole epoch)
+    const float* params;  // [kMlpParams]
+    float* partial;       // [gridDim.x][kMlpPartialStride]: gradient sums + batch loss
+    int64_t row0, nrows;  // this step's minibatch = epoch positions row0 .. row0 + nrows
+    Shuffle shuf;         // epoch position -> stored row
+    int ntiles;
+    float two_over_b, inv_keep;
+    uint32_t keep16, step, k0, k1;
+};
+
+__global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
+{
+    extern __shared__ float lds[];
+    float* sW1 = lds;
+    float* sW2 = sW1 + kH * kLdW1;
+    float* sB2 = sW2 + kH * kLdW2;
+    float* sW3 = sB2 + kH;
+    float* sB3 = sW3 + kH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+    float* tH1 = lds + kLdsWeights + wave * kLdsWave;
+    float* tDZ = tH1 + kH * kLdT;
+    float* tX = tDZ + kH * kLdT;
+
+    for (int i = tid; i < kH * 8; i += 256) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[kOW1 + i];
+    for (int i = tid; i < kH * kH; i += 256) sW2[(i >> 6) * kLdW2 + (i & 63)] = a.params[kOW2 + i];
+    if (tid < kH) {
+        sB2[tid] = a.params[kOB2 + tid];
+        sW3[tid] = a.params[kOW3 + tid];
+    }
+    if (tid == 0) sB3[0] = a.params[kOB3];
+    __syncthreads();
+
+    v16f gW2[2][2], gW1[2], gw3[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gW2[i][0][r] = 0.0f;
+            gW2[i][1][r] = 0.0f;
+            gW1[i][r] = 0.0f;
+            gw3[i][r] = 0.0f;
+        }
+    }
+    float gb2[2] = {0.0f, 0.0f}, gb3 = 0.0f, loss = 0.0f;
+
+    const int nwaves = gridDim.x * 4;
+    auto fetch = [&](int tile) {
+        const int64_t r = (int64_t)tile * 32 + c;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (tile < a.ntiles && r < a.nrows)
+            v = reinterpret_cast<const float4*>(a.data + shuffle_index(a.shuf, (uint64_t)(a.row0 + r)) * 8)[h];
+        return v;
+    };
+    float4 xnext = fetch(blockIdx.x * 4 + wave);
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += nwaves) {
+        const int64_t row = (int64_t)tile * 32 + c;
+        const bool live = row < a.nrows;
+        float4 x = xnext;
+        xnext = fetch(tile + nwaves);  // in flight while this tile is computed
+        float y = x.w;                 // upper half-wave: column 7 is the target ...
+        if (h == 1) x.w = 1.0f;        // ... and its slot carries the bias input
+        y = __shfl(y, c + 32, 64);
+        wave_sync_lds();               // the previous tile's staging reads are done
+        tX[(4 * h + 0) * kLdT + c] = x.x;
+        tX[(4 * h + 1) * kLdT + c] = x.y;
+        tX[(4 * h + 2) * kLdT + c] = x.z;
+        tX[(4 * h + 3) * kLdT + c] = x.w;
+
+        // ---- layer 1: Z1^T [64 x 32] = W1a [64 x 8] * Xa^T [8 x 32]; k-step s <-> inputs s, s+4
+        v16f h1[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[mt][r] = 0.0f;
+            const float* wr = sW1 + (32 * mt + c) * kLdW1 + 4 * h;
+            h1[mt] = mfma(wr[0], x.x, h1[mt]);
+            h1[mt] = mfma(wr[1], x.y, h1[mt]);
+            h1[mt] = mfma(wr[2], x.z, h1[mt]);
+            h1[mt] = mfma(wr[3], x.w, h1[mt]);
+        }
+        relu_dropout(h1, (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tH1[unit_of(mt, r, h) * kLdT + c] = h1[mt][r];
+
+        // ---- layer 2: Z2^T = W2 * H1^T + b2; k-step (kt, s) <-> hidden units unit_of(kt, s, h)
+        v16f h2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[mt][r] = sB2[unit_of(mt, r, h)];
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = unit_of(kt, s, h);
+                h2[0] = mfma(sW2[(c)*kLdW2 + k], h1[kt][s], h2[0]);
+                h2[1] = mfma(sW2[(32 + c) * kLdW2 + k], h1[kt][s], h2[1]);
+            }
+        }
+        relu_dropout(h2, (uint32_t)row, a.step, 0x200u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
+
+        // ---- output, loss, d(loss)/d(out)
+        float o = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o = __builtin_fmaf(sW3[unit_of(mt, r, h)], h2[mt][r], o);
+        o += __shfl_xor(o, 32, 64);
+        o += sB3[0];
+        const float diff = live ? o - y : 0.0f;
+        const float dout = diff * a.two_over_b;
+        if (h == 0) {
+            loss = __builtin_fmaf(diff, diff, loss);
+            gb3 += dout;
+        }
+        // ---- back through layer 2's activation; h2 becomes dZ2
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float act = h2[mt][r];
+                gw3[mt][r] = __builtin_fmaf(dout, act, gw3[mt][r]);
+                const float dz = act > 0.0f ? sW3[unit_of(mt, r, h)] * dout * a.inv_keep : 0.0f;
+                h2[mt][r] = dz;
+                tDZ[unit_of(mt, r, h) * kLdT + c] = dz;
+            }
+        }
+        wave_sync_lds();
+
+        // ---- gW2 [i][k] += sum_rows dZ2[i][row] * H1[k][row]; k-step <-> rows 16h + 4q + j
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a0 = *reinterpret_cast<const float4*>(tDZ + (c)*kLdT + 16 * h + 4 * q);
+            const float4 a1 = *reinterpret_cast<const float4*>(tDZ + (32 + c) * kLdT + 16 * h + 4 * q);
+            const float4 b0 = *reinterpret_cast<const float4*>(tH1 + (c)*kLdT + 16 * h + 4 * q);
+            const float4 b1 = *reinterpret_cast<const float4*>(tH1 + (32 + c) * kLdT + 16 * h + 4 * q);
+            gb2[0] += (a0.x + a0.y) + (a0.z + a0.w);
+            gb2[1] += (a1.x + a1.y) + (a1.z + a1.w);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gW2[0][0] = mfma(av0[j], bv0[j], gW2[0][0]);
+                gW2[0][1] = mfma(av0[j], bv1[j], gW2[0][1]);
+                gW2[1][0] = mfma(av1[j], bv0[j], gW2[1][0]);
+                gW2[1][1] = mfma(av1[j], bv1[j], gW2[1][1]);
+            }
+        }
+
+        // ---- dH1^T = W2^T * dZ2^T, then through layer 1's activation
+        v16f d1[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[mt][r] = 0.0f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float* wr = sW2 + unit_of(it, s, h) * kLdW2 + c;
+                d1[0] = mfma(wr[0], h2[it][s], d1[0]);
+                d1[1] = mfma(wr[32], h2[it][s], d1[1]);
+            }
+        }
+        wave_sync_lds();  // gW2's reads of tDZ are done
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tDZ[unit_of(mt, r, h) * kLdT + c] = h1[mt][r] > 0.0f ? d1[mt][r] * a.inv_keep : 0.0f;
+        wave_sync_lds();
+
+        // ---- gW1a [i][n] += sum_rows dZ1[i][row] * Xa[n][row]; only columns n < 8 exist
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a0 = *reinterpret_cast<const float4*>(tDZ + (c)*kLdT + 16 * h + 4 * q);
+            const float4 a1 = *reinterpret_cast<const float4*>(tDZ + (32 + c) * kLdT + 16 * h + 4 * q);
+            float4 b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (c < 8) b = *reinterpret_cast<const float4*>(tX + c * kLdT + 16 * h + 4 * q);
+            gW1[0] = mfma(a0.x, b.x, gW1[0]);
+            gW1[1] = mfma(a1.x, b.x, gW1[1]);
+            gW1[0] = mfma(a0.y, b.y, gW1[0]);
+            gW1[1] = mfma(a1.y, b.y, gW1[1]);
+            gW1[0] = mfma(a0.z, b.z, gW1[0]);
+            gW1[1] = mfma(a1.z, b.z, gW1[1]);
+            gW1[0] = mfma(a0.w, b.w, gW1[0]);
+            gW1[1] = mfma(a1.w, b.w, gW1[1]);
+        }
+    }
+
+    // ---- per-lane partials -> per-wave sums
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = gw3[mt][r];
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+            gw3[mt][r] = v;
+        }
+        gb2[mt] += __shfl_xor(gb2[mt], 32, 64);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        gb3 += __shfl_xor(gb3, m, 64);
+        loss += __shfl_xor(loss, m, 64);
+    }
+
+    // ---- workgroup sum in wave order through LDS (aliases wave 0's staging patch), then out
+    float* G = lds + kLdsWeights;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            const bool first = (w == 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = unit_of(mi, r, h);
+                    float* g0 = G + kOW2 + i * kH + c;
+                    g0[0] = (first ? 0.0f : g0[0]) + gW2[mi][0][r];
+                    g0[32] = (first ? 0.0f : g0[32]) + gW2[mi][1][r];
+                    if (c < 8) {
+                        float* g1 = G + kOW1 + i * 8 + c;
+                        *g1 = (first ? 0.0f : *g1) + gW1[mi][r];
+                    }
+                    if (c == 0) {
+                        float* g3 = G + kOW3 + i;
+                        *g3 = (first ? 0.0f : *g3) + gw3[mi][r];
+                    }
+                }
+                if (h == 0) {
+                    float* gb = G + kOB2 + 32 * mi + c;
+                    *gb = (first ? 0.0f : *gb) + gb2[mi];
+                }
+            }
+            if (lane == 0) {
+                G[kOB3] = (first ? 0.0f : G[kOB3]) + gb3;
+                G[kMlpParams] = (first ? 0.0f : G[kMlpParams]) + loss;
+            }
+        }
+        __syncthreads();
+    }
+    float* out = a.partial + (size_t)blockIdx.x * kMlpPartialStride;
+    for (int i = tid; i <= kMlpParams; i += 256) out[i] = G[i];
+}
+
+struct MlpAdamArgs {
+    float* params;
+    float* m;
+    float* v;
+    const float* partial;
+    double* loss_acc;  // running sum of batch-mean losses of the epoch
+    int nparts;
+    float inv_b, lr_t, inv_sqrt_bc2, beta1, beta2, eps, wd;
+};
+
+// 16 parameters per workgroup, 16 threads per parameter: thread (slice, j) sums partials
+// slice, slice + 16, ... of parameter j (independent loads, all in flight together), the 16 slice
+// sums are added in slice order through LDS, thread (0, j) applies Adam.
+__global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a)
+{
+    __shared__ float red[16][17];
+    const int j = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int p = blockIdx.x * 16 + j;
+    float g = 0.0f;
+    if (p <= kMlpParams) {
+#pragma unroll 16
+        for (int w = slice; w < a.nparts; w += 16) g += a.partial[(size_t)w * kMlpPartialStride + p];
+    }
+    red[slice][j] = g;
+    __syncthreads();
+    if (slice != 0 || p > kMlpParams) return;
+    g = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) g += red[s2][j];
+    if (p == kMlpParams) {  // the loss slot
+        *a.loss_acc += (double)g * (double)a.inv_b;
+        return;
+    }
+    const float w0 = a.params[p];
+    g = __builtin_fmaf(a.wd, w0, g);
+    const float m = __builtin_fmaf(a.beta1, a.m[p], (1.0f - a.beta1) * g);
+    const float v = __builtin_fmaf(a.beta2, a.v[p], (1.0f - a.beta2) * g * g);
+    a.m[p] = m;
+    a.v[p] = v;
+    const float denom = __builtin_amdgcn_sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    a.params[p] = w0 - a.lr_t * (m / denom);
+}
+
+Shuffle make_shuffle(int64_t n, uint64_t key)
+{
+    Shuffle sh;
+    sh.n = (uint64_t)n;
+    sh.on = (key != 0 && n > 1) ? 1 : 0;
+    uint32_t bits = 2;
+    while (bits < 62 && (1ull << bits) < sh.n) ++bits;
+    sh.abits = bits / 2;
+    sh.bbits = bits - sh.abits;
+    for (int i = 0; i < 4; ++i) {  // splitmix64 of the key -> round keys
+        uint64_t z = key + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        sh.key[i] = (uint32_t)((z ^ (z >> 31)) >> 16);
+    }
+    return sh;
+}
+
+__global__ __launch_bounds__(256) void mlp_shuffle_kernel(Shuffle s, int64_t* out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < s.n) out[i] = (int64_t)shuffle_index(s, i);
+}
+
+}  // namespace
+
+size_t mlp_partial_bytes() { return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride; }
+
+hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mlp_shuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       make_shuffle(n, shuffle_key), out);
+    return hipGetLastError();
+}
+
+hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
+{
+    static bool attr_set = false;
+    const size_t lds_bytes = sizeof(float) * (size_t)kLdsFloats;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
+    int64_t step = t.first_step;
+    for (int64_t o = 0; o < t.nrows; o += t.batch) {
+        const int64_t nb = (t.nrows - o < t.batch) ? t.nrows - o : t.batch;
+        ++step;
+        MlpTrainArgs a;
+        a.data = t.data;
+        a.params = t.params;
+        a.partial = t.partial;
+        a.row0 = o;
+        a.nrows = nb;
+        a.shuf = sh;
+        a.ntiles = (int)((nb + 31) / 32);
+        a.two_over_b = (float)(2.0 / (double)nb);
+        a.keep16 = t.dropout > 0.0 ? (uint32_t)llround((1.0 - t.dropout) * 65536.0) : 65536u;
+        a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
+        a.step = (uint32_t)step;
+        a.k0 = (uint32_t)t.seed;
+        a.k1 = (uint32_t)(t.seed >> 32);
+        int groups = (a.ntiles + 3) / 4;
+        if (groups > kMlpMaxGroups) groups = kMlpMaxGroups;
+        hipLaunchKernelGGL(mlp_train_kernel, dim3(groups), dim3(256), lds_bytes, st, a);
+        MlpAdamArgs b;
+        b.params = t.params;
+        b.m = t.adam_m;
+        b.v = t.adam_v;
+        b.partial = t.partial;
+        b.loss_acc = t.loss_acc;
+        b.nparts = groups;
+        b.inv_b = (float)(1.0 / (double)nb);
+        const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
+        b.lr_t = (float)(t.lr / bc1);
+        b.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        b.beta1 = (float)t.beta1;
+        b.beta2 = (float)t.beta2;
+        b.eps = (float)t.eps;
+        b.wd = (float)t.weight_decay;
+        hipLaunchKernelGGL(mlp_adam_kernel, dim3((kMlpParams + 16) / 16), dim3(256), 0, st, b);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace omc

@@ -1,8 +1,10 @@
 """NN continuation-value regressor (BASELINE config 5): the reference's own v3 scheme --
 ONE global MLP on 7 features, trained on every in-the-money (t, path) of pass 1, then a sticky
-pass 2 -- run on the MI355X.  This is the only part of the product that uses PyTorch-ROCm
-(north_star: "PyTorch-ROCm only for the optional NN continuation-value regressor"); paths still
-come from the hand-written HIP kernels, written straight into the torch tensor.
+pass 2 -- run on the MI355X.  Paths come from the hand-written HIP kernels, written straight
+into the torch tensor; the network BASELINE config 5 names (7 -> 64 -> 64 -> 1) is trained by the
+library's own fused MFMA forward/backward + Adam kernels (omc_mlp_train_epoch, csrc/omc_mlp.hip);
+PyTorch-ROCm holds the tensors, builds the rows and trains any other SingleLSMNet shape
+(north_star: "PyTorch-ROCm only for the optional NN continuation-value regressor").
 
 Reference lines mirrored (options_model_3/options_model_3.py):
     SingleLSMNet                         :85-103   (Linear/ReLU/Dropout stacks, 3 hidden layers)
@@ -20,7 +22,9 @@ Deviations, all forced by scale and stated in the result dict:
     the same thing with 512..8192, option_model_3_gpu.py:751-755).  At config 5, R ~ 1.15e8.
   * pass 2 evaluates the net densely on all M paths per step and masks, instead of gathering
     the active subset: no host sync inside the time loop.
-  * torch's GPU generator replaces the CPU generator: same distributions, different streams.
+  * torch's GPU generator replaces the CPU generator: same distributions, different streams;
+    the fused trainer shuffles each epoch with a keyed Feistel permutation evaluated in the
+    kernel (instead of randperm + gather) and draws its dropout bits from Philox-seeded streams.
 """
 from __future__ import annotations
 
@@ -212,15 +216,102 @@ class _GraphedStep:
         return self._eager(batch)
 
 
+def fused_trainer_supports(net):
+    """The hand-written trainer (omc_mlp_train_epoch) covers the network BASELINE config 5
+    names: 7 -> 64 -> 64 -> 1."""
+    torch = _torch()
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    return [(m.in_features, m.out_features) for m in lin] == [(7, 64), (64, 64), (64, 1)]
+
+
+def flatten_params(net):
+    """torch SingleLSMNet(7, 64, 2) -> the library's flat float32 layout: W1|b1 as [64][8] (bias
+    in column 7), W2 [64][64], b2 [64], w3 [64], b3 [1] (include/omc.h, omc_mlp_train_epoch)."""
+    torch = _torch()
+    l1, l2, l3 = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        return torch.cat([torch.cat([l1.weight, l1.bias[:, None]], dim=1).reshape(-1), l2.weight.reshape(-1),
+                          l2.bias, l3.weight.reshape(-1), l3.bias]).float().contiguous()
+
+
+def unflatten_params(net, flat):
+    torch = _torch()
+    l1, l2, l3 = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        w1 = flat[:512].view(64, 8)
+        l1.weight.copy_(w1[:, :7])
+        l1.bias.copy_(w1[:, 7])
+        l2.weight.copy_(flat[512:4608].view(64, 64))
+        l2.bias.copy_(flat[4608:4672])
+        l3.weight.copy_(flat[4672:4736].view(1, 64))
+        l3.bias.copy_(flat[4736:4737])
+
+
+def _dropout_of(net):
+    torch = _torch()
+    ps = [m.p for m in net.net if isinstance(m, torch.nn.Dropout)]
+    return float(ps[0]) if ps else 0.0
+
+
+def _train_fused(net, data, epochs, lr, bs, verbose):
+    """The epoch loop of :565-613 around omc_mlp_train_epoch (hand-written MFMA forward/backward +
+    Adam kernels); shuffling, the plateau scheduler and early stopping stay on the host side."""
+    torch = _torch()
+    dev = data.device
+    R = data.shape[0]
+    ctx = _ctx_on_torch_stream(dev.index or 0)
+    params = flatten_params(net)
+    m = torch.zeros_like(params)
+    v = torch.zeros_like(params)
+    holder = torch.zeros(1, requires_grad=True)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(torch.optim.SGD([holder], lr=float(lr)), patience=5,
+                                                       factor=0.5, min_lr=1e-6)
+    p_drop = _dropout_of(net)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # drawn from torch's seeded generator
+    best, best_params, bad, step = float("inf"), None, 0, 0
+    t_kernels = 0.0
+    torch.cuda.current_stream(dev).synchronize()  # the training matrix is complete
+    for epoch in range(epochs):
+        t1 = time.perf_counter()
+        # the epoch's shuffle (:575 randperm) is a keyed permutation evaluated inside the kernel
+        avg, step = ctx.mlp_train_epoch(data.data_ptr(), R, bs, params.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                        step, sched.optimizer.param_groups[0]["lr"], p_drop, seed,
+                                        shuffle_key=(seed ^ (0x9E3779B97F4A7C15 * (epoch + 1))) % (1 << 64) or 1)
+        t_kernels += time.perf_counter() - t1
+        sched.step(avg)
+        if avg < best - 1e-6:
+            best, best_params, bad = avg, params.clone(), 0
+        else:
+            bad += 1
+            if bad >= 8:
+                if verbose:
+                    print(f"Early stopping at epoch {epoch + 1}, restoring best weights")
+                break
+    unflatten_params(net, best_params if best_params is not None else params)
+    return dict(batch=bs, optimizer_steps=step, epochs_run=epoch + 1, best_loss=best, graphed=False,
+                trainer="hip", seconds_train_kernels=t_kernels)
+
+
 def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbose=False,
-          use_graph=True):
+          use_graph=True, trainer="auto"):
     """:565-613: Adam(lr, wd 1e-5), MSE, shuffled minibatches, ReduceLROnPlateau on the epoch-mean
-    loss, early stop after 8 non-improving epochs, best-weights restore."""
+    loss, early stop after 8 non-improving epochs, best-weights restore.
+    trainer: "hip" = the library's fused MFMA kernels (7->64->64->1 only), "torch" = PyTorch-ROCm
+    autograd (any SingleLSMNet shape), "auto" = hip where it applies."""
     torch = _torch()
     R = x.numel()
     bs = pick_batch(R, nn_batch)
     dev = x.device
+    t_m = time.perf_counter()
     data = build_training_matrix(x, t, y, fm, fs, ym, ysd, T, dt)
+    torch.cuda.synchronize(dev)
+    t_m = time.perf_counter() - t_m
+    if trainer not in ("auto", "hip", "torch"):
+        raise ValueError("trainer must be 'auto', 'hip' or 'torch'")
+    if trainer == "hip" and not fused_trainer_supports(net):
+        raise ValueError("trainer='hip' covers SingleLSMNet(7, 64, 2) only")
+    if trainer != "torch" and fused_trainer_supports(net):
+        return dict(_train_fused(net, data, epochs, lr, bs, verbose), seconds_matrix=t_m)
     # state snapshots for the warm-up steps of the graph capture must not leak into training
     init_state = copy.deepcopy(net.state_dict())
     lr_t = torch.tensor(float(lr), dtype=torch.float32, device=dev)
@@ -270,7 +361,8 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
                 break
     if best_state is not None:
         net.load_state_dict(best_state)
-    return dict(batch=bs, optimizer_steps=steps, epochs_run=epoch + 1, best_loss=best, graphed=graphed)
+    return dict(batch=bs, optimizer_steps=steps, epochs_run=epoch + 1, best_loss=best, graphed=graphed,
+                trainer="torch", seconds_matrix=t_m)
 
 
 def pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, path_chunk=1 << 20):
@@ -302,7 +394,8 @@ def pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, path_chunk=
 
 
 def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3, nn_dropout=0.1,
-                     nn_epochs=25, nn_lr=1e-3, nn_batch=None, inference_dropout=True, verbose=False):
+                     nn_epochs=25, nn_lr=1e-3, nn_batch=None, inference_dropout=True, verbose=False,
+                     trainer="auto"):
     """The whole v3 NN flow on a device path matrix S (torch float32 [N+1, M])."""
     torch = _torch()
     N, M = S.shape[0] - 1, S.shape[1]
@@ -315,10 +408,13 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
         cf = payT * math.exp(-r * dt * (N - 1))
         return dict(price=float(cf.mean()), R=0, n_paths=M, n_exercised=0)
     x, t, y, _ = rows
+    torch.cuda.synchronize(S.device)
+    t_c = time.perf_counter()
     fm, fs, ym, ysd = normalisers(x, t, y, T, dt)
     net = make_net(7, nn_hidden, nn_layers, nn_dropout).to(S.device)
+    torch.cuda.synchronize(S.device)
     t1 = time.perf_counter()
-    info = train(net, x, t, y, fm, fs, ym, ysd, T, dt, nn_epochs, nn_lr, nn_batch, verbose)
+    info = train(net, x, t, y, fm, fs, ym, ysd, T, dt, nn_epochs, nn_lr, nn_batch, verbose, trainer=trainer)
     torch.cuda.synchronize(S.device)
     t2 = time.perf_counter()
     cf, ex = pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
@@ -327,7 +423,8 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
     var = float(((cf - price) ** 2).mean())
     info.update(price=price, std=math.sqrt(var), stderr=math.sqrt(var / M), R=int(x.numel()), n_paths=M,
                 n_exercised=int(ex.sum()), zero_prob=float((cf == 0).double().mean()),
-                Y_mean=float(ym), Y_std=float(ysd), seconds_collect=t1 - t0, seconds_train=t2 - t1,
+                Y_mean=float(ym), Y_std=float(ysd), seconds_collect=t_c - t0, seconds_normalise=t1 - t_c,
+                seconds_train=t2 - t1,
                 seconds_pass2=t3 - t2, net=net, feat_mean=fm, feat_std=fs)
     return info
 
@@ -351,7 +448,7 @@ def price_two_pass_nn(pricer, S0, T, M, N, path_seed, torch_seed):
 def price_american_option_nn(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", option_type="put",
                              heston_params=None, seed=42, stream=0, device=0, nn_hidden=64,
                              nn_layers=2, nn_dropout=0.1, nn_epochs=25, nn_lr=1e-3, nn_batch=None,
-                             inference_dropout=True):
+                             inference_dropout=True, nn_trainer="auto"):
     """Facade backend for regressor='nn' (BASELINE config 5 names a 2x64 MLP)."""
     from .api import PriceResult, _validate
     torch = _torch()
@@ -365,7 +462,7 @@ def price_american_option_nn(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", 
         S = torch.empty((int(n_steps) + 1, M), dtype=torch.float32, device=dev)
         generate_paths(ctx, S, kw, S0, r, sigma or 0.0, T, seed, stream)
         out = price_with_paths(S, K, r, T, option_type == "put", seed + 1, nn_hidden, nn_layers,
-                               nn_dropout, nn_epochs, nn_lr, nn_batch, inference_dropout)
+                               nn_dropout, nn_epochs, nn_lr, nn_batch, inference_dropout, trainer=nn_trainer)
     return PriceResult(price=out["price"], stderr=out.get("stderr", 0.0), std=out.get("std", 0.0),
                        zero_prob=out.get("zero_prob", 0.0), n_paths=M,
                        n_exercised=out.get("n_exercised", 0), sum_nitm=out.get("R", 0), model=model_l,

@@ -1,0 +1,229 @@
+"""GPU tests of the fused continuation-value-network trainer (omc_mlp_train_epoch):
+the hand-written MFMA forward/backward + Adam kernels against PyTorch autograd + torch.optim.Adam on
+the same float32 data and initial weights (the reference's own trainer, options_model_3.py:565-600).
+Tolerances are float32 accumulation-order tolerances; they are written next to each assert."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(ctx):
+    import torch
+
+    from options_model_amd import nn_regressor as nnr
+    return torch, nnr, torch.device("cuda", 0)
+
+
+def _data(torch, dev, rows, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    X = torch.randn(rows, 7, generator=g)
+    X[:, 0] = 0.0  # the constant feature normalises to zero
+    y = (0.7 * X[:, 1] - 0.3 * X[:, 2] ** 2 + 0.1 * torch.randn(rows, generator=g))[:, None]
+    return torch.cat([X, y], dim=1).float().contiguous().to(dev)
+
+
+def _torch_grads(torch, net, batch):
+    net.zero_grad(set_to_none=True)
+    loss = torch.nn.functional.mse_loss(net(batch[:, :7]), batch[:, 7:])
+    loss.backward()
+    return loss
+
+
+def _flat_grads(torch, nnr, net):
+    import copy
+    g = copy.deepcopy(net)
+    with torch.no_grad():
+        for pg, p in zip(g.parameters(), net.parameters()):
+            pg.copy_(p.grad)
+    return nnr.flatten_params(g)
+
+
+@pytest.mark.parametrize("rows", [32, 100, 4096, 50_000])
+def test_gradients_and_loss_match_autograd(env, ctx, rows):
+    """After ONE Adam step from zero moments, m = (1 - beta1) * (grad + wd * w): the first-moment
+    buffer exposes the kernel's gradient."""
+    torch, nnr, dev = env
+    torch.manual_seed(3)
+    net = nnr.make_net(7, 64, 2, 0.0).to(dev)
+    data = _data(torch, dev, rows, 11)
+    loss_t = _torch_grads(torch, net, data)
+    gref = _flat_grads(torch, nnr, net)
+    p0 = nnr.flatten_params(net)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    torch.cuda.synchronize()
+    loss, step = ctx.mlp_train_epoch(data.data_ptr(), rows, rows, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                     0, 1e-3, 0.0, 5, weight_decay=0.0)
+    assert step == 1
+    assert loss == pytest.approx(float(loss_t.detach()), rel=2e-5)
+    g = (m / 0.1).cpu().numpy()
+    ref = gref.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(g - ref).max() <= 2e-5 * scale  # float32 sums over up to 50k rows, different order
+    # first Adam step: w -= lr * g / (|g| + eps)
+    expect = p0 - 1e-3 * gref / (gref.abs() + 1e-8)
+    big = gref.abs() > 1e-6  # where g ~ 0 the sign is noise
+    assert torch.allclose(p[big], expect[big], rtol=0, atol=2e-6)
+
+
+def test_many_steps_track_torch_adam(env, ctx):
+    torch, nnr, dev = env
+    torch.manual_seed(4)
+    net = nnr.make_net(7, 64, 2, 0.0).to(dev)
+    rows, bs = 10_000, 1000  # 10 steps, none ragged
+    data = _data(torch, dev, rows, 12)
+    p = nnr.flatten_params(net)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    torch.cuda.synchronize()
+    loss, step = ctx.mlp_train_epoch(data.data_ptr(), rows, bs, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                     0, 1e-3, 0.0, 5)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    tot = 0.0
+    for o in range(0, rows, bs):
+        l_ = _torch_grads(torch, net, data[o:o + bs])
+        opt.step()
+        tot += float(l_)
+    assert step == 10
+    assert loss == pytest.approx(tot / 10, rel=1e-4)
+    ref = nnr.flatten_params(net)
+    # Adam's sign-like early steps amplify rounding where a gradient component is ~0; compare in bulk
+    diff = (p - ref).abs()
+    assert float(diff.max()) <= 2.5e-3 and float(diff.mean()) <= 2e-5
+    # second epoch continues the step count (bias correction) and the loss keeps falling
+    loss2, step2 = ctx.mlp_train_epoch(data.data_ptr(), rows, bs, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                       step, 1e-3, 0.0, 5)
+    assert step2 == 20 and loss2 < loss
+
+
+def test_ragged_last_batch(env, ctx):
+    torch, nnr, dev = env
+    torch.manual_seed(5)
+    net = nnr.make_net(7, 64, 2, 0.0).to(dev)
+    rows, bs = 1000, 300  # 300, 300, 300, 100
+    data = _data(torch, dev, rows, 13)
+    p = nnr.flatten_params(net)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    torch.cuda.synchronize()
+    loss, step = ctx.mlp_train_epoch(data.data_ptr(), rows, bs, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                     0, 1e-3, 0.0, 5)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    tot = 0.0
+    for o in range(0, rows, bs):
+        tot += float(_torch_grads(torch, net, data[o:o + bs]))
+        opt.step()
+    assert step == 4
+    assert loss == pytest.approx(tot / 4, rel=1e-4)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 1000, 65536, 65537, 1_000_003])
+def test_shuffle_is_a_permutation(env, ctx, n):
+    torch, nnr, dev = env
+    out = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    ctx.mlp_shuffle_indices(n, 12345, out.data_ptr())
+    idx = out.cpu().numpy()
+    assert np.array_equal(np.sort(idx), np.arange(n))
+    ctx.mlp_shuffle_indices(n, 0, out.data_ptr())
+    assert np.array_equal(out.cpu().numpy(), np.arange(n))  # key 0: storage order
+    if n >= 1000:
+        out2 = torch.empty_like(out)
+        ctx.mlp_shuffle_indices(n, 12346, out2.data_ptr())
+        idx2 = out2.cpu().numpy()
+        assert (idx != idx2).mean() > 0.99 and (idx != np.arange(n)).mean() > 0.99
+        # no visible structure: rank correlation with the identity and between keys is ~0
+        assert abs(np.corrcoef(idx, np.arange(n))[0, 1]) < 0.1 and abs(np.corrcoef(idx, idx2)[0, 1]) < 0.1
+
+
+def test_shuffled_epoch_visits_every_row_once(env, ctx):
+    """One full-batch step: the gradient is a sum over the rows, so any permutation gives the same
+    step up to rounding; minibatches of a shuffled epoch equal minibatches of the gathered data."""
+    torch, nnr, dev = env
+    torch.manual_seed(6)
+    net = nnr.make_net(7, 64, 2, 0.0).to(dev)
+    rows = 50_000
+    data = _data(torch, dev, rows, 14)
+    p0 = nnr.flatten_params(net)
+    res = []
+    for key in (0, 77):
+        p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+        torch.cuda.synchronize()
+        loss, _ = ctx.mlp_train_epoch(data.data_ptr(), rows, rows, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                      0, 1e-3, 0.0, 5, weight_decay=0.0, shuffle_key=key)
+        res.append((loss, m.clone()))
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-5)
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[0][1].abs().max())
+    # minibatches: shuffled in-kernel == storage order on the gathered copy, bit for bit
+    idx = torch.empty(rows, dtype=torch.int64, device=dev)
+    ctx.mlp_shuffle_indices(rows, 77, idx.data_ptr())
+    gathered = data[idx].contiguous()
+    outs = []
+    for d, key in ((data, 77), (gathered, 0)):
+        p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+        torch.cuda.synchronize()
+        loss, step = ctx.mlp_train_epoch(d.data_ptr(), rows, 4096, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                         0, 1e-3, 0.0, 5, shuffle_key=key)
+        outs.append((loss, p.cpu().numpy()))
+    assert step == 13 and outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_dropout_is_inverted_bernoulli_and_deterministic(env, ctx):
+    """W1 = 0, b1 = 1, W2 = 0, b2 = 1, w3 = 1/64, b3 = 0, target 0: out = mean_j keep_j / q, so the
+    batch loss is E[out^2] = 1 + (1 - q) / (64 q) for keep probability q = 1 - p."""
+    torch, nnr, dev = env
+    rows = 1 << 17
+    data = torch.zeros(rows, 8, device=dev)
+    flat = torch.zeros(4737, device=dev)
+    flat[:512].view(64, 8)[:, 7] = 1.0
+    flat[4608:4672] = 1.0
+    flat[4672:4736] = 1.0 / 64
+    for p_drop in (0.1, 0.5):
+        q = 1 - p_drop
+        res = []
+        for seed in (1, 1, 2):
+            p, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
+            torch.cuda.synchronize()
+            loss, _ = ctx.mlp_train_epoch(data.data_ptr(), rows, rows, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                          0, 1e-3, p_drop, seed)
+            res.append((loss, p.cpu().numpy()))
+        expect = 1 + (1 - q) / (64 * q)
+        sd = 2 * math.sqrt((1 - q) / (64 * q)) / math.sqrt(rows)
+        assert abs(res[0][0] - expect) < 6 * sd + 1e-4
+        assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])  # same seed: same bits
+        assert res[0][0] != res[2][0]
+
+
+def test_unsupported_shapes_and_bad_arguments(env, ctx):
+    torch, nnr, dev = env
+    lib = ctx.lib
+    assert lib.omc_mlp_param_count(64, 2) == 4737
+    assert lib.omc_mlp_param_count(128, 3) == -1
+    d = torch.zeros(64, 8, device=dev)
+    p = torch.zeros(4737, device=dev)
+    with pytest.raises(ValueError, match="hidden = 64"):
+        ctx.mlp_train_epoch(d.data_ptr(), 64, 64, p.data_ptr(), p.data_ptr(), p.data_ptr(), 0, 1e-3, 0.0, 1,
+                            hidden=128, layers=3)
+    with pytest.raises(ValueError, match="dropout"):
+        ctx.mlp_train_epoch(d.data_ptr(), 64, 64, p.data_ptr(), p.data_ptr(), p.data_ptr(), 0, 1e-3, 1.0, 1)
+    assert not nnr.fused_trainer_supports(nnr.make_net(7, 128, 3, 0.1))
+    with pytest.raises(ValueError, match="covers"):
+        nnr.train(nnr.make_net(7, 128, 3, 0.1).to(dev), torch.ones(10, device=dev, dtype=torch.float64),
+                  torch.ones(10, device=dev, dtype=torch.int32), torch.ones(10, device=dev, dtype=torch.float64),
+                  torch.zeros(7, device=dev, dtype=torch.float64), torch.ones(7, device=dev, dtype=torch.float64),
+                  torch.zeros((), device=dev, dtype=torch.float64), torch.ones((), device=dev, dtype=torch.float64),
+                  1.0, 0.1, 1, 1e-3, trainer="hip")
+
+
+def test_fused_and_torch_trainers_price_alike(env, ctx):
+    """Same paths, same rows: the two trainers differ only in minibatch order, dropout streams and
+    rounding -> prices agree to Monte-Carlo + training noise (the reference itself moves by ~0.3
+    between seeds on this flow, tests/golden/scalars.json reference_nn_seed_band)."""
+    torch, nnr, dev = env
+    out = {}
+    for tr in ("hip", "torch"):
+        r = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, seed=9, nn_epochs=6,
+                                         nn_trainer=tr)
+        out[tr] = r
+    assert abs(out["hip"].price - out["torch"].price) < 0.25
+    assert 5.5 < out["hip"].price < 8.0

@@ -48,14 +48,18 @@ def main():
     poly("C3_shard", 8_000_000, 252, reps=3)
     poly("C4", 4_000_000, 252, model="Heston", option_type="call", heston_params=HP, reps=3)
     if not only or "C5" in only:
-        t0 = time.perf_counter()
-        res = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 1_000_000, 252, regressor="nn", seed=42)
-        dt = time.perf_counter() - t0
-        rows.append(dict(config="C5", paths=1_000_000, steps=252, regressor="nn 2x64 (SingleLSMNet(7,64,2)), "
-                         "25 epochs max, Adam 1e-3, batch auto", price=res.price, stderr=res.stderr,
-                         seconds=dt, path_steps_per_s=1_000_000 * 252 / dt, R=res.sum_nitm,
-                         timings_ms=res.timings_ms))
-        print(json.dumps(rows[-1]), flush=True)
+        from options_model_amd import nn_regressor
+        trainers = [t for t in ("hip", "torch") if not only or not ({"hip", "torch"} & only) or t in only]
+        for trainer in trainers:
+            t0 = time.perf_counter()
+            res = nn_regressor.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 1_000_000, 252, seed=42,
+                                                        nn_trainer=trainer)
+            dt = time.perf_counter() - t0
+            rows.append(dict(config="C5", paths=1_000_000, steps=252, trainer=trainer,
+                             regressor="nn 2x64 (SingleLSMNet(7,64,2)), 25 epochs max, Adam 1e-3, batch auto",
+                             price=res.price, stderr=res.stderr, seconds=dt,
+                             path_steps_per_s=1_000_000 * 252 / dt, R=res.sum_nitm, timings_ms=res.timings_ms))
+            print(json.dumps(rows[-1]), flush=True)
 
 
 if __name__ == "__main__":
