@@ -181,6 +181,22 @@ int omc_heston_price_strikes(omc_ctx* ctx, int64_t n_paths, int n_steps, double 
  * *mean_loss = mean over the epoch's steps of the batch-mean squared error (the value the
  * reference feeds to ReduceLROnPlateau and its early-stopping test, :601-613). */
 int omc_mlp_param_count(int hidden, int layers);
+/* Pass 2 of the NN flow (options_model_3.py:615-651): sticky backward sweep over a device path
+ * matrix with the trained network as continuation value -- features [1, x, x^2, x^3,
+ * max(x-1,0), s, x*s] of x = S/K normalised with (feat_mean, feat_std) (host, 7 each), network
+ * output scaled back by y_std, y_mean; exercise where payoff > continuation; dropout (> 0) stays
+ * active as in the reference, which never calls .eval() on this net; cash-flows valued at
+ * t = dt.  params: device, omc_mlp_train_epoch's layout.  Optional sx_out / tex_out (host). */
+int omc_lsm_apply_mlp(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                      double r, double T, int is_put, int hidden, int layers, const float* params,
+                      const double* feat_mean, const double* feat_std, double y_mean, double y_std,
+                      double dropout, uint64_t seed, omc_result* res, float* sx_out, int32_t* tex_out);
+/* Normalisers of the training rows (options_model_3.py:550-563) in float64: for rows i < n_rows
+ * with x[i] = S/K, step index t[i] and target y[i] (device arrays), out16[0..6] = means of
+ * [x, x^2, x^3, max(x-1,0), s, x*s, y] with s = sqrt(max(T - t*dt, 1e-6)), out16[8..14] =
+ * their population variances (two passes: mean first, then squared deviations).  out16: host. */
+int omc_nn_feature_stats(omc_ctx* ctx, const double* x, const int32_t* t, const double* y,
+                         int64_t n_rows, double T, double dt, double* out16);
 int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t batch, int hidden,
                         int layers, float* params, float* adam_m, float* adam_v, int64_t* step,
                         double lr, double beta1, double beta2, double eps, double weight_decay,

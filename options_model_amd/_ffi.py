@@ -80,6 +80,9 @@ SIGNATURES = {
     "omc_mlp_train_epoch": (C.c_int, [_P, _P, _I64, _I64, _I, _I, _P, _P, _P, C.POINTER(C.c_int64)]
                             + [_D] * 6 + [_U64, _U64, C.POINTER(C.c_double)]),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
+    "omc_lsm_apply_mlp": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _I, _P, _P, _P, _D, _D, _D, _U64,
+                                    C.POINTER(Result), _P, _P]),
+    "omc_nn_feature_stats": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P]),
 }
 
 _lib = None
@@ -381,6 +384,32 @@ class Context:
             int(m_ptr), int(v_ptr), C.byref(st), float(lr), float(beta1), float(beta2), float(eps),
             float(weight_decay), float(dropout), int(seed), int(shuffle_key), C.byref(loss)))
         return loss.value, st.value
+
+    def lsm_apply_mlp(self, S_ptr, ld, n_paths, n_steps, K, r, T, is_put, params_ptr, feat_mean, feat_std,
+                      y_mean, y_std, dropout, seed, want_state=False, hidden=64, layers=2):
+        """Pass 2 of the NN flow on a device path matrix -> result dict (+ sx, tex if want_state)."""
+        fm = np.ascontiguousarray(feat_mean, np.float64)
+        fs = np.ascontiguousarray(feat_std, np.float64)
+        assert fm.size == 7 and fs.size == 7
+        res = Result()
+        sx = np.empty(n_paths, np.float32) if want_state else None
+        tex = np.empty(n_paths, np.int32) if want_state else None
+        _check(self.lib, self.lib.omc_lsm_apply_mlp(
+            self.handle, int(S_ptr), int(ld), int(n_paths), int(n_steps), float(K), float(r), float(T),
+            int(bool(is_put)), int(hidden), int(layers), int(params_ptr), fm.ctypes.data, fs.ctypes.data,
+            float(y_mean), float(y_std), float(dropout), int(seed), C.byref(res),
+            sx.ctypes.data if want_state else None, tex.ctypes.data if want_state else None))
+        out = res.as_dict()
+        if want_state:
+            out["sx"], out["tex"] = sx, tex
+        return out
+
+    def nn_feature_stats(self, x_ptr, t_ptr, y_ptr, n_rows, T, dt):
+        """-> (means[7], variances[7]) of [x, x^2, x^3, max(x-1,0), s, x*s, y] over device rows."""
+        out = np.zeros(16)
+        _check(self.lib, self.lib.omc_nn_feature_stats(self.handle, int(x_ptr), int(t_ptr), int(y_ptr),
+                                                       int(n_rows), float(T), float(dt), out.ctypes.data))
+        return out[:7].copy(), out[8:15].copy()
 
     def mlp_shuffle_indices(self, n_rows, shuffle_key, out_ptr):
         _check(self.lib, self.lib.omc_mlp_shuffle_indices(self.handle, int(n_rows), int(shuffle_key), int(out_ptr)))

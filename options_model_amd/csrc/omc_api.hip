@@ -753,6 +753,52 @@ int omc_mlp_param_count(int hidden, int layers)
     return (hidden == 64 && layers == 2) ? omc::kMlpParams : -1;
 }
 
+int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                      double r, double T, int is_put, int hidden, int layers, const float* params,
+                      const double* feat_mean, const double* feat_std, double y_mean, double y_std,
+                      double dropout, uint64_t seed, omc_result* res, float* sx_out, int32_t* tex_out)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_market(1.0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (omc_mlp_param_count(hidden, layers) < 0)
+        return fail(-9, "the network kernels support hidden = 64, layers = 2 only.");
+    if (!params || !feat_mean || !feat_std || !res) return fail(-7, "null pointer.");
+    if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
+    for (int i = 0; i < 7; ++i)
+        if (!(feat_std[i] > 0.0)) return fail(-4, "feature standard deviations must be positive.");
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w))) return rc;
+    omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
+    HIP_TRY(omc::mlp_apply_pass2(c->stream, p, params, feat_mean, feat_std, y_mean, y_std, dropout, seed,
+                                 w.sx, w.tex));
+    HIP_TRY(omc::lsm_final_reduce(c->stream, p, w, 1));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    fill_result(res, c->hres, n_paths);
+    return 0;
+}
+
+int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const double* y, int64_t n_rows,
+                         double T, double dt, double* out16)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!x || !t || !y || !out16) return fail(-7, "null pointer.");
+    if (n_rows <= 0) return fail(-3, "n_rows must be positive.");
+    if ((rc = c->scratch.ensure(omc::nn_stats_scratch_bytes() + sizeof(double) * 16))) return rc;
+    double* scratch = (double*)c->scratch.p;
+    double* dev16 = scratch + omc::nn_stats_scratch_bytes() / sizeof(double);
+    HIP_TRY(omc::nn_feature_stats(c->stream, x, t, y, n_rows, T, dt, scratch, dev16));
+    HIP_TRY(hipMemcpyAsync(out16, dev16, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int omc_mlp_shuffle_indices(omc_ctx* c, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device)
 {
     int rc = bind(c);

@@ -107,6 +107,14 @@ struct MlpTrainPlan {
     uint64_t shuffle_key;  // 0: rows in storage order; else a keyed pseudo-random permutation
 };
 size_t mlp_partial_bytes();
+// pass 2 of the NN flow: sticky sweep with the network as continuation value -> (sx, tex)
+hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, const float* params, const double* feat_mean,
+                           const double* feat_std, double y_mean, double y_std, double dropout, uint64_t seed,
+                           float* sx, int32_t* tex);
+// float64 means / population variances of the regression features and the target over n rows
+size_t nn_stats_scratch_bytes();
+hipError_t nn_feature_stats(hipStream_t st, const double* x, const int32_t* t, const double* y, int64_t n,
+                            double T, double dt, double* scratch, double* out16);
 // the permutation the trainer walks (for tests): out[i] = stored row visited at epoch position i
 hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out);
 // one epoch: ceil(nrows / batch) optimizer steps (forward+backward kernel, reduce+Adam kernel)

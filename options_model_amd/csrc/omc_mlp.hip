@@ -36,7 +36,7 @@ constexpr int kLdT = 36;               // staging [unit][row]: 32 rows + pad, 16
 constexpr int kLdsWeights = kH * kLdW1 + kH * kLdW2 + kH + kH + 4;
 constexpr int kLdsWave = 2 * kH * kLdT + 8 * kLdT;
 constexpr int kLdsFloats = kLdsWeights + 4 * kLdsWave;
-static_assert(kLdsWave >= kMlpParams, "the workgroup gradient buffer aliases one staging patch");
+static_assert(kLdsWave > kMlpParams, "a wave's gradient vector is laid out in its staging patch");
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
     for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += nwaves) {
         const int64_t row = (int64_t)tile * 32 + c;
         const bool live = row < a.nrows;
-        float4 x = xnext;
-        xnext = fetch(tile + nwaves);  // in flight while this tile is computed
+        const float4 xin = xnext;
+        float4 x = xin;
         float y = x.w;                 // upper half-wave: column 7 is the target ...
         if (h == 1) x.w = 1.0f;        // ... and its slot carries the bias input
         y = __shfl(y, c + 32, 64);
@@ -201,6 +201,9 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
             h1[mt] = mfma(wr[2], x.z, h1[mt]);
             h1[mt] = mfma(wr[3], x.w, h1[mt]);
         }
+        // next tile's rows: issued once this tile's are consumed (a wait on the older load would
+        // otherwise drain this one too), in flight for the rest of the tile
+        xnext = fetch(tile + nwaves);
         relu_dropout(h1, (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -332,43 +335,31 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
         loss += __shfl_xor(loss, m, 64);
     }
 
-    // ---- workgroup sum in wave order through LDS (aliases wave 0's staging patch), then out
-    float* G = lds + kLdsWeights;
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-            const bool first = (w == 0);
+    // ---- every wave lays its gradient vector out in its own staging patch (plain stores, nothing
+    // to wait for), then the workgroup adds the four copies in wave order on the way out
+    float* G = tH1;
+    wave_sync_lds();  // this wave's last staging reads are done
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = unit_of(mi, r, h);
-                    float* g0 = G + kOW2 + i * kH + c;
-                    g0[0] = (first ? 0.0f : g0[0]) + gW2[mi][0][r];
-                    g0[32] = (first ? 0.0f : g0[32]) + gW2[mi][1][r];
-                    if (c < 8) {
-                        float* g1 = G + kOW1 + i * 8 + c;
-                        *g1 = (first ? 0.0f : *g1) + gW1[mi][r];
-                    }
-                    if (c == 0) {
-                        float* g3 = G + kOW3 + i;
-                        *g3 = (first ? 0.0f : *g3) + gw3[mi][r];
-                    }
-                }
-                if (h == 0) {
-                    float* gb = G + kOB2 + 32 * mi + c;
-                    *gb = (first ? 0.0f : *gb) + gb2[mi];
-                }
-            }
-            if (lane == 0) {
-                G[kOB3] = (first ? 0.0f : G[kOB3]) + gb3;
-                G[kMlpParams] = (first ? 0.0f : G[kMlpParams]) + loss;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int i = unit_of(mi, r, h);
+            G[kOW2 + i * kH + c] = gW2[mi][0][r];
+            G[kOW2 + i * kH + 32 + c] = gW2[mi][1][r];
+            if (c < 8) G[kOW1 + i * 8 + c] = gW1[mi][r];
+            if (c == 0) G[kOW3 + i] = gw3[mi][r];
         }
-        __syncthreads();
+        if (h == 0) G[kOB2 + 32 * mi + c] = gb2[mi];
     }
+    if (lane == 0) {
+        G[kOB3] = gb3;
+        G[kMlpParams] = loss;
+    }
+    __syncthreads();
+    const float* G0 = lds + kLdsWeights;
     float* out = a.partial + (size_t)blockIdx.x * kMlpPartialStride;
-    for (int i = tid; i <= kMlpParams; i += 256) out[i] = G[i];
+    for (int i = tid; i <= kMlpParams; i += 256)
+        out[i] = ((G0[i] + G0[kLdsWave + i]) + G0[2 * kLdsWave + i]) + G0[3 * kLdsWave + i];
 }
 
 struct MlpAdamArgs {
@@ -413,6 +404,207 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a)
     const float denom = __builtin_amdgcn_sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
     a.params[p] = w0 - a.lr_t * (m / denom);
 }
+
+// ------------------------------------------------------------------ feature statistics
+// Means and population variances of the six non-constant regression features
+// [x, x^2, x^3, max(x-1,0), s, x*s] (create_regression_features, options_model_3.py:105-121;
+// s = sqrt(max(T - t*dt, 1e-6))) and of the target over all R rows, in float64
+// (:550-563).  PASS 0 sums values, PASS 1 sums squared deviations from the given means.
+struct StatArgs {
+    const double* x;
+    const int32_t* t;
+    const double* y;
+    int64_t n;
+    double T, dt;
+    const double* mean;  // [8] (PASS 1)
+    double* part;        // [8][pstride]
+    int pstride;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void nn_stats_kernel(StatArgs a)
+{
+    __shared__ double red[kNQ * kRedStride];
+    double acc[8], mu[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        acc[q] = 0.0;
+        mu[q] = PASS ? a.mean[q] : 0.0;
+    }
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        const double x = a.x[i];
+        const double s = sqrt(fmax(a.T - (double)a.t[i] * a.dt, 1e-6));
+        const double x2 = x * x;
+        const double f[8] = {x, x2, x2 * x, fmax(x - 1.0, 0.0), s, x * s, a.y[i], 0.0};
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const double d = f[q] - mu[q];
+            acc[q] += PASS ? d * d : d;
+        }
+    }
+    const double r = block_reduce8(acc, red);
+    if (threadIdx.x < 64 && (threadIdx.x & 7) == 0)
+        a.part[(size_t)(threadIdx.x >> 3) * a.pstride + blockIdx.x] = r;
+}
+
+// part[q][0..nblk) summed in index order, divided by n -> out[q]
+__global__ __launch_bounds__(kBlock) void nn_stats_finish_kernel(const double* part, int nblk, int pstride,
+                                                                double n, double* out)
+{
+    __shared__ double red[kNQ * kRedStride];
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += kBlock) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += part[(size_t)q * pstride + i];
+    }
+    const double r = block_reduce8(acc, red);
+    if (threadIdx.x < 64 && (threadIdx.x & 7) == 0) out[threadIdx.x >> 3] = r / n;
+}
+
+// ------------------------------------------------------------------ pass 2 with the network
+// Sticky backward sweep of the NN flow (options_model_3.py:615-649): at every step the
+// continuation value of every still-alive in-the-money path is the network's output on the
+// normalised features; exercise where payoff > continuation (strict), first hit going backwards
+// sticks.  One wave owns 32 paths for the whole sweep (state in registers), the forward pass
+// is the training kernel's (float32 MFMA, transposed layout), dropout stays ACTIVE when asked
+// for (the reference never switches the net to eval mode).  Leaves (sx, tex)
+// for the common valuation kernel.
+struct MlpApplyArgs {
+    const float* S;
+    int64_t ld, M;
+    int N, is_put;
+    double K, T, dt;
+    const float* params;
+    double fm[7], rs[7];  // feature means, reciprocal stds
+    double ym, ysd;
+    float* sx;
+    int32_t* tex;
+    float inv_keep;
+    uint32_t keep16, k0, k1;
+    int ntiles;
+};
+
+__global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
+{
+    __shared__ float sw[kLdsWeights];
+    float* sW1 = sw;
+    float* sW2 = sW1 + kH * kLdW1;
+    float* sB2 = sW2 + kH * kLdW2;
+    float* sW3 = sB2 + kH;
+    float* sB3 = sW3 + kH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+    for (int i = tid; i < kH * 8; i += 256) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[kOW1 + i];
+    for (int i = tid; i < kH * kH; i += 256) sW2[(i >> 6) * kLdW2 + (i & 63)] = a.params[kOW2 + i];
+    if (tid < kH) {
+        sB2[tid] = a.params[kOB2 + tid];
+        sW3[tid] = a.params[kOW3 + tid];
+    }
+    if (tid == 0) sB3[0] = a.params[kOB3];
+    __syncthreads();
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.ntiles) return;  // whole wave; no barrier below
+    const int64_t p = (int64_t)tile * 32 + c;
+    const bool live = p < a.M;
+    const float* col = a.S + (live ? p : a.M - 1);
+    const double K = a.K;
+    float sx = col[(int64_t)a.N * a.ld];
+    int tex = a.N;
+    bool done = !live;
+    float s_next = a.N > 1 ? col[(int64_t)(a.N - 1) * a.ld] : 0.0f;
+    for (int t = a.N - 1; t >= 1; --t) {
+        const float sf = s_next;
+        if (t > 1) s_next = col[(int64_t)(t - 1) * a.ld];
+        const double sd = (double)sf;
+        const double imm = a.is_put ? K - sd : sd - K;
+        const bool need = !done && imm > 0.0;
+        if (__builtin_amdgcn_ballot_w64(need) == 0) continue;  // nobody to decide for (uniform)
+        const double x = sd / K;
+        const double st = sqrt(fmax(a.T - (double)t * a.dt, 1e-6));
+        float4 xin;
+        if (h == 0) {
+            xin.x = (float)((1.0 - a.fm[0]) * a.rs[0]);
+            xin.y = (float)((x - a.fm[1]) * a.rs[1]);
+            xin.z = (float)((x * x - a.fm[2]) * a.rs[2]);
+            xin.w = (float)((x * x * x - a.fm[3]) * a.rs[3]);
+        } else {
+            xin.x = (float)((fmax(x - 1.0, 0.0) - a.fm[4]) * a.rs[4]);
+            xin.y = (float)((st - a.fm[5]) * a.rs[5]);
+            xin.z = (float)((x * st - a.fm[6]) * a.rs[6]);
+            xin.w = 1.0f;  // bias input
+        }
+        v16f h1[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[mt][r] = 0.0f;
+            const float* wr = sW1 + (32 * mt + c) * kLdW1 + 4 * h;
+            h1[mt] = mfma(wr[0], xin.x, h1[mt]);
+            h1[mt] = mfma(wr[1], xin.y, h1[mt]);
+            h1[mt] = mfma(wr[2], xin.z, h1[mt]);
+            h1[mt] = mfma(wr[3], xin.w, h1[mt]);
+        }
+        relu_dropout(h1, (uint32_t)p, (uint32_t)t, 0x300u + (uint32_t)h + 2u * (uint32_t)(p >> 32), a.keep16,
+                     a.inv_keep, a.k0, a.k1);
+        v16f h2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[mt][r] = sB2[unit_of(mt, r, h)];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = unit_of(kt, s, h);
+                h2[0] = mfma(sW2[(c)*kLdW2 + k], h1[kt][s], h2[0]);
+                h2[1] = mfma(sW2[(32 + c) * kLdW2 + k], h1[kt][s], h2[1]);
+            }
+        }
+        relu_dropout(h2, (uint32_t)p, (uint32_t)t, 0x400u + (uint32_t)h + 2u * (uint32_t)(p >> 32), a.keep16,
+                     a.inv_keep, a.k0, a.k1);
+        float o = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o = __builtin_fmaf(sW3[unit_of(mt, r, h)], h2[mt][r], o);
+        o += __shfl_xor(o, 32, 64);
+        o += sB3[0];
+        const double cont = (double)o * a.ysd + a.ym;
+        if (need && imm > cont) {
+            done = true;
+            tex = t;
+            sx = sf;
+        }
+    }
+    if (live && h == 0) {
+        a.sx[p] = sx;
+        a.tex[p] = tex;
+    }
+}
+
+}  // namespace
+
+size_t nn_stats_scratch_bytes() { return sizeof(double) * 8 * (1024 + 2); }
+
+// out[0..7] = means, out[8..15] = population variances (slots 0-5 features 1..6, slot 6 target)
+hipError_t nn_feature_stats(hipStream_t st, const double* x, const int32_t* t, const double* y, int64_t n,
+                            double T, double dt, double* scratch, double* out16)
+{
+    StatArgs a;
+    a.x = x; a.t = t; a.y = y; a.n = n; a.T = T; a.dt = dt;
+    a.part = scratch; a.pstride = 1024; a.mean = out16;
+    int nblk = (int)((n + kBlock * 8 - 1) / (kBlock * 8));
+    nblk = nblk < 1 ? 1 : (nblk > 1024 ? 1024 : nblk);
+    hipLaunchKernelGGL(nn_stats_kernel<0>, dim3(nblk), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(nn_stats_finish_kernel, dim3(1), dim3(kBlock), 0, st, scratch, nblk, 1024, (double)n, out16);
+    hipLaunchKernelGGL(nn_stats_kernel<1>, dim3(nblk), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(nn_stats_finish_kernel, dim3(1), dim3(kBlock), 0, st, scratch, nblk, 1024, (double)n, out16 + 8);
+    return hipGetLastError();
+}
+
+namespace {
 
 Shuffle make_shuffle(int64_t n, uint64_t key)
 {
@@ -499,6 +691,29 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         b.wd = (float)t.weight_decay;
         hipLaunchKernelGGL(mlp_adam_kernel, dim3((kMlpParams + 16) / 16), dim3(256), 0, st, b);
     }
+    return hipGetLastError();
+}
+
+hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, const float* params, const double* feat_mean,
+                           const double* feat_std, double y_mean, double y_std, double dropout, uint64_t seed,
+                           float* sx, int32_t* tex)
+{
+    MlpApplyArgs a;
+    a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
+    a.K = p.K; a.T = p.T; a.dt = p.T / (double)p.N;
+    a.params = params;
+    for (int i = 0; i < 7; ++i) {
+        a.fm[i] = feat_mean[i];
+        a.rs[i] = 1.0 / feat_std[i];
+    }
+    a.ym = y_mean; a.ysd = y_std;
+    a.sx = sx; a.tex = tex;
+    a.keep16 = dropout > 0.0 ? (uint32_t)llround((1.0 - dropout) * 65536.0) : 65536u;
+    a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
+    a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
+    const int64_t ntiles = (p.M + 31) / 32;
+    a.ntiles = (int)ntiles;
+    hipLaunchKernelGGL(mlp_apply_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -120,33 +120,21 @@ def collect_rows(S, K, r, T, is_put, step_chunk=32):
     return torch.cat(xs), torch.cat(ts), torch.cat(ys), payT
 
 
-def normalisers(x, t, y, T, dt, chunk=1 << 24):
-    """:550-563 in float64: population std; zero feature std -> 1; zero target std -> 1."""
+def normalisers(x, t, y, T, dt):
+    """:550-563 in float64: population std; zero feature std -> 1; zero target std -> 1.
+    The sums run in the library (omc_nn_feature_stats: mean pass, then squared deviations)."""
     torch = _torch()
-    R = x.numel()
-    s1 = torch.zeros(7, dtype=torch.float64, device=x.device)
-    s2 = torch.zeros(7, dtype=torch.float64, device=x.device)
-    for o in range(0, R, chunk):
-        st = torch.sqrt(torch.clamp(T - t[o:o + chunk].double() * dt, min=1e-6))
-        f = features(x[o:o + chunk], st)
-        s1 += f.sum(0)
-        s2 += (f * f).sum(0)
-    # tensor / tensor is a true IEEE division; tensor / python-scalar is lowered to a multiply
-    # by the reciprocal on the GPU, which turns the mean of the constant column into 1 - 2^-53
-    # and its "zero" std into 1e-16 instead of the exact 0 the reference tests for (:562)
-    Rt = torch.tensor(float(R), dtype=torch.float64, device=x.device)
-    fm = s1 / Rt
-    # two-pass variance for accuracy (features are O(1), R up to 1e8)
-    v = torch.zeros(7, dtype=torch.float64, device=x.device)
-    for o in range(0, R, chunk):
-        st = torch.sqrt(torch.clamp(T - t[o:o + chunk].double() * dt, min=1e-6))
-        d = features(x[o:o + chunk], st) - fm
-        v += (d * d).sum(0)
-    fs = torch.sqrt(v / Rt)
-    fs = torch.where(fs == 0, torch.ones_like(fs), fs)
-    ym = y.sum() / Rt
-    ysd = torch.sqrt(((y - ym) ** 2).sum() / Rt)
-    if not float(ysd) > 0:
+    dev = x.device
+    ctx = _ctx_on_torch_stream(dev.index or 0)
+    torch.cuda.current_stream(dev).synchronize()
+    mean, var = ctx.nn_feature_stats(x.data_ptr(), t.data_ptr(), y.data_ptr(), x.numel(), T, dt)
+    fm = torch.tensor([1.0] + list(mean[:6]), dtype=torch.float64, device=dev)
+    fs = torch.tensor([0.0] + list(var[:6]), dtype=torch.float64, device=dev).sqrt()
+    # a constant column: exactly zero in exact arithmetic, rounding noise of the sums here
+    fs = torch.where(fs <= 1e-13 * fm.abs().clamp(min=1e-300), torch.ones_like(fs), fs)
+    ym = torch.tensor(float(mean[6]), dtype=torch.float64, device=dev)
+    ysd = torch.tensor(math.sqrt(float(var[6])), dtype=torch.float64, device=dev)
+    if not float(ysd) > 1e-13 * abs(float(ym)):
         ysd = torch.ones_like(ysd)
     return fm, fs, ym, ysd
 
@@ -393,6 +381,26 @@ def pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, path_chunk=
     return cf, exercised
 
 
+def pass2_fused(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, want_state=False):
+    """:615-651 by the library's kernel (omc_lsm_apply_mlp): the same sticky sweep, the network
+    evaluated by float32 MFMA per 32-path tile, dropout bits from Philox-seeded streams."""
+    torch = _torch()
+    dev = S.device
+    N, M = S.shape[0] - 1, S.shape[1]
+    ctx = _ctx_on_torch_stream(dev.index or 0)
+    params = flatten_params(net)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    torch.cuda.current_stream(dev).synchronize()
+    out = ctx.lsm_apply_mlp(S.data_ptr(), S.stride(0), M, N, K, r, T, is_put, params.data_ptr(),
+                            fm.cpu().numpy(), fs.cpu().numpy(), float(ym), float(ysd),
+                            _dropout_of(net) if dropout_on else 0.0, seed, want_state=want_state)
+    res = dict(price=out["price"], std=out["std"], n_exercised=out["n_exercised"], zero_prob=out["zero_prob"],
+               pass2="hip")
+    if want_state:
+        res.update(sx=out["sx"], tex=out["tex"])
+    return res
+
+
 def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3, nn_dropout=0.1,
                      nn_epochs=25, nn_lr=1e-3, nn_batch=None, inference_dropout=True, verbose=False,
                      trainer="auto"):
@@ -417,15 +425,18 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
     info = train(net, x, t, y, fm, fs, ym, ysd, T, dt, nn_epochs, nn_lr, nn_batch, verbose, trainer=trainer)
     torch.cuda.synchronize(S.device)
     t2 = time.perf_counter()
-    cf, ex = pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
-    price = float(cf.mean())
+    if trainer != "torch" and fused_trainer_supports(net):
+        res = pass2_fused(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
+    else:
+        cf, ex = pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
+        price = float(cf.mean())
+        var = float(((cf - price) ** 2).mean())
+        res = dict(price=price, std=math.sqrt(var), n_exercised=int(ex.sum()),
+                   zero_prob=float((cf == 0).double().mean()), pass2="torch")
     t3 = time.perf_counter()
-    var = float(((cf - price) ** 2).mean())
-    info.update(price=price, std=math.sqrt(var), stderr=math.sqrt(var / M), R=int(x.numel()), n_paths=M,
-                n_exercised=int(ex.sum()), zero_prob=float((cf == 0).double().mean()),
+    info.update(res, stderr=res["std"] / math.sqrt(M), R=int(x.numel()), n_paths=M,
                 Y_mean=float(ym), Y_std=float(ysd), seconds_collect=t_c - t0, seconds_normalise=t1 - t_c,
-                seconds_train=t2 - t1,
-                seconds_pass2=t3 - t2, net=net, feat_mean=fm, feat_std=fs)
+                seconds_train=t2 - t1, seconds_pass2=t3 - t2, net=net, feat_mean=fm, feat_std=fs)
     return info
 
 

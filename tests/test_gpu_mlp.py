@@ -85,7 +85,7 @@ def test_many_steps_track_torch_adam(env, ctx):
     for o in range(0, rows, bs):
         l_ = _torch_grads(torch, net, data[o:o + bs])
         opt.step()
-        tot += float(l_)
+        tot += float(l_.detach())
     assert step == 10
     assert loss == pytest.approx(tot / 10, rel=1e-4)
     ref = nnr.flatten_params(net)
@@ -112,7 +112,7 @@ def test_ragged_last_batch(env, ctx):
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
     tot = 0.0
     for o in range(0, rows, bs):
-        tot += float(_torch_grads(torch, net, data[o:o + bs]))
+        tot += float(_torch_grads(torch, net, data[o:o + bs]).detach())
         opt.step()
     assert step == 4
     assert loss == pytest.approx(tot / 4, rel=1e-4)
@@ -192,6 +192,64 @@ def test_dropout_is_inverted_bernoulli_and_deterministic(env, ctx):
         assert abs(res[0][0] - expect) < 6 * sd + 1e-4
         assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])  # same seed: same bits
         assert res[0][0] != res[2][0]
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 3_000_001])
+def test_feature_statistics_match_numpy(env, ctx, n):
+    """omc_nn_feature_stats against numpy float64 on the same rows (options_model_3.py:550-563)."""
+    torch, nnr, dev = env
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0.5, 1.0, n)
+    t = rng.integers(1, 50, n).astype(np.int32)
+    y = rng.exponential(3.0, n)
+    T, dt = 1.0, 1.0 / 50
+    s = np.sqrt(np.maximum(T - t * dt, 1e-6))
+    F = np.stack([x, x * x, x ** 3, np.maximum(x - 1, 0), s, x * s, y])
+    xd, td, yd = (torch.from_numpy(a).to(dev) for a in (x, t, y))
+    torch.cuda.synchronize()
+    mean, var = ctx.nn_feature_stats(xd.data_ptr(), td.data_ptr(), yd.data_ptr(), n, T, dt)
+    assert np.allclose(mean, F.mean(axis=1), rtol=1e-12, atol=1e-15)
+    assert np.allclose(var, F.var(axis=1), rtol=1e-9, atol=1e-18)
+    fm, fs, ym, ysd = nnr.normalisers(xd, td, yd, T, dt)
+    assert fm[0] == 1.0 and fs[0] == 1.0           # the constant column: std 0 -> 1 (:562)
+    assert fs[4] == 1.0                             # max(x-1,0) is all zero here: std 0 -> 1
+    if n > 1:
+        assert float(ysd) == pytest.approx(y.std(), rel=1e-9) and float(ym) == pytest.approx(y.mean(), rel=1e-12)
+    else:
+        assert float(ysd) == 1.0 and bool((fs == 1.0).all())
+
+
+def test_pass2_kernel_matches_torch_sweep(env, ctx):
+    """Same trained-ish net, same paths, dropout off: the exercise decisions of omc_lsm_apply_mlp
+    are those of the torch sweep except where payoff and continuation agree to float32 rounding."""
+    torch, nnr, dev = env
+    from options_model_amd import _ffi
+    torch.manual_seed(8)
+    M, N, K, r, T = 20_000, 30, 100.0, 0.05, 1.0
+    S = torch.empty((N + 1, M), dtype=torch.float32, device=dev)
+    c2 = nnr._ctx_on_torch_stream(0)
+    nnr.generate_paths(c2, S, dict(model="gbm"), 100.0, r, 0.2, T, 21)
+    x, t, y, _ = nnr.collect_rows(S, K, r, T, True)
+    fm, fs, ym, ysd = nnr.normalisers(x, t, y, T, T / N)
+    net = nnr.make_net(7, 64, 2, 0.1).to(dev)
+    nnr.train(net, x, t, y, fm, fs, ym, ysd, T, T / N, 3, 1e-3)
+    cf, ex = nnr.pass2(S, K, r, T, True, net, fm, fs, ym, ysd, dropout_on=False)
+    out = nnr.pass2_fused(S, K, r, T, True, net, fm, fs, ym, ysd, dropout_on=False, want_state=True)
+    ref_price = float(cf.mean())
+    assert out["price"] == pytest.approx(ref_price, rel=2e-4)
+    exn = ex.cpu().numpy()
+    assert abs(int(out["n_exercised"]) - int(exn.sum())) <= 5e-4 * M
+    assert ((out["tex"] < N) != exn).mean() <= 5e-4
+    # value of each path at t = dt from (sx, tex) reproduces the torch cash-flows where decisions agree
+    disc = np.exp(-r * (T / N) * (out["tex"].astype(np.float64) - 1))
+    cf_h = np.maximum(K - out["sx"].astype(np.float64), 0) * disc
+    same = np.isclose(cf_h, cf.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    assert same.mean() >= 1 - 1e-3
+    # dropout on: another stream of masks than torch's, same distribution -> same price level
+    on = nnr.pass2_fused(S, K, r, T, True, net, fm, fs, ym, ysd, dropout_on=True)
+    cf_t, _ = nnr.pass2(S, K, r, T, True, net, fm, fs, ym, ysd, dropout_on=True)
+    assert on["price"] == pytest.approx(float(cf_t.mean()), abs=0.05)
+    assert on["pass2"] == "hip"
 
 
 def test_unsupported_shapes_and_bad_arguments(env, ctx):
