@@ -216,6 +216,25 @@ def main():
             dt = (time.perf_counter() - t1) / reps
             var[sem] = {"path_steps_per_s": M * N / dt, "ms_per_pricing": 1e3 * dt, "ms_lsm": o["ms_lsm"],
                         "price": o["price"]}
+        if a.model == "gbm":
+            # BASELINE config 5: the NN regressor (7->64->64->1) on the same paths x steps; the
+            # network is trained by the library's fused float32-MFMA kernels (omc_mlp_train_epoch)
+            from options_model_amd import nn_regressor as nnr
+            nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, seed=1, nn_epochs=2)  # warm
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            o = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, M, N, seed=42)
+            dt = time.perf_counter() - t1
+            tk = o.timings_ms.get("seconds_train_kernels", 0.0) * 1e-3
+            flop = 2 * (8 * 64 + 64 * 64 + 64) + 2 * 2 * 64 * 64 + 2 * 8 * 64  # per row: fwd, dH1, gW2, gW1
+            rows_seen = o.sum_nitm * o.info.get("epochs_run", 0)
+            var["nn_2x64"] = {"path_steps_per_s": M * N / dt, "seconds": dt, "price": o.price,
+                              "rows": o.sum_nitm, "train_kernel_seconds": tk, "info": o.info,
+                              "timings_ms": {k: round(v, 3) for k, v in o.timings_ms.items()}}
+            if rows_seen and tk > 0:
+                var["nn_2x64"]["train_mfma"] = {"bound": "mfma", "achieved": rows_seen * flop / tk / 1e12,
+                                                "peak": 157.3, "unit": "TFLOP/s",
+                                                "frac": rows_seen * flop / tk / 1e12 / 157.3}
         line["variants"] = var
 
     if rank == 0 and not dist_mode and not a.no_cpu_baseline:

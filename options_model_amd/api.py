@@ -44,6 +44,7 @@ class PriceResult:
     semantics: str
     option_type: str
     timings_ms: dict = field(default_factory=dict)
+    info: dict = field(default_factory=dict)  # regressor='nn': trainer, batch, epochs_run, optimizer_steps ...
 
     def __float__(self):
         return float(self.price)

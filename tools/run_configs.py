@@ -50,6 +50,8 @@ def main():
     if not only or "C5" in only:
         from options_model_amd import nn_regressor
         trainers = [t for t in ("hip", "torch") if not only or not ({"hip", "torch"} & only) or t in only]
+        # warm the process (torch import, HIP module load, allocator pools) on a small problem
+        nn_regressor.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, seed=1, nn_epochs=2)
         for trainer in trainers:
             t0 = time.perf_counter()
             res = nn_regressor.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 1_000_000, 252, seed=42,
