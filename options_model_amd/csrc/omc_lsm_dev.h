@@ -23,6 +23,18 @@ __device__ __forceinline__ void loadf(const float* __restrict__ p, float (&v)[VE
         v[0] = *p;
     }
 }
+// streaming variant: rows of S that this launch reads exactly once
+template <int VEC>
+__device__ __forceinline__ void loadf_stream(const float* __restrict__ p, float (&v)[VEC])
+{
+    if constexpr (VEC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 x = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+        v[0] = __builtin_nontemporal_load(p);
+    }
+}
 template <int VEC>
 __device__ __forceinline__ void loadi(const int32_t* __restrict__ p, int32_t (&v)[VEC])
 {
@@ -313,7 +325,7 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     }
     auto load_rows = [&](float (&buf)[TPW][VEC], int t) {
 #pragma unroll
-        for (int k = 0; k < TPW; ++k) loadf<VEC>(colp[k] + (int64_t)t * a.ld, buf[k]);
+        for (int k = 0; k < TPW; ++k) loadf_stream<VEC>(colp[k] + (int64_t)t * a.ld, buf[k]);
     };
     // Branch-free accumulation: an out-of-the-money (or padding) path contributes u = 0, p = 0
     // (adding +0.0 is exact, so the sums are those of the masked loop, bit for bit), and the
@@ -360,6 +372,8 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         const double s = wave_reduce8(acc, wl[wave]);
         if ((lane & 7) == 0) a.part1[((size_t)t * 8 + (lane >> 3)) * a.ntiles + tg] = s;
     };
+    // Rows are read with the nontemporal hint (each byte is used once per launch): 253 -> 218 us at
+    // C2; the same hint on pass 2 or on the generator's stores did nothing or lost a little.
     // Three rotating register buffers, rows fetched TWO steps ahead of their use; row indices are
     // clamped to the chunk, so every load is unconditional and the compiler can count them
     // (vmcnt(7..4) in the ISA instead of vmcnt(0)).  Measured (SQ counters):
