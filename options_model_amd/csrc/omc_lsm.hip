@@ -125,7 +125,7 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     const int tpw = (v4 && (tpw_env == 1 || tpw_env == 2 || tpw_env == 8)) ? tpw_env : 4;
     const int64_t per_wave = 64 * (int64_t)(v4 ? 4 : 1) * tpw;  // paths per wave per step
     a.ntiles = (p.M + per_wave - 1) / per_wave;
-    a.tchunk = (tch_env >= 2 && tch_env <= 64) ? tch_env : 16;
+    a.tchunk = (tch_env >= 2 && tch_env <= 64) ? tch_env : 32;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
     auto launch = [&](auto vec, auto tp) {
