@@ -46,6 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c",
                "-Wall", "-Wno-unused-function", os.path.join(CSRC, s), "-o", o]
+        cmd[1:1] = os.environ.get("OMC_HIPCC_FLAGS", "").split()  # experiments (-D..., -save-temps)
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd), flush=True)

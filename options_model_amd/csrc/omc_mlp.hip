@@ -18,6 +18,7 @@
 // No atomics: a training run is bitwise reproducible.
 #include "omc_device.h"
 #include "omc_kernels.h"
+#include <cstdlib>
 
 namespace omc {
 
@@ -32,13 +33,43 @@ constexpr int kOB3 = kOW3 + kH;        // [1]
 static_assert(kOB3 + 1 == kMlpParams, "parameter layout");
 
 constexpr int kLdW1 = 9, kLdW2 = 65;   // LDS leading dimensions (odd: conflict-free column walks)
-constexpr int kLdT = 36;               // staging [unit][row]: 32 rows + pad, 16-byte aligned rows
 constexpr int kLdsWeights = kH * kLdW1 + kH * kLdW2 + kH + kH + 4;
-constexpr int kLdsWave = 2 * kH * kLdT + 8 * kLdT;
-constexpr int kLdsFloats = kLdsWeights + 4 * kLdsWave;
-static_assert(kLdsWave > kMlpParams, "a wave's gradient vector is laid out in its staging patch");
+// Staging patches are [unit][32 rows] without padding; the row index is XOR-swizzled per unit in
+// units of 4 rows, so that the 16-byte row-quad reads of 16 consecutive units fall on 16 different
+// bank groups and a quad stays contiguous.  2 x 8 KB (H1, dZ) + 1 KB (X) per wave: 8 waves + the
+// weights fit the 160 KB of a CU, i.e. two waves per SIMD.  (The second patch holds H2, not dZ2:
+// the reading lane rebuilds dZ2 = [H2 > 0] w3 dout / keep from it and gets the w3 gradient from
+// the same values, which saves the 32 per-lane accumulators a register-side sum would need.)
+constexpr int kLdsWave = 2 * kH * 32 + 9 * 32;  // H1, H2 patches; X patch (8 inputs) + d(loss)/d(out) row
+constexpr int kGStride = 4864;  // per-wave gradient vector in the epilogue (>= kMlpParams + 1)
+constexpr int lds_floats(int waves) { return kLdsWeights + waves * kLdsWave; }
+static_assert(kGStride > kMlpParams && 4 * kGStride <= lds_floats(4) && 8 * kGStride <= lds_floats(8),
+              "the epilogue re-partitions the whole LDS allocation into one gradient vector per wave");
+static_assert(lds_floats(8) * 4 <= 160 * 1024, "LDS of one CU");
+
+__device__ __forceinline__ int st_idx(int unit, int row) { return unit * 32 + (row ^ (((unit >> 1) & 7) << 2)); }
+// The two access patterns of the kernel, written so that every address is one of four per-lane
+// registers plus a compile-time offset (an XOR with a lane-dependent value cannot be folded into
+// the instruction's immediate offset; left to itself hipcc keeps ~100 separate addresses live):
+//   write: unit = unit_of(mt, r, h), row = c        -> 32*unit_const(mt, r) + wr[((r >> 2) & 1) * 2 + ((r >> 1) & 1)]
+//   read : unit = c (+32), rows 16h + 4q .. + 3     -> 32*32*(unit >= 32) + rd[q]
+struct StageOfs { int wr[4], rd[4]; };
+__device__ __forceinline__ StageOfs stage_offsets(int c, int h)
+{
+    StageOfs o;
+    // swizzle of unit_of(mt, r, h): ((unit >> 1) & 7) = 4*((r >> 2) & 1) ^ 2*h ^ ((r >> 1) & 1)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) o.wr[v] = 128 * h + (c ^ (((4 * (v >> 1)) ^ (2 * h) ^ (v & 1)) << 2));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o.rd[q] = c * 32 + ((16 * h + 4 * q) ^ (((c >> 1) & 7) << 2));
+    return o;
+}
+// offset of unit_of(mt, r, h) without its h term (that one is in StageOfs::wr)
+__device__ __forceinline__ constexpr int unit_base(int mt, int r) { return 32 * (32 * mt + (r >> 2) * 8 + (r & 3)); }
+__device__ __forceinline__ constexpr int wr_sel(int r) { return ((r >> 2) & 1) * 2 + ((r >> 1) & 1); }
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // hidden unit held by accumulator register r of 32x32 tile mt in half-wave h
 __device__ __forceinline__ int unit_of(int mt, int r, int h) { return 32 * mt + (r >> 2) * 8 + 4 * h + (r & 3); }
@@ -59,6 +90,9 @@ __device__ __forceinline__ void wave_sync_lds()
 // One Philox block per (row, half-wave, layer, step) seeds two multiply-with-carry streams
 // (x <- a * lo32(x) + hi32(x): one v_mad_u64_u32 per 32 bits); 16 bits per unit, kept if
 // below keep16.
+// SCALE = false leaves the 1 / keep factor to the caller (the trainer folds it into the next
+// layer's weights).
+template <bool SCALE>
 __device__ __forceinline__ void relu_dropout(v16f (&z)[2], uint32_t row, uint32_t step, uint32_t tag,
                                              uint32_t keep16, float inv_keep, uint32_t k0, uint32_t k1)
 {
@@ -78,8 +112,8 @@ __device__ __forceinline__ void relu_dropout(v16f (&z)[2], uint32_t row, uint32_
             st[mt] = (uint64_t)4294957665u * (uint32_t)st[mt] + (st[mt] >> 32);
             const uint32_t w = (uint32_t)st[mt];
             const float v0 = z[mt][e], v1 = z[mt][e + 1];
-            z[mt][e] = (v0 > 0.0f && (w & 0xffffu) < keep16) ? v0 * inv_keep : 0.0f;
-            z[mt][e + 1] = (v1 > 0.0f && (w >> 16) < keep16) ? v1 * inv_keep : 0.0f;
+            z[mt][e] = (v0 > 0.0f && (w & 0xffffu) < keep16) ? (SCALE ? v0 * inv_keep : v0) : 0.0f;
+            z[mt][e + 1] = (v1 > 0.0f && (w >> 16) < keep16) ? (SCALE ? v1 * inv_keep : v1) : 0.0f;
         }
     }
 }
@@ -131,8 +165,10 @@ struct MlpTrainArgs {
     uint32_t keep16, step, k0, k1;
 };
 
-__global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mlp_train_kernel(MlpTrainArgs a)
 {
+    constexpr int NT = 64 * WAVES;
     extern __shared__ float lds[];
     float* sW1 = lds;
     float* sW2 = sW1 + kH * kLdW1;
@@ -141,32 +177,38 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
     float* sB3 = sW3 + kH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
     float* tH1 = lds + kLdsWeights + wave * kLdsWave;
-    float* tDZ = tH1 + kH * kLdT;
-    float* tX = tDZ + kH * kLdT;
+    float* tDZ = tH1 + kH * 32;
+    float* tX = tDZ + kH * 32;
 
-    for (int i = tid; i < kH * 8; i += 256) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[kOW1 + i];
-    for (int i = tid; i < kH * kH; i += 256) sW2[(i >> 6) * kLdW2 + (i & 63)] = a.params[kOW2 + i];
+    for (int i = tid; i < kH * 8; i += NT) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[kOW1 + i];
+    // Inverted dropout's 1 / keep is folded into the weights that consume the dropped activations
+    // (W2 and w3 are staged pre-multiplied), so activations carry the 0/1 mask only: with
+    // H' = mask * relu(Z), W2s = W2 / keep: Z2 = W2s H1' + b2, dZ1 = [H1' > 0] W2s^T dZ2, and the
+    // two gradients taken against H' (gW2, gw3) are multiplied by 1 / keep once, on the way out.
+    for (int i = tid; i < kH * kH; i += NT) sW2[(i >> 6) * kLdW2 + (i & 63)] = a.params[kOW2 + i] * a.inv_keep;
     if (tid < kH) {
         sB2[tid] = a.params[kOB2 + tid];
-        sW3[tid] = a.params[kOW3 + tid];
+        sW3[tid] = a.params[kOW3 + tid] * a.inv_keep;
     }
     if (tid == 0) sB3[0] = a.params[kOB3];
     __syncthreads();
 
-    v16f gW2[2][2], gW1[2], gw3[2];
+    v16f gW2[2][2];
+    v4f gW1[4];  // 16x16 tiles: units 16*mt4 + 4*(lane/16) + r, input column lane%16 (< 8 exist)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             gW2[i][0][r] = 0.0f;
             gW2[i][1][r] = 0.0f;
-            gW1[i][r] = 0.0f;
-            gw3[i][r] = 0.0f;
         }
     }
-    float gb2[2] = {0.0f, 0.0f}, gb3 = 0.0f, loss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gW1[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    float gb2[2] = {0.0f, 0.0f}, gw3[2] = {0.0f, 0.0f}, gb3 = 0.0f, loss = 0.0f;
 
-    const int nwaves = gridDim.x * 4;
+    const StageOfs so = stage_offsets(c, h);
+    const int nwaves = gridDim.x * WAVES;
     auto fetch = [&](int tile) {
         const int64_t r = (int64_t)tile * 32 + c;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -174,8 +216,8 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
             v = reinterpret_cast<const float4*>(a.data + shuffle_index(a.shuf, (uint64_t)(a.row0 + r)) * 8)[h];
         return v;
     };
-    float4 xnext = fetch(blockIdx.x * 4 + wave);
-    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += nwaves) {
+    float4 xnext = fetch(blockIdx.x * WAVES + wave);
+    for (int tile = blockIdx.x * WAVES + wave; tile < a.ntiles; tile += nwaves) {
         const int64_t row = (int64_t)tile * 32 + c;
         const bool live = row < a.nrows;
         const float4 xin = xnext;
@@ -184,10 +226,10 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
         if (h == 1) x.w = 1.0f;        // ... and its slot carries the bias input
         y = __shfl(y, c + 32, 64);
         wave_sync_lds();               // the previous tile's staging reads are done
-        tX[(4 * h + 0) * kLdT + c] = x.x;
-        tX[(4 * h + 1) * kLdT + c] = x.y;
-        tX[(4 * h + 2) * kLdT + c] = x.z;
-        tX[(4 * h + 3) * kLdT + c] = x.w;
+        tX[st_idx(4 * h + 0, c)] = x.x;
+        tX[st_idx(4 * h + 1, c)] = x.y;
+        tX[st_idx(4 * h + 2, c)] = x.z;
+        tX[st_idx(4 * h + 3, c)] = x.w;
 
         // ---- layer 1: Z1^T [64 x 32] = W1a [64 x 8] * Xa^T [8 x 32]; k-step s <-> inputs s, s+4
         v16f h1[2];
@@ -204,11 +246,11 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
         // next tile's rows: issued once this tile's are consumed (a wait on the older load would
         // otherwise drain this one too), in flight for the rest of the tile
         xnext = fetch(tile + nwaves);
-        relu_dropout(h1, (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
+        relu_dropout<false>(h1, (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tH1[unit_of(mt, r, h) * kLdT + c] = h1[mt][r];
+            for (int r = 0; r < 16; ++r) tH1[unit_base(mt, r) + so.wr[wr_sel(r)]] = h1[mt][r];
 
         // ---- layer 2: Z2^T = W2 * H1^T + b2; k-step (kt, s) <-> hidden units unit_of(kt, s, h)
         v16f h2[2];
@@ -226,8 +268,13 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
                 h2[1] = mfma(sW2[(32 + c) * kLdW2 + k], h1[kt][s], h2[1]);
             }
         }
-        relu_dropout(h2, (uint32_t)row, a.step, 0x200u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
+        relu_dropout<false>(h2, (uint32_t)row, a.step, 0x200u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
 
+        // ---- H2 to its patch (the weight-gradient products read it back unit-major)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tDZ[unit_base(mt, r) + so.wr[wr_sel(r)]] = h2[mt][r];
         // ---- output, loss, d(loss)/d(out)
         float o = 0.0f;
 #pragma unroll
@@ -241,38 +288,42 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
         if (h == 0) {
             loss = __builtin_fmaf(diff, diff, loss);
             gb3 += dout;
+            tX[8 * 32 + c] = dout;
         }
-        // ---- back through layer 2's activation; h2 becomes dZ2
+        // ---- back through layer 2's activation; h2 becomes dZ2 (B operand of the dH1 product)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float act = h2[mt][r];
-                gw3[mt][r] = __builtin_fmaf(dout, act, gw3[mt][r]);
-                const float dz = act > 0.0f ? sW3[unit_of(mt, r, h)] * dout * a.inv_keep : 0.0f;
-                h2[mt][r] = dz;
-                tDZ[unit_of(mt, r, h) * kLdT + c] = dz;
-            }
-        }
+            for (int r = 0; r < 16; ++r)
+                h2[mt][r] = h2[mt][r] > 0.0f ? sW3[unit_of(mt, r, h)] * dout : 0.0f;
         wave_sync_lds();
 
-        // ---- gW2 [i][k] += sum_rows dZ2[i][row] * H1[k][row]; k-step <-> rows 16h + 4q + j
+        // ---- gW2 [i][k] += sum_rows dZ2[i][row] * H1[k][row]; k-step <-> rows 16h + 4q + j.
+        // This lane owns units c and 32 + c here: dZ2 of those units is rebuilt from H2, and
+        // gw3 [i] += sum_rows dout[row] * H2[i][row], gb2 [i] += sum_rows dZ2[i][row] come along.
+        const float w3s0 = sW3[c], w3s1 = sW3[32 + c];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 a0 = *reinterpret_cast<const float4*>(tDZ + (c)*kLdT + 16 * h + 4 * q);
-            const float4 a1 = *reinterpret_cast<const float4*>(tDZ + (32 + c) * kLdT + 16 * h + 4 * q);
-            const float4 b0 = *reinterpret_cast<const float4*>(tH1 + (c)*kLdT + 16 * h + 4 * q);
-            const float4 b1 = *reinterpret_cast<const float4*>(tH1 + (32 + c) * kLdT + 16 * h + 4 * q);
-            gb2[0] += (a0.x + a0.y) + (a0.z + a0.w);
-            gb2[1] += (a1.x + a1.y) + (a1.z + a1.w);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float4 e0 = *reinterpret_cast<const float4*>(tDZ + so.rd[q]);
+            const float4 e1 = *reinterpret_cast<const float4*>(tDZ + 32 * 32 + so.rd[q]);
+            const float4 dq = *reinterpret_cast<const float4*>(tX + 8 * 32 + 16 * h + 4 * q);
+            const float4 b0 = *reinterpret_cast<const float4*>(tH1 + so.rd[q]);
+            const float4 b1 = *reinterpret_cast<const float4*>(tH1 + 32 * 32 + so.rd[q]);
+            const float hv0[4] = {e0.x, e0.y, e0.z, e0.w}, hv1[4] = {e1.x, e1.y, e1.z, e1.w};
+            const float dv[4] = {dq.x, dq.y, dq.z, dq.w};
             const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                gW2[0][0] = mfma(av0[j], bv0[j], gW2[0][0]);
-                gW2[0][1] = mfma(av0[j], bv1[j], gW2[0][1]);
-                gW2[1][0] = mfma(av1[j], bv0[j], gW2[1][0]);
-                gW2[1][1] = mfma(av1[j], bv1[j], gW2[1][1]);
+                gw3[0] = __builtin_fmaf(dv[j], hv0[j], gw3[0]);
+                gw3[1] = __builtin_fmaf(dv[j], hv1[j], gw3[1]);
+                const float av0 = hv0[j] > 0.0f ? w3s0 * dv[j] : 0.0f;
+                const float av1 = hv1[j] > 0.0f ? w3s1 * dv[j] : 0.0f;
+                gb2[0] += av0;
+                gb2[1] += av1;
+                gW2[0][0] = mfma(av0, bv0[j], gW2[0][0]);
+                gW2[0][1] = mfma(av0, bv1[j], gW2[0][1]);
+                gW2[1][0] = mfma(av1, bv0[j], gW2[1][0]);
+                gW2[1][1] = mfma(av1, bv1[j], gW2[1][1]);
             }
         }
 
@@ -296,38 +347,42 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                tDZ[unit_of(mt, r, h) * kLdT + c] = h1[mt][r] > 0.0f ? d1[mt][r] * a.inv_keep : 0.0f;
+                tDZ[unit_base(mt, r) + so.wr[wr_sel(r)]] = h1[mt][r] > 0.0f ? d1[mt][r] : 0.0f;
         wave_sync_lds();
 
-        // ---- gW1a [i][n] += sum_rows dZ1[i][row] * Xa[n][row]; only columns n < 8 exist
+        // ---- gW1a [i][n] += sum_rows dZ1[i][row] * Xa[n][row]; only input columns n < 8 exist, so
+        // this product runs on 16x16x4 tiles (unit = lane%16 + 16*mt4, column = lane%16); k-slot
+        // kq = lane/16 of step s stands for row 8*kq + s: a lane reads its 8 rows as two quads
+        {
+            const int l16 = lane & 15, kq = lane >> 4, sw = ((l16 >> 1) & 7) << 2;
+            const int o0 = l16 * 32 + ((8 * kq) ^ sw), o1 = l16 * 32 + ((8 * kq + 4) ^ sw);
+            float4 bq0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), bq1 = bq0;
+            if (l16 < 8) {
+                bq0 = *reinterpret_cast<const float4*>(tX + o0);
+                bq1 = *reinterpret_cast<const float4*>(tX + o1);
+            }
+            const float bv[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
+            float av[4][8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 a0 = *reinterpret_cast<const float4*>(tDZ + (c)*kLdT + 16 * h + 4 * q);
-            const float4 a1 = *reinterpret_cast<const float4*>(tDZ + (32 + c) * kLdT + 16 * h + 4 * q);
-            float4 b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (c < 8) b = *reinterpret_cast<const float4*>(tX + c * kLdT + 16 * h + 4 * q);
-            gW1[0] = mfma(a0.x, b.x, gW1[0]);
-            gW1[1] = mfma(a1.x, b.x, gW1[1]);
-            gW1[0] = mfma(a0.y, b.y, gW1[0]);
-            gW1[1] = mfma(a1.y, b.y, gW1[1]);
-            gW1[0] = mfma(a0.z, b.z, gW1[0]);
-            gW1[1] = mfma(a1.z, b.z, gW1[1]);
-            gW1[0] = mfma(a0.w, b.w, gW1[0]);
-            gW1[1] = mfma(a1.w, b.w, gW1[1]);
+            for (int mt4 = 0; mt4 < 4; ++mt4) {
+                const float4 aq0 = *reinterpret_cast<const float4*>(tDZ + 16 * 32 * mt4 + o0);
+                const float4 aq1 = *reinterpret_cast<const float4*>(tDZ + 16 * 32 * mt4 + o1);
+                av[mt4][0] = aq0.x; av[mt4][1] = aq0.y; av[mt4][2] = aq0.z; av[mt4][3] = aq0.w;
+                av[mt4][4] = aq1.x; av[mt4][5] = aq1.y; av[mt4][6] = aq1.z; av[mt4][7] = aq1.w;
+            }
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8)  // the four tiles take turns: no MFMA waits for the one before it
+#pragma unroll
+                for (int mt4 = 0; mt4 < 4; ++mt4)
+                    gW1[mt4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt4][s8], bv[s8], gW1[mt4], 0, 0, 0);
         }
     }
 
-    // ---- per-lane partials -> per-wave sums
+    // ---- per-lane partials -> per-wave sums (a lane holds the rows of its half-wave only)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = gw3[mt][r];
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-            gw3[mt][r] = v;
-        }
         gb2[mt] += __shfl_xor(gb2[mt], 32, 64);
+        gw3[mt] += __shfl_xor(gw3[mt], 32, 64);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -335,31 +390,42 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
         loss += __shfl_xor(loss, m, 64);
     }
 
-    // ---- every wave lays its gradient vector out in its own staging patch (plain stores, nothing
-    // to wait for), then the workgroup adds the four copies in wave order on the way out
-    float* G = tH1;
-    wave_sync_lds();  // this wave's last staging reads are done
+    // ---- the whole LDS allocation (weights are no longer needed) is re-cut into one gradient
+    // vector per wave: plain stores, nothing to wait for; then the workgroup adds the copies in
+    // wave order on the way out
+    __syncthreads();
+    float* G = lds + wave * kGStride;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = unit_of(mi, r, h);
-            G[kOW2 + i * kH + c] = gW2[mi][0][r];
-            G[kOW2 + i * kH + 32 + c] = gW2[mi][1][r];
-            if (c < 8) G[kOW1 + i * 8 + c] = gW1[mi][r];
-            if (c == 0) G[kOW3 + i] = gw3[mi][r];
+            G[kOW2 + i * kH + c] = gW2[mi][0][r] * a.inv_keep;
+            G[kOW2 + i * kH + 32 + c] = gW2[mi][1][r] * a.inv_keep;
         }
-        if (h == 0) G[kOB2 + 32 * mi + c] = gb2[mi];
+        if (h == 0) {
+            G[kOB2 + 32 * mi + c] = gb2[mi];
+            G[kOW3 + 32 * mi + c] = gw3[mi] * a.inv_keep;
+        }
+    }
+    if ((lane & 15) < 8) {
+#pragma unroll
+        for (int mt4 = 0; mt4 < 4; ++mt4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) G[kOW1 + (16 * mt4 + 4 * (lane >> 4) + r) * 8 + (lane & 15)] = gW1[mt4][r];
     }
     if (lane == 0) {
         G[kOB3] = gb3;
         G[kMlpParams] = loss;
     }
     __syncthreads();
-    const float* G0 = lds + kLdsWeights;
     float* out = a.partial + (size_t)blockIdx.x * kMlpPartialStride;
-    for (int i = tid; i <= kMlpParams; i += 256)
-        out[i] = ((G0[i] + G0[kLdsWave + i]) + G0[2 * kLdsWave + i]) + G0[3 * kLdsWave + i];
+    for (int i = tid; i <= kMlpParams; i += NT) {
+        float g = lds[i];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) g += lds[w * kGStride + i];
+        out[i] = g;
+    }
 }
 
 struct MlpAdamArgs {
@@ -546,7 +612,7 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
             h1[mt] = mfma(wr[2], xin.z, h1[mt]);
             h1[mt] = mfma(wr[3], xin.w, h1[mt]);
         }
-        relu_dropout(h1, (uint32_t)p, (uint32_t)t, 0x300u + (uint32_t)h + 2u * (uint32_t)(p >> 32), a.keep16,
+        relu_dropout<true>(h1, (uint32_t)p, (uint32_t)t, 0x300u + (uint32_t)h + 2u * (uint32_t)(p >> 32), a.keep16,
                      a.inv_keep, a.k0, a.k1);
         v16f h2[2];
 #pragma unroll
@@ -562,7 +628,7 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
                 h2[1] = mfma(sW2[(32 + c) * kLdW2 + k], h1[kt][s], h2[1]);
             }
         }
-        relu_dropout(h2, (uint32_t)p, (uint32_t)t, 0x400u + (uint32_t)h + 2u * (uint32_t)(p >> 32), a.keep16,
+        relu_dropout<true>(h2, (uint32_t)p, (uint32_t)t, 0x400u + (uint32_t)h + 2u * (uint32_t)(p >> 32), a.keep16,
                      a.inv_keep, a.k0, a.k1);
         float o = 0.0f;
 #pragma unroll
@@ -645,10 +711,18 @@ hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, 
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
 {
     static bool attr_set = false;
-    const size_t lds_bytes = sizeof(float) * (size_t)kLdsFloats;
+    // workgroup size: 4 waves (one per SIMD).  OMC_MLP_WAVES=8 runs two per SIMD; measured no
+    // faster: float32 MFMA executes on the SIMD's float32 lanes (it has the vector rate), so a
+    // second wave's vector arithmetic cannot run underneath it
+    static const int waves = (getenv("OMC_MLP_WAVES") && atoi(getenv("OMC_MLP_WAVES")) == 8) ? 8 : 4;
+    const size_t lds_bytes = sizeof(float) * (size_t)lds_floats(waves);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_kernel<4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(float) * lds_floats(4)));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_kernel<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * lds_floats(8)));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -671,9 +745,10 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         a.step = (uint32_t)step;
         a.k0 = (uint32_t)t.seed;
         a.k1 = (uint32_t)(t.seed >> 32);
-        int groups = (a.ntiles + 3) / 4;
+        int groups = (a.ntiles + waves - 1) / waves;
         if (groups > kMlpMaxGroups) groups = kMlpMaxGroups;
-        hipLaunchKernelGGL(mlp_train_kernel, dim3(groups), dim3(256), lds_bytes, st, a);
+        if (waves == 4) hipLaunchKernelGGL(mlp_train_kernel<4>, dim3(groups), dim3(256), lds_bytes, st, a);
+        else hipLaunchKernelGGL(mlp_train_kernel<8>, dim3(groups), dim3(512), lds_bytes, st, a);
         MlpAdamArgs b;
         b.params = t.params;
         b.m = t.adam_m;
