@@ -168,7 +168,8 @@ int omc_heston_price_strikes(omc_ctx* ctx, int64_t n_paths, int n_steps, double 
 /* replaces the minibatch loop of price_american_enhanced_lsm (options_model_3.py:565-600:
  * SingleLSMNet(7, hidden, layers) :85-103, nn.MSELoss, optim.Adam(lr, weight_decay), shuffled
  * minibatches) for the network BASELINE config 5 names, 7 -> 64 -> 64 -> 1 (hidden = 64,
- * layers = 2; anything else returns -9).  One call = one epoch over `n_rows` rows of
+ * layers = 2; anything else returns -9; omc_mlp_param_count also knows the shapes that only
+ * omc_lsm_apply_mlp supports).  One call = one epoch over `n_rows` rows of
  * `data` ([n_rows][8] float32 device memory: 7 normalised features + normalised target):
  * ceil(n_rows / batch) optimizer steps of float32 MFMA forward/backward + Adam.  The epoch
  * visits the rows in a pseudo-random permutation keyed by `shuffle_key` (a Feistel network with
@@ -186,7 +187,12 @@ int omc_mlp_param_count(int hidden, int layers);
  * max(x-1,0), s, x*s] of x = S/K normalised with (feat_mean, feat_std) (host, 7 each), network
  * output scaled back by y_std, y_mean; exercise where payoff > continuation; dropout (> 0) stays
  * active as in the reference, which never calls .eval() on this net; cash-flows valued at
- * t = dt.  params: device, omc_mlp_train_epoch's layout.  Optional sx_out / tex_out (host). */
+ * t = dt.  Networks: SingleLSMNet(7, hidden, layers) with hidden in {64, 128} and layers in
+ * {2, 3} -- the reference's default is (128, 3), options_model_3.py:87 -- anything else: -9.
+ * params (device, omc_mlp_param_count(hidden, layers) floats): W1|b1 as [hidden][8] (bias in
+ * column 7), then per further hidden layer W [hidden][hidden] and b [hidden], then the output
+ * weights [hidden] and bias [1]; for (64, 2) this is omc_mlp_train_epoch's layout.
+ * Optional sx_out / tex_out (host). */
 int omc_lsm_apply_mlp(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
                       double r, double T, int is_put, int hidden, int layers, const float* params,
                       const double* feat_mean, const double* feat_std, double y_mean, double y_std,

@@ -748,10 +748,7 @@ int omc_price_european_batch(omc_ctx* c, const omc_params* p, int n, omc_result*
     return run_batch(c, p, n, res, false);
 }
 
-int omc_mlp_param_count(int hidden, int layers)
-{
-    return (hidden == 64 && layers == 2) ? omc::kMlpParams : -1;
-}
+int omc_mlp_param_count(int hidden, int layers) { return omc::mlp_apply_param_count(hidden, layers); }
 
 int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
                       double r, double T, int is_put, int hidden, int layers, const float* params,
@@ -764,7 +761,7 @@ int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
     if (omc_mlp_param_count(hidden, layers) < 0)
-        return fail(-9, "the network kernels support hidden = 64, layers = 2 only.");
+        return fail(-9, "pass 2 supports hidden = 64 or 128 with 2 or 3 hidden layers.");
     if (!params || !feat_mean || !feat_std || !res) return fail(-7, "null pointer.");
     if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
     for (int i = 0; i < 7; ++i)
@@ -772,8 +769,8 @@ int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
     omc::LsmWorkspace w;
     if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w))) return rc;
     omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
-    HIP_TRY(omc::mlp_apply_pass2(c->stream, p, params, feat_mean, feat_std, y_mean, y_std, dropout, seed,
-                                 w.sx, w.tex));
+    HIP_TRY(omc::mlp_apply_pass2(c->stream, p, hidden, layers, params, feat_mean, feat_std, y_mean, y_std,
+                                 dropout, seed, w.sx, w.tex));
     HIP_TRY(omc::lsm_final_reduce(c->stream, p, w, 1));
     HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
     if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
@@ -816,7 +813,7 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
 {
     int rc = bind(c);
     if (rc) return rc;
-    if (omc_mlp_param_count(hidden, layers) < 0)
+    if (hidden != 64 || layers != 2)
         return fail(-9, "the fused trainer supports hidden = 64, layers = 2 only.");
     if (!data || !params || !adam_m || !adam_v || !step || !mean_loss) return fail(-7, "null pointer.");
     if (n_rows <= 0 || batch <= 0 || *step < 0) return fail(-3, "n_rows, batch must be positive.");

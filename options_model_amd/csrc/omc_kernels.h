@@ -108,9 +108,11 @@ struct MlpTrainPlan {
 };
 size_t mlp_partial_bytes();
 // pass 2 of the NN flow: sticky sweep with the network as continuation value -> (sx, tex)
-hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, const float* params, const double* feat_mean,
-                           const double* feat_std, double y_mean, double y_std, double dropout, uint64_t seed,
-                           float* sx, int32_t* tex);
+// hidden in {64, 128}, layers (hidden layers) in {2, 3}; mlp_apply_param_count: floats, -1 otherwise
+int mlp_apply_param_count(int hidden, int layers);
+hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, int hidden, int layers, const float* params,
+                           const double* feat_mean, const double* feat_std, double y_mean, double y_std,
+                           double dropout, uint64_t seed, float* sx, int32_t* tex);
 // float64 means / population variances of the regression features and the target over n rows
 size_t nn_stats_scratch_bytes();
 hipError_t nn_feature_stats(hipStream_t st, const double* x, const int32_t* t, const double* y, int64_t n,

@@ -553,22 +553,50 @@ struct MlpApplyArgs {
     int ntiles;
 };
 
+// Flat parameter layout for any (H hidden units, L hidden layers): W1|b1 as [H][8], then for
+// every further hidden layer its weights [H][H] and bias [H], then the output weights [H] and
+// bias [1].  (64, 2) is the trainer's layout above.
+__host__ __device__ constexpr int mlp_params_of(int H, int L) { return H * 8 + (L - 1) * (H * H + H) + H + 1; }
+__host__ __device__ constexpr int apply_lds_floats(int H, int L)
+{
+    return H * kLdW1 + (L - 1) * (H * (H + 1) + H) + H + 4;
+}
+
+// ReLU + inverted dropout over NT 32-unit tiles; one Philox block seeds the two streams of a
+// tile pair.
+template <int NT>
+__device__ __forceinline__ void relu_dropout_n(v16f (&z)[NT], uint32_t row, uint32_t step, uint32_t tag,
+                                               uint32_t keep16, float inv_keep, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int p = 0; p < NT; p += 2) {
+        v16f pair[2] = {z[p], z[p + 1]};
+        relu_dropout<true>(pair, row, step, tag + 0x1000u * (uint32_t)p, keep16, inv_keep, k0, k1);
+        z[p] = pair[0];
+        z[p + 1] = pair[1];
+    }
+}
+
+template <int H, int L>
 __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
 {
-    __shared__ float sw[kLdsWeights];
-    float* sW1 = sw;
-    float* sW2 = sW1 + kH * kLdW1;
-    float* sB2 = sW2 + kH * kLdW2;
-    float* sW3 = sB2 + kH;
-    float* sB3 = sW3 + kH;
+    constexpr int NT = H / 32, LDW = H + 1;
+    extern __shared__ float sw[];
+    float* sW1 = sw;                       // [H][9]
+    float* sWh = sW1 + H * kLdW1;          // (L-1) x { [H][H+1], bias [H] }
+    float* sWo = sWh + (L - 1) * (H * LDW + H);
+    float* sBo = sWo + H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    for (int i = tid; i < kH * 8; i += 256) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[kOW1 + i];
-    for (int i = tid; i < kH * kH; i += 256) sW2[(i >> 6) * kLdW2 + (i & 63)] = a.params[kOW2 + i];
-    if (tid < kH) {
-        sB2[tid] = a.params[kOB2 + tid];
-        sW3[tid] = a.params[kOW3 + tid];
+    for (int i = tid; i < H * 8; i += 256) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[i];
+#pragma unroll
+    for (int l = 0; l < L - 1; ++l) {
+        const float* src = a.params + H * 8 + l * (H * H + H);
+        float* dst = sWh + l * (H * LDW + H);
+        for (int i = tid; i < H * H; i += 256) dst[(i / H) * LDW + (i % H)] = src[i];
+        for (int i = tid; i < H; i += 256) dst[H * LDW + i] = src[H * H + i];
     }
-    if (tid == 0) sB3[0] = a.params[kOB3];
+    for (int i = tid; i < H; i += 256) sWo[i] = a.params[H * 8 + (L - 1) * (H * H + H) + i];
+    if (tid == 0) sBo[0] = a.params[H * 8 + (L - 1) * (H * H + H) + H];
     __syncthreads();
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= a.ntiles) return;  // whole wave; no barrier below
@@ -576,6 +604,7 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
     const bool live = p < a.M;
     const float* col = a.S + (live ? p : a.M - 1);
     const double K = a.K;
+    const uint32_t rtag = (uint32_t)h + 2u * (uint32_t)(p >> 32);
     float sx = col[(int64_t)a.N * a.ld];
     int tex = a.N;
     bool done = !live;
@@ -601,42 +630,48 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
             xin.z = (float)((x * st - a.fm[6]) * a.rs[6]);
             xin.w = 1.0f;  // bias input
         }
-        v16f h1[2];
+        v16f act[NT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < NT; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h1[mt][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) act[mt][r] = 0.0f;
             const float* wr = sW1 + (32 * mt + c) * kLdW1 + 4 * h;
-            h1[mt] = mfma(wr[0], xin.x, h1[mt]);
-            h1[mt] = mfma(wr[1], xin.y, h1[mt]);
-            h1[mt] = mfma(wr[2], xin.z, h1[mt]);
-            h1[mt] = mfma(wr[3], xin.w, h1[mt]);
+            act[mt] = mfma(wr[0], xin.x, act[mt]);
+            act[mt] = mfma(wr[1], xin.y, act[mt]);
+            act[mt] = mfma(wr[2], xin.z, act[mt]);
+            act[mt] = mfma(wr[3], xin.w, act[mt]);
         }
-        relu_dropout<true>(h1, (uint32_t)p, (uint32_t)t, 0x300u + (uint32_t)h + 2u * (uint32_t)(p >> 32), a.keep16,
-                     a.inv_keep, a.k0, a.k1);
-        v16f h2[2];
+        relu_dropout_n<NT>(act, (uint32_t)p, (uint32_t)t, 0x300u + rtag, a.keep16, a.inv_keep, a.k0, a.k1);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int l = 0; l < L - 1; ++l) {
+            const float* W = sWh + l * (H * LDW + H);
+            const float* B = W + H * LDW;
+            v16f nxt[NT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h2[mt][r] = sB2[unit_of(mt, r, h)];
+            for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+                for (int r = 0; r < 16; ++r) nxt[mt][r] = B[unit_of(mt, r, h)];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int k = unit_of(kt, s, h);
-                h2[0] = mfma(sW2[(c)*kLdW2 + k], h1[kt][s], h2[0]);
-                h2[1] = mfma(sW2[(32 + c) * kLdW2 + k], h1[kt][s], h2[1]);
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int k = unit_of(kt, s, h);
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt) nxt[mt] = mfma(W[(32 * mt + c) * LDW + k], act[kt][s], nxt[mt]);
+                }
             }
+            relu_dropout_n<NT>(nxt, (uint32_t)p, (uint32_t)t, 0x400u + 0x100u * (uint32_t)l + rtag, a.keep16,
+                               a.inv_keep, a.k0, a.k1);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) act[mt] = nxt[mt];
         }
-        relu_dropout<true>(h2, (uint32_t)p, (uint32_t)t, 0x400u + (uint32_t)h + 2u * (uint32_t)(p >> 32), a.keep16,
-                     a.inv_keep, a.k0, a.k1);
         float o = 0.0f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o = __builtin_fmaf(sW3[unit_of(mt, r, h)], h2[mt][r], o);
+            for (int r = 0; r < 16; ++r) o = __builtin_fmaf(sWo[unit_of(mt, r, h)], act[mt][r], o);
         o += __shfl_xor(o, 32, 64);
-        o += sB3[0];
+        o += sBo[0];
         const double cont = (double)o * a.ysd + a.ym;
         if (need && imm > cont) {
             done = true;
@@ -769,9 +804,30 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
     return hipGetLastError();
 }
 
-hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, const float* params, const double* feat_mean,
-                           const double* feat_std, double y_mean, double y_std, double dropout, uint64_t seed,
-                           float* sx, int32_t* tex)
+int mlp_apply_param_count(int hidden, int layers)
+{
+    if ((hidden != 64 && hidden != 128) || (layers != 2 && layers != 3)) return -1;
+    return mlp_params_of(hidden, layers);
+}
+
+template <int H, int L>
+static hipError_t launch_apply(hipStream_t st, const MlpApplyArgs& a)
+{
+    static bool attr_set = false;
+    const size_t lds_bytes = sizeof(float) * (size_t)apply_lds_floats(H, L);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_apply_kernel<H, L>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_apply_kernel<H, L>), dim3((unsigned)((a.ntiles + 3) / 4)), dim3(256), lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, int hidden, int layers, const float* params,
+                           const double* feat_mean, const double* feat_std, double y_mean, double y_std,
+                           double dropout, uint64_t seed, float* sx, int32_t* tex)
 {
     MlpApplyArgs a;
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
@@ -786,10 +842,12 @@ hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, const float* par
     a.keep16 = dropout > 0.0 ? (uint32_t)llround((1.0 - dropout) * 65536.0) : 65536u;
     a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
-    const int64_t ntiles = (p.M + 31) / 32;
-    a.ntiles = (int)ntiles;
-    hipLaunchKernelGGL(mlp_apply_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a);
-    return hipGetLastError();
+    a.ntiles = (int)((p.M + 31) / 32);
+    if (hidden == 64 && layers == 2) return launch_apply<64, 2>(st, a);
+    if (hidden == 64 && layers == 3) return launch_apply<64, 3>(st, a);
+    if (hidden == 128 && layers == 2) return launch_apply<128, 2>(st, a);
+    if (hidden == 128 && layers == 3) return launch_apply<128, 3>(st, a);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace omc

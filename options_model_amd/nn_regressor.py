@@ -204,22 +204,43 @@ class _GraphedStep:
         return self._eager(batch)
 
 
+def _linear_shape(net):
+    """-> (hidden, hidden_layers) of a SingleLSMNet(7, hidden, layers), else None."""
+    torch = _torch()
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    dims = [(m.in_features, m.out_features) for m in lin]
+    if len(dims) < 2 or dims[0][0] != 7 or dims[-1][1] != 1:
+        return None
+    H = dims[0][1]
+    if any(d != (H, H) for d in dims[1:-1]) or dims[-1][0] != H:
+        return None
+    return H, len(dims) - 1
+
+
 def fused_trainer_supports(net):
     """The hand-written trainer (omc_mlp_train_epoch) covers the network BASELINE config 5
     names: 7 -> 64 -> 64 -> 1."""
-    torch = _torch()
-    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
-    return [(m.in_features, m.out_features) for m in lin] == [(7, 64), (64, 64), (64, 1)]
+    return _linear_shape(net) == (64, 2)
+
+
+def fused_apply_supports(net):
+    """The pass-2 kernel (omc_lsm_apply_mlp) covers 64 or 128 hidden units x 2 or 3 hidden layers,
+    i.e. also the reference's own SingleLSMNet defaults (3 x 128, options_model_3.py:87)."""
+    return _linear_shape(net) in ((64, 2), (64, 3), (128, 2), (128, 3))
 
 
 def flatten_params(net):
-    """torch SingleLSMNet(7, 64, 2) -> the library's flat float32 layout: W1|b1 as [64][8] (bias
-    in column 7), W2 [64][64], b2 [64], w3 [64], b3 [1] (include/omc.h, omc_mlp_train_epoch)."""
+    """torch SingleLSMNet -> the library's flat float32 layout (include/omc.h): W1|b1 as [H][8]
+    (bias in column 7), then per further hidden layer W [H][H] and b [H], then the output weights
+    [H] and bias [1]."""
     torch = _torch()
-    l1, l2, l3 = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
     with torch.no_grad():
-        return torch.cat([torch.cat([l1.weight, l1.bias[:, None]], dim=1).reshape(-1), l2.weight.reshape(-1),
-                          l2.bias, l3.weight.reshape(-1), l3.bias]).float().contiguous()
+        parts = [torch.cat([lin[0].weight, lin[0].bias[:, None]], dim=1).reshape(-1)]
+        for m in lin[1:-1]:
+            parts += [m.weight.reshape(-1), m.bias]
+        parts += [lin[-1].weight.reshape(-1), lin[-1].bias]
+        return torch.cat(parts).float().contiguous()
 
 
 def unflatten_params(net, flat):
@@ -388,12 +409,14 @@ def pass2_fused(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, want_
     dev = S.device
     N, M = S.shape[0] - 1, S.shape[1]
     ctx = _ctx_on_torch_stream(dev.index or 0)
+    H, L = _linear_shape(net)
     params = flatten_params(net)
     seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     torch.cuda.current_stream(dev).synchronize()
     out = ctx.lsm_apply_mlp(S.data_ptr(), S.stride(0), M, N, K, r, T, is_put, params.data_ptr(),
                             fm.cpu().numpy(), fs.cpu().numpy(), float(ym), float(ysd),
-                            _dropout_of(net) if dropout_on else 0.0, seed, want_state=want_state)
+                            _dropout_of(net) if dropout_on else 0.0, seed, want_state=want_state,
+                            hidden=H, layers=L)
     res = dict(price=out["price"], std=out["std"], n_exercised=out["n_exercised"], zero_prob=out["zero_prob"],
                pass2="hip")
     if want_state:
@@ -425,7 +448,7 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
     info = train(net, x, t, y, fm, fs, ym, ysd, T, dt, nn_epochs, nn_lr, nn_batch, verbose, trainer=trainer)
     torch.cuda.synchronize(S.device)
     t2 = time.perf_counter()
-    if trainer != "torch" and fused_trainer_supports(net):
+    if trainer != "torch" and fused_apply_supports(net):
         res = pass2_fused(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
     else:
         cf, ex = pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)

@@ -256,7 +256,8 @@ def test_unsupported_shapes_and_bad_arguments(env, ctx):
     torch, nnr, dev = env
     lib = ctx.lib
     assert lib.omc_mlp_param_count(64, 2) == 4737
-    assert lib.omc_mlp_param_count(128, 3) == -1
+    assert lib.omc_mlp_param_count(128, 3) == 128 * 8 + 2 * (128 * 128 + 128) + 128 + 1
+    assert lib.omc_mlp_param_count(32, 2) == -1 and lib.omc_mlp_param_count(64, 4) == -1
     d = torch.zeros(64, 8, device=dev)
     p = torch.zeros(4737, device=dev)
     with pytest.raises(ValueError, match="hidden = 64"):

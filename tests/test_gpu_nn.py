@@ -59,6 +59,39 @@ def test_pass2_with_reference_weights_reproduces_reference_decisions(torch_cuda,
     assert np.allclose(cf.cpu().numpy()[same], nn[f"{tag}_cf_eval"][same], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("tag", ["gbm_put", "heston_call"])
+def test_hip_pass2_with_reference_weights_reproduces_reference_decisions(torch_cuda, golden, tag):
+    """The library's own pass-2 kernel (omc_lsm_apply_mlp, float32 MFMA) on the reference's trained
+    network (3 x 128 for gbm_put -- its default shape -- and 3 x 64 for heston_call), normalisers and
+    paths: the reference's eval-mode exercise decisions and price come back.  Paths go through
+    float32 here (the kernels' storage type), so a path whose payoff sits within rounding of its
+    continuation value may flip."""
+    torch = torch_cuda
+    from options_model_amd import nn_regressor as nr
+    nn = golden["nn"]
+    S0, K, r, sig, T, is_put, hidden = nn[f"{tag}_params"]
+    S = torch.from_numpy(nn[f"{tag}_S"]).float().cuda().contiguous()
+    net = _load_net(torch, nn, tag, hidden)
+    assert nr.fused_apply_supports(net) and not nr.fused_trainer_supports(net)
+    fm = torch.from_numpy(nn[f"{tag}_feat_mean"]).cuda()
+    fs = torch.from_numpy(nn[f"{tag}_feat_std"]).cuda()
+    ym, ysd = (torch.tensor(v, dtype=torch.float64, device="cuda") for v in nn[f"{tag}_Y_mean_std"])
+    out = nr.pass2_fused(S, K, r, T, bool(is_put), net, fm, fs, ym, ysd, dropout_on=False, want_state=True)
+    N = S.shape[0] - 1
+    ex = out["tex"] < N
+    flips = int((ex != nn[f"{tag}_ex_eval"]).sum())
+    assert flips <= 3, flips
+    ref = float(nn[f"{tag}_price_eval"])
+    assert abs(out["price"] - ref) <= 2e-3 * ref
+    same = ex == nn[f"{tag}_ex_eval"]
+    disc = np.exp(-r * (T / N) * (out["tex"].astype(np.float64) - 1))
+    pay = np.maximum((K - out["sx"].astype(np.float64)) if is_put else (out["sx"].astype(np.float64) - K), 0)
+    assert np.allclose((pay * disc)[same], nn[f"{tag}_cf_eval"][same], rtol=0, atol=2e-5)  # float32 S: half an ulp at S ~ 150 is 8e-6
+    # the continuation values themselves: replay the reference's recorded eval-mode outputs
+    on = nr.pass2_fused(S, K, r, T, bool(is_put), net, fm, fs, ym, ysd, dropout_on=True)
+    assert abs(on["price"] - float(nn[f"{tag}_price_ref"])) <= 0.05 * ref  # other dropout stream
+
+
 def test_config1_nn_end_to_end_band(torch_cuda, golden):
     """10k x 50 ATM put, reference hyper-parameters (128x3, 25 epochs, batch 256).  The
     reference's own answer moves from seed to seed (6.81 for RNGManager(42); 7.29 / 6.96 / 7.19
