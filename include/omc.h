@@ -209,6 +209,21 @@ int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t
                         double dropout, uint64_t seed, uint64_t shuffle_key, double* mean_loss);
 int omc_mlp_shuffle_indices(omc_ctx* ctx, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device);
 
+/* ---- local-vol paths through the implied-vol network ------------------------ */
+/* replaces simulate_local_vol_paths_antithetic (options_model_3.py:300-333) together with the
+ * IVModel.get_volatility_batch call it makes every step (:263-298): S_t = S_{t-1} exp((r -
+ * sigma^2/2) dt + sigma sqrt(dt) z) with sigma = ImprovedIVNetwork(log(K/S)/m_scale, tau/tau_scale)
+ * (NN_training_stock_iv.py:109-155; hidden_dim 64, `layers` residual LayerNorm/GELU blocks),
+ * clamped at `epsilon` and 1e-6, evaluated inside the kernel on the matrix cores.  S: device
+ * [n_steps+1][ld] float32, antithetic partner of column j is j + n_paths/2; Z: device
+ * [n_steps][n_paths/2] float32 normals (omc_gbm_normals_f32 makes them, or inject your own).
+ * params (device, omc_localvol_param_count floats): input_proj as [64][4] (w_m, w_tau, bias, 0),
+ * per block Linear W [64][64], b [64], LayerNorm gamma [64], beta [64], then output w [64], b. */
+int omc_localvol_param_count(int hidden, int layers);
+int omc_localvol_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, int n_steps, double S0,
+                           double r, double T, double K, int hidden, int layers, const float* params,
+                           double m_scale, double tau_scale, double epsilon, const float* Z);
+
 /* ---- many small pricings in one go ------------------------------------------------------- */
 /* replaces the curve loops compute_curve_for_S0 (options_model_3.py:697-713, Options_model.py:
  * 190-211, options_model_2.py:336-355) and their ProcessPoolExecutor fan-out: n independent

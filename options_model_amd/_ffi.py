@@ -82,6 +82,8 @@ SIGNATURES = {
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
     "omc_lsm_apply_mlp": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _I, _P, _P, _P, _D, _D, _D, _U64,
                                     C.POINTER(Result), _P, _P]),
+    "omc_localvol_param_count": (C.c_int, [_I, _I]),
+    "omc_localvol_paths_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _D, _I, _I, _P, _D, _D, _D, _P]),
     "omc_nn_feature_stats": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P]),
 }
 

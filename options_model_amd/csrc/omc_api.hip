@@ -780,6 +780,28 @@ int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
     return 0;
 }
 
+int omc_localvol_param_count(int hidden, int layers) { return omc::localvol_param_count(hidden, layers); }
+
+int omc_localvol_paths_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, int n_steps, double S0,
+                           double r, double T, double K, int hidden, int layers, const float* params,
+                           double m_scale, double tau_scale, double epsilon, const float* Z)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_market(S0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (omc_localvol_param_count(hidden, layers) < 0)
+        return fail(-9, "the local-vol kernel supports hidden_dim = 64 with 1..8 hidden layers.");
+    if (!params || !Z) return fail(-7, "null pointer.");
+    if (n_paths & 1) return fail(-3, "antithetic layout needs an even n_paths.");
+    if (!(m_scale > 0) || !(tau_scale > 0)) return fail(-4, "scaler values must be positive.");
+    HIP_TRY(omc::localvol_paths(c->stream, S, ld, n_paths, n_steps, layers, params, Z, S0, r, T, K, m_scale,
+                                tau_scale, epsilon));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const double* y, int64_t n_rows,
                          double T, double dt, double* out16)
 {

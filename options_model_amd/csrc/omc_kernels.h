@@ -113,6 +113,11 @@ int mlp_apply_param_count(int hidden, int layers);
 hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, int hidden, int layers, const float* params,
                            const double* feat_mean, const double* feat_std, double y_mean, double y_std,
                            double dropout, uint64_t seed, float* sx, int32_t* tex);
+// local-vol paths through the implied-vol network (hidden 64, `layers` residual blocks), row f-4
+int localvol_param_count(int hidden, int layers);
+hipError_t localvol_paths(hipStream_t st, float* S, int64_t ld, int64_t M, int N, int layers, const float* params,
+                          const float* Z, double S0, double r, double T, double K, double m_scale,
+                          double tau_scale, double eps_out);
 // float64 means / population variances of the regression features and the target over n rows
 size_t nn_stats_scratch_bytes();
 hipError_t nn_feature_stats(hipStream_t st, const double* x, const int32_t* t, const double* y, int64_t n,

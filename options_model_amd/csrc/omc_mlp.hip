@@ -685,6 +685,126 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
     }
 }
 
+// ------------------------------------------------------------------ local-vol paths (row f-4)
+// simulate_local_vol_paths_antithetic (options_model_3.py:300-333) with the implied-vol network
+// (ImprovedIVNetwork, NN_training_stock_iv.py:109-155: Linear(2,64)+GELU, L x [h += GELU(
+// LayerNorm(Linear(h)))], Linear(64,1) clamped at epsilon; dropout is off in eval mode) evaluated
+// inside the path loop: one wave carries 32 columns through all time steps, activations stay in
+// the transposed MFMA accumulator layout of the trainer above (lane <-> column), so LayerNorm's
+// sums over the 64 units are sums over a lane's registers plus one swap between half-waves.
+// Flat parameters: Win|bin as [64][4] (w_m, w_tau, bias, 0), per layer W [64][64], b, gamma,
+// beta [64] each, then the output weights [64] and bias [1].
+struct LocalVolArgs {
+    float* S;
+    int64_t ld, M, P;
+    int N, L;
+    const float* params;
+    const float* Z;  // [N][P] normals of the first half; the partner column uses -z
+    float s0, r, dt, sqdt, eps_out;
+    double K, T, dtd, inv_m_scale, inv_tau_scale;
+    int ntiles;
+};
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__global__ __launch_bounds__(256) void localvol_paths_kernel(LocalVolArgs a)
+{
+    constexpr int kLayer = kH * kLdW2 + 3 * kH;
+    extern __shared__ float sw[];
+    float* sWin = sw;                 // [64][4]
+    float* sLay = sWin + kH * 4;      // L x { W [64][65], b, gamma, beta }
+    float* sWo = sLay + a.L * kLayer;  // [64] + bias
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+    for (int i = tid; i < kH * 4; i += 256) sWin[i] = a.params[i];
+    for (int l = 0; l < a.L; ++l) {
+        const float* src = a.params + kH * 4 + l * (kH * kH + 3 * kH);
+        float* dst = sLay + l * kLayer;
+        for (int i = tid; i < kH * kH; i += 256) dst[(i >> 6) * kLdW2 + (i & 63)] = src[i];
+        for (int i = tid; i < 3 * kH; i += 256) dst[kH * kLdW2 + i] = src[kH * kH + i];
+    }
+    for (int i = tid; i <= kH; i += 256) sWo[i] = a.params[kH * 4 + a.L * (kH * kH + 3 * kH) + i];
+    __syncthreads();
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.ntiles) return;  // whole wave; no barrier below
+    const int64_t col = (int64_t)tile * 32 + c;
+    const bool live = col < a.M;
+    const int64_t zc = live ? (col < a.P ? col : col - a.P) : 0;
+    const float zs = col < a.P ? 1.0f : -1.0f;
+    float s = a.s0;
+    if (live && h == 0) a.S[col] = s;
+    float z_next = a.Z[zc];
+    for (int t = 1; t <= a.N; ++t) {
+        const float z = z_next * zs;
+        if (t < a.N) z_next = a.Z[(int64_t)t * a.P + zc];
+        const double tau = fmax(a.T - (double)(t - 1) * a.dtd, 1e-6);
+        const float xin = h == 0 ? (float)(log(fmax(a.K, 1e-8) / fmax((double)s, 1e-8)) * a.inv_m_scale)
+                                 : (float)(tau * a.inv_tau_scale);
+        v16f act[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) act[mt][r] = sWin[unit_of(mt, r, h) * 4 + 2];
+            act[mt] = mfma(sWin[(32 * mt + c) * 4 + h], xin, act[mt]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) act[mt][r] = gelu_exact(act[mt][r]);
+        }
+        for (int l = 0; l < a.L; ++l) {
+            const float* W = sLay + l * kLayer;
+            const float* B = W + kH * kLdW2;
+            v16f zz[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zz[mt][r] = B[unit_of(mt, r, h)];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int sI = 0; sI < 16; ++sI) {
+                    const int k = unit_of(kt, sI, h);
+                    zz[0] = mfma(W[(c)*kLdW2 + k], act[kt][sI], zz[0]);
+                    zz[1] = mfma(W[(32 + c) * kLdW2 + k], act[kt][sI], zz[1]);
+                }
+            }
+            // LayerNorm over the 64 units of a column: this lane's 32 + the other half-wave's 32
+            float sum = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += zz[mt][r];
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.0f / 64.0f);
+            float sq = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = zz[mt][r] - mean;
+                    sq = __builtin_fmaf(d, d, sq);
+                }
+            sq += __shfl_xor(sq, 32, 64);
+            const float rstd = 1.0f / __builtin_sqrtf(sq * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int u = unit_of(mt, r, h);
+                    const float y = (zz[mt][r] - mean) * rstd * B[kH + u] + B[2 * kH + u];
+                    act[mt][r] += gelu_exact(y);
+                }
+        }
+        float o = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o = __builtin_fmaf(sWo[unit_of(mt, r, h)], act[mt][r], o);
+        o += __shfl_xor(o, 32, 64);
+        o += sWo[kH];
+        const float sig = fmaxf(fmaxf(o, a.eps_out), 1e-6f);
+        s = s * expf((a.r - 0.5f * sig * sig) * a.dt + sig * a.sqdt * z);
+        if (live && h == 0) a.S[(int64_t)t * a.ld + col] = s;
+    }
+}
+
 }  // namespace
 
 size_t nn_stats_scratch_bytes() { return sizeof(double) * 8 * (1024 + 2); }
@@ -848,6 +968,33 @@ hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, int hidden, int 
     if (hidden == 128 && layers == 2) return launch_apply<128, 2>(st, a);
     if (hidden == 128 && layers == 3) return launch_apply<128, 3>(st, a);
     return hipErrorInvalidValue;
+}
+
+int localvol_param_count(int hidden, int layers)
+{
+    if (hidden != 64 || layers < 1 || layers > 8) return -1;
+    return kH * 4 + layers * (kH * kH + 3 * kH) + kH + 1;
+}
+
+hipError_t localvol_paths(hipStream_t st, float* S, int64_t ld, int64_t M, int N, int layers, const float* params,
+                          const float* Z, double S0, double r, double T, double K, double m_scale,
+                          double tau_scale, double eps_out)
+{
+    LocalVolArgs a;
+    a.S = S; a.ld = ld; a.M = M; a.P = M / 2; a.N = N; a.L = layers;
+    a.params = params; a.Z = Z;
+    const double dt = T / (double)N;
+    a.s0 = (float)S0; a.r = (float)r; a.dt = (float)dt; a.sqdt = (float)sqrt(dt); a.eps_out = (float)eps_out;
+    a.K = K; a.T = T; a.dtd = dt; a.inv_m_scale = 1.0 / m_scale; a.inv_tau_scale = 1.0 / tau_scale;
+    a.ntiles = (int)((M + 31) / 32);
+    const size_t lds_bytes = sizeof(float) * (size_t)(kH * 4 + layers * (kH * kLdW2 + 3 * kH) + kH + 4);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(localvol_paths_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(localvol_paths_kernel, dim3((unsigned)((a.ntiles + 3) / 4)), dim3(256), lds_bytes, st, a);
+    return hipGetLastError();
 }
 
 }  // namespace omc

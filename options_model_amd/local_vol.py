@@ -4,12 +4,14 @@ drop-in for `IVModel` (options_model_3/options_model_3.py:263-298) and
 
 Per time step the reference calls the IV network on ALL paths (2 -> 64 -> 4 x [Linear 64x64,
 LayerNorm, GELU, residual] -> 1; NN_training_stock_iv.py:109-155) through numpy <-> torch-CPU
-round trips.  Here the whole simulation stays on the GPU: normals from the library's Philox
-generator (same counter layout as the GBM kernel: `omc_gbm_normals_f32`), the network forward
-as batched GEMMs over the M paths (PyTorch-ROCm -> hipBLASLt -> MFMA: the one place in path
-generation that is GEMM-shaped), the log-Euler update fused into a few elementwise kernels.
-The resulting [step][path] float32 matrix feeds the same HIP backward-induction kernels as
-every other model (`omc_lsm_poly` on the tensor's device pointer).
+round trips.  Here the whole simulation is ONE kernel of the library (`omc_localvol_paths_f32`,
+csrc/omc_mlp.hip): a wave carries 32 columns through all time steps and evaluates the network on
+the matrix cores in float32, weights in LDS, activations in registers; normals come from the
+library's Philox generator (`omc_gbm_normals_f32`, the GBM kernel's counter layout).  Networks of
+another width go through PyTorch-ROCm (batched GEMMs per step; backend="torch" forces that
+path, which the tests use as a cross-check).  The resulting [step][path] float32 matrix feeds the
+same HIP backward-induction kernels as every other model (`omc_lsm_poly` on the tensor's device
+pointer).
 """
 from __future__ import annotations
 
@@ -89,11 +91,38 @@ class IVModel:
         return self.sigma_tensor(K, s, tau).double().cpu().numpy()
 
 
-def simulate_local_vol_paths(S0, r, T, num_simulations, num_time_steps, iv_model: IVModel, K, seed,
-                             stream=0, z_half=None):
-    """-> float32 device tensor S [num_time_steps+1, M], M = num_simulations // 2 * 2, antithetic
-    partner of column j is j + M/2 (:306-307).  z_half (optional, [N][M/2]) injects normals."""
+def _flatten_iv_network(net):
+    """-> (flat float32 parameters in omc_localvol_paths_f32's layout, hidden layers) or None if the
+    network is not the ImprovedIVNetwork shape with hidden_dim 64."""
     torch = _torch()
+    try:
+        lin_in, layers, out = net.input_proj, list(net.layers), net.output
+        if lin_in.weight.shape != (64, 2) or out.weight.shape != (1, 64) or not 1 <= len(layers) <= 8:
+            return None
+        parts = [torch.cat([lin_in.weight, lin_in.bias[:, None], torch.zeros_like(lin_in.bias[:, None])],
+                           dim=1).reshape(-1)]
+        for blk in layers:
+            lin, ln, act = blk[0], blk[1], blk[2]
+            if (lin.weight.shape != (64, 64) or not isinstance(ln, torch.nn.LayerNorm) or abs(ln.eps - 1e-5) > 0
+                    or not isinstance(act, torch.nn.GELU) or getattr(act, "approximate", "none") != "none"):
+                return None
+            parts += [lin.weight.reshape(-1), lin.bias, ln.weight, ln.bias]
+        parts += [out.weight.reshape(-1), out.bias]
+        with torch.no_grad():
+            return torch.cat([p.detach() for p in parts]).float().contiguous(), len(layers)
+    except (AttributeError, IndexError, TypeError):
+        return None
+
+
+def simulate_local_vol_paths(S0, r, T, num_simulations, num_time_steps, iv_model: IVModel, K, seed,
+                             stream=0, z_half=None, backend="auto"):
+    """-> float32 device tensor S [num_time_steps+1, M], M = num_simulations // 2 * 2, antithetic
+    partner of column j is j + M/2 (:306-307).  z_half (optional, [N][M/2]) injects normals.
+    backend: "hip" = the library's kernel (network evaluated inside the path loop; hidden_dim 64),
+    "torch" = per-step batched GEMMs through PyTorch-ROCm, "auto" = hip where the shape allows."""
+    torch = _torch()
+    if backend not in ("auto", "hip", "torch"):
+        raise ValueError("backend must be 'auto', 'hip' or 'torch'")
     dev = iv_model.device
     N = int(num_time_steps)
     M = int(num_simulations) // 2 * 2
@@ -110,6 +139,19 @@ def simulate_local_vol_paths(S0, r, T, num_simulations, num_time_steps, iv_model
             Z = torch.as_tensor(z_half, dtype=torch.float32, device=dev)
             assert Z.shape == (N, P)
         S = torch.empty((N + 1, M), dtype=torch.float32, device=dev)
+        flat = _flatten_iv_network(iv_model.model) if backend != "torch" else None
+        if backend == "hip" and flat is None:
+            raise ValueError("backend='hip' needs the ImprovedIVNetwork shape with hidden_dim 64")
+        if flat is not None:
+            params, layers = flat
+            params = params.to(dev)
+            ctx = _ffi.default_context(dev.index or 0)
+            torch.cuda.synchronize(dev)
+            _ffi._check(ctx.lib, ctx.lib.omc_localvol_paths_f32(
+                ctx.handle, S.data_ptr(), M, M, N, float(S0), float(r), float(T), float(K), 64, layers,
+                params.data_ptr(), iv_model.m_scale, iv_model.tau_scale, float(iv_model.model.epsilon),
+                Z.contiguous().data_ptr()))
+            return S
         S[0] = S0
         sq = math.sqrt(dt)
         for t in range(1, N + 1):

@@ -67,3 +67,32 @@ def test_local_vol_philox_paths_and_pricing(lv, ctx):
     eu = p2.price_american_option(S0, T, 100_000, N)
     assert am > eu > 0 and am < K
     assert p.last_result["n_paths"] == 100_000
+
+
+def test_hip_kernel_matches_torch_backend(lv):
+    """The library's one-kernel simulator (network inside the path loop, float32 MFMA) against the
+    per-step PyTorch-ROCm evaluation of the same network on the same normals."""
+    g, local_vol, model = lv
+    S0, r, T, K = g["params"][:4]
+    for M, N in ((2, 3), (62, 5), (20_000, 24)):
+        a = local_vol.simulate_local_vol_paths(S0, r, T, M, N, model, K, seed=5, backend="hip")
+        b = local_vol.simulate_local_vol_paths(S0, r, T, M, N, model, K, seed=5, backend="torch")
+        assert a.shape == b.shape == (N + 1, M)
+        rel = (a.double() / b.double() - 1).abs().max()
+        assert float(rel) <= 2e-5, (M, N, float(rel))  # float32 paths, different summation orders
+    with pytest.raises(ValueError, match="backend"):
+        local_vol.simulate_local_vol_paths(S0, r, T, 10, 3, model, K, seed=5, backend="cuda")
+
+
+def test_hip_kernel_rejects_other_widths(lv, ctx):
+    g, local_vol, model = lv
+    import torch
+    assert ctx.lib.omc_localvol_param_count(64, 4) == 64 * 4 + 4 * (64 * 64 + 3 * 64) + 65
+    assert ctx.lib.omc_localvol_param_count(128, 4) == -1
+    wide = local_vol.make_iv_network(128, 2)
+    wide.scaler = types.SimpleNamespace(m_scale=1.0, tau_scale=1.0)
+    wm = local_vol.IVModel(wide)
+    with pytest.raises(ValueError, match="hidden_dim 64"):
+        local_vol.simulate_local_vol_paths(100.0, 0.05, 1.0, 64, 4, wm, 100.0, seed=1, backend="hip")
+    S = local_vol.simulate_local_vol_paths(100.0, 0.05, 1.0, 64, 4, wm, 100.0, seed=1)  # auto -> torch
+    assert S.shape == (5, 64) and bool(torch.isfinite(S).all())
