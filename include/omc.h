@@ -167,16 +167,18 @@ int omc_heston_price_strikes(omc_ctx* ctx, int64_t n_paths, int n_steps, double 
 /* ---- NN continuation-value regressor: fused training of the network ------------------------ */
 /* replaces the minibatch loop of price_american_enhanced_lsm (options_model_3.py:565-600:
  * SingleLSMNet(7, hidden, layers) :85-103, nn.MSELoss, optim.Adam(lr, weight_decay), shuffled
- * minibatches) for the network BASELINE config 5 names, 7 -> 64 -> 64 -> 1 (hidden = 64,
- * layers = 2; anything else returns -9; omc_mlp_param_count also knows the shapes that only
- * omc_lsm_apply_mlp supports).  One call = one epoch over `n_rows` rows of
+ * minibatches) for hidden = 64 with layers = 2 (the network BASELINE config 5 names, 7 -> 64 ->
+ * 64 -> 1) or layers = 3 (the depth SingleLSMNet always has in the reference); anything else
+ * returns -9 (omc_mlp_param_count also knows the shapes that only omc_lsm_apply_mlp supports).
+ * One call = one epoch over `n_rows` rows of
  * `data` ([n_rows][8] float32 device memory: 7 normalised features + normalised target):
  * ceil(n_rows / batch) optimizer steps of float32 MFMA forward/backward + Adam.  The epoch
  * visits the rows in a pseudo-random permutation keyed by `shuffle_key` (a Feistel network with
  * cycle-walking, evaluated in the kernel: no randperm, no gather; 0 = storage order) --
  * omc_mlp_shuffle_indices writes that permutation out (out[i] = row visited at position i).
  * `params` (device, omc_mlp_param_count floats) is laid out W1|b1 as [hidden][8] (bias in
- * column 7), W2 [hidden][hidden], b2, w3, b3; adam_m / adam_v are the moment buffers (zero
+ * column 7), then per further hidden layer W [hidden][hidden] and b [hidden], then the output
+ * weights [hidden] and bias [1]; adam_m / adam_v are the moment buffers (zero
  * them before the first epoch); *step counts optimizer steps across calls (bias correction).
  * dropout is applied after each ReLU as in training mode (Philox bits keyed by `seed`).
  * *mean_loss = mean over the epoch's steps of the batch-mean squared error (the value the

@@ -835,8 +835,8 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
 {
     int rc = bind(c);
     if (rc) return rc;
-    if (hidden != 64 || layers != 2)
-        return fail(-9, "the fused trainer supports hidden = 64, layers = 2 only.");
+    if (omc::mlp_train_param_count(hidden, layers) < 0)
+        return fail(-9, "the fused trainer supports hidden = 64 with 2 or 3 hidden layers.");
     if (!data || !params || !adam_m || !adam_v || !step || !mean_loss) return fail(-7, "null pointer.");
     if (n_rows <= 0 || batch <= 0 || *step < 0) return fail(-3, "n_rows, batch must be positive.");
     if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
@@ -847,7 +847,7 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
     omc::MlpTrainPlan t;
     t.data = data; t.params = params; t.adam_m = adam_m; t.adam_v = adam_v;
     t.partial = (float*)c->mlp_part.p; t.loss_acc = (double*)c->mlp_loss.p;
-    t.nrows = n_rows; t.batch = batch; t.first_step = *step;
+    t.nrows = n_rows; t.batch = batch; t.first_step = *step; t.layers = layers;
     t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.weight_decay = weight_decay;
     t.dropout = dropout; t.seed = seed; t.shuffle_key = shuffle_key;
     HIP_TRY(omc::mlp_train_steps(c->stream, t));

@@ -90,9 +90,10 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
 // valuation of (sx,tex): sums into w.result ; tval = 1 (reference flows) or 0 (textbook)
 hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval);
 
-// ---- continuation-value network of the NN flow (omc_mlp.hip): 7 -> 64 -> 64 -> 1
-constexpr int kMlpParams = 64 * 8 + 64 * 64 + 64 + 64 + 1;  // W1|b1 [64][8], W2 [64][64], b2, w3, b3
-constexpr int kMlpPartialStride = 4800;                    // >= kMlpParams + 1 (loss slot)
+// ---- continuation-value network of the NN flow (omc_mlp.hip): 7 -> 64 -> 64 (-> 64) -> 1
+constexpr int kMlpParams = 64 * 8 + 64 * 64 + 64 + 64 + 1;  // two hidden layers: W1|b1 [64][8], W2, b2, w3, b3
+constexpr int kMlpPartialStride2 = 4800;                   // gradient partial per workgroup, 2 / 3 hidden layers
+constexpr int kMlpPartialStride3 = 8960;                   // (>= parameters + 1 loss slot, multiple of 64)
 constexpr int kMlpMaxGroups = 256;                         // one workgroup per CU
 struct MlpTrainPlan {
     const float* data;  // [nrows][8] float32: 7 inputs + target
@@ -102,11 +103,13 @@ struct MlpTrainPlan {
     float* partial;     // mlp_partial_bytes()
     double* loss_acc;   // += batch-mean loss of every step
     int64_t nrows, batch, first_step;  // optimizer steps taken before this call
+    int layers;                        // hidden layers: 2 or 3 (64 units each)
     double lr, beta1, beta2, eps, weight_decay, dropout;
     uint64_t seed;         // dropout bits
     uint64_t shuffle_key;  // 0: rows in storage order; else a keyed pseudo-random permutation
 };
 size_t mlp_partial_bytes();
+int mlp_train_param_count(int hidden, int layers);  // -1: shape not covered by the trainer
 // pass 2 of the NN flow: sticky sweep with the network as continuation value -> (sx, tex)
 // hidden in {64, 128}, layers (hidden layers) in {2, 3}; mlp_apply_param_count: floats, -1 otherwise
 int mlp_apply_param_count(int hidden, int layers);

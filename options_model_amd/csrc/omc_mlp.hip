@@ -1,6 +1,7 @@
 // omc_mlp.hip -- the continuation-value network of the NN flow as
-// hand-written gfx950 kernels: one fused forward + backward pass of the 7 -> 64 -> 64 -> 1 MLP
-// (Linear/ReLU/Dropout stacks of SingleLSMNet, options_model_3.py:85-103) over a minibatch, and
+// hand-written gfx950 kernels: one fused forward + backward pass of the 7 -> 64 -> 64 (-> 64) -> 1
+// MLP (Linear/ReLU/Dropout stacks of SingleLSMNet, options_model_3.py:85-103; the reference's class
+// always has three hidden layers, BASELINE config 5 names two) over a minibatch, and
 // the gradient reduce + Adam update (options_model_3.py:565-600: Adam, weight decay, MSE).
 //
 // The minibatch GEMMs run on the matrix cores in float32 (v_mfma_f32_32x32x2_f32; the reference
@@ -25,28 +26,12 @@ namespace omc {
 namespace {
 
 constexpr int kH = 64;                 // hidden width
-constexpr int kOW1 = 0;                // [64][8]: 7 feature weights + bias in column 7
-constexpr int kOW2 = kOW1 + kH * 8;    // [64][64]
-constexpr int kOB2 = kOW2 + kH * kH;   // [64]
-constexpr int kOW3 = kOB2 + kH;        // [64]
-constexpr int kOB3 = kOW3 + kH;        // [1]
-static_assert(kOB3 + 1 == kMlpParams, "parameter layout");
-
 constexpr int kLdW1 = 9, kLdW2 = 65;   // LDS leading dimensions (odd: conflict-free column walks)
-constexpr int kLdsWeights = kH * kLdW1 + kH * kLdW2 + kH + kH + 4;
 // Staging patches are [unit][32 rows] without padding; the row index is XOR-swizzled per unit in
 // units of 4 rows, so that the 16-byte row-quad reads of 16 consecutive units fall on 16 different
-// bank groups and a quad stays contiguous.  2 x 8 KB (H1, dZ) + 1 KB (X) per wave: 8 waves + the
-// weights fit the 160 KB of a CU, i.e. two waves per SIMD.  (The second patch holds H2, not dZ2:
-// the reading lane rebuilds dZ2 = [H2 > 0] w3 dout / keep from it and gets the w3 gradient from
-// the same values, which saves the 32 per-lane accumulators a register-side sum would need.)
-constexpr int kLdsWave = 2 * kH * 32 + 9 * 32;  // H1, H2 patches; X patch (8 inputs) + d(loss)/d(out) row
-constexpr int kGStride = 4864;  // per-wave gradient vector in the epilogue (>= kMlpParams + 1)
-constexpr int lds_floats(int waves) { return kLdsWeights + waves * kLdsWave; }
-static_assert(kGStride > kMlpParams && 4 * kGStride <= lds_floats(4) && 8 * kGStride <= lds_floats(8),
-              "the epilogue re-partitions the whole LDS allocation into one gradient vector per wave");
-static_assert(lds_floats(8) * 4 <= 160 * 1024, "LDS of one CU");
-
+// bank groups and a quad stays contiguous.  (The last hidden layer's patch holds H, not dZ: the
+// reading lane rebuilds dZ = [H > 0] wo dout / keep from it and gets the output-weight gradient
+// from the same values, which saves the 32 per-lane accumulators a register-side sum would need.)
 __device__ __forceinline__ int st_idx(int unit, int row) { return unit * 32 + (row ^ (((unit >> 1) & 7) << 2)); }
 // The two access patterns of the kernel, written so that every address is one of four per-lane
 // registers plus a compile-time offset (an XOR with a lane-dependent value cannot be folded into
@@ -156,8 +141,8 @@ __device__ __forceinline__ uint64_t shuffle_index(const Shuffle& s, uint64_t i)
 
 struct MlpTrainArgs {
     const float* data;    // [n][8]: 7 normalised features + normalised target (the whole epoch)
-    const float* params;  // [kMlpParams]
-    float* partial;       // [gridDim.x][kMlpPartialStride]: gradient sums + batch loss
+    const float* params;  // [train_params(L)]
+    float* partial;       // [gridDim.x][g_stride(L)]: gradient sums + batch loss
     int64_t row0, nrows;  // this step's minibatch = epoch positions row0 .. row0 + nrows
     Shuffle shuf;         // epoch position -> stored row
     int ntiles;
@@ -165,50 +150,35 @@ struct MlpTrainArgs {
     uint32_t keep16, step, k0, k1;
 };
 
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void mlp_train_kernel(MlpTrainArgs a)
+// sizes for L hidden layers of 64 units (flat layout: mlp_params_of(64, L))
+__host__ __device__ constexpr int train_params(int L) { return kH * 8 + (L - 1) * (kH * kH + kH) + kH + 1; }
+__host__ __device__ constexpr int g_stride(int L) { return (train_params(L) + 1 + 63) / 64 * 64; }
+__host__ __device__ constexpr int lds_weights(int L) { return kH * kLdW1 + (L - 1) * (kH * kLdW2 + kH) + kH + 4; }
+__host__ __device__ constexpr int lds_wave(int L) { return L * kH * 32 + 9 * 32; }  // L patches + X + dout row
+__host__ __device__ constexpr int train_lds_floats(int L)
 {
-    constexpr int NT = 64 * WAVES;
+    return lds_weights(L) + 4 * lds_wave(L) > 4 * g_stride(L) ? lds_weights(L) + 4 * lds_wave(L) : 4 * g_stride(L);
+}
+static_assert(g_stride(2) == kMlpPartialStride2 && g_stride(3) == kMlpPartialStride3, "omc_kernels.h");
+static_assert(train_lds_floats(3) * 4 <= 160 * 1024, "LDS of one CU");
+
+// L hidden layers.  Connection j (j = 1 .. L-1) is the 64x64 matrix from hidden layer j-1 to j;
+// patch j holds H_j until its weight-gradient product has read it, then dZ_j.
+template <int L>
+__global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
+{
+    constexpr int kConn = kH * kLdW2 + kH;  // one staged connection: weights [64][65] + bias [64]
     extern __shared__ float lds[];
     float* sW1 = lds;
-    float* sW2 = sW1 + kH * kLdW1;
-    float* sB2 = sW2 + kH * kLdW2;
-    float* sW3 = sB2 + kH;
-    float* sB3 = sW3 + kH;
+    float* sWc = sW1 + kH * kLdW1;            // (L-1) connections, pre-multiplied by 1 / keep
+    float* sWo = sWc + (L - 1) * kConn;       // output weights (pre-multiplied) ...
+    float* sBo = sWo + kH;                    // ... and bias
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    float* tH1 = lds + kLdsWeights + wave * kLdsWave;
-    float* tDZ = tH1 + kH * 32;
-    float* tX = tDZ + kH * 32;
-
-    for (int i = tid; i < kH * 8; i += NT) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[kOW1 + i];
-    // Inverted dropout's 1 / keep is folded into the weights that consume the dropped activations
-    // (W2 and w3 are staged pre-multiplied), so activations carry the 0/1 mask only: with
-    // H' = mask * relu(Z), W2s = W2 / keep: Z2 = W2s H1' + b2, dZ1 = [H1' > 0] W2s^T dZ2, and the
-    // two gradients taken against H' (gW2, gw3) are multiplied by 1 / keep once, on the way out.
-    for (int i = tid; i < kH * kH; i += NT) sW2[(i >> 6) * kLdW2 + (i & 63)] = a.params[kOW2 + i] * a.inv_keep;
-    if (tid < kH) {
-        sB2[tid] = a.params[kOB2 + tid];
-        sW3[tid] = a.params[kOW3 + tid] * a.inv_keep;
-    }
-    if (tid == 0) sB3[0] = a.params[kOB3];
-    __syncthreads();
-
-    v16f gW2[2][2];
-    v4f gW1[4];  // 16x16 tiles: units 16*mt4 + 4*(lane/16) + r, input column lane%16 (< 8 exist)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            gW2[i][0][r] = 0.0f;
-            gW2[i][1][r] = 0.0f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gW1[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    float gb2[2] = {0.0f, 0.0f}, gw3[2] = {0.0f, 0.0f}, gb3 = 0.0f, loss = 0.0f;
+    float* patch = lds + lds_weights(L) + wave * lds_wave(L);  // [L][64][32]
+    float* tX = patch + L * kH * 32;                           // [8][32] inputs + [32] d(loss)/d(out)
 
     const StageOfs so = stage_offsets(c, h);
-    const int nwaves = gridDim.x * WAVES;
+    const int nwaves = gridDim.x * 4;
     auto fetch = [&](int tile) {
         const int64_t r = (int64_t)tile * 32 + c;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -216,12 +186,43 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_train_kernel(MlpTrainArgs a)
             v = reinterpret_cast<const float4*>(a.data + shuffle_index(a.shuf, (uint64_t)(a.row0 + r)) * 8)[h];
         return v;
     };
-    float4 xnext = fetch(blockIdx.x * WAVES + wave);
-    for (int tile = blockIdx.x * WAVES + wave; tile < a.ntiles; tile += nwaves) {
+    float4 xnext = fetch(blockIdx.x * 4 + wave);  // travels while the weights are staged
+
+    // Inverted dropout's 1 / keep is folded into the weights that consume the dropped activations
+    // (connections and output weights are staged pre-multiplied), so activations carry the 0/1
+    // mask only: with H' = mask * relu(Z), Ws = W / keep: Z_j = Ws H'_{j-1} + b, dZ_{j-1} =
+    // [H'_{j-1} > 0] Ws^T dZ_j, and the gradients taken against H' (connections, output weights)
+    // are multiplied by 1 / keep once, on the way out.
+    for (int i = tid; i < kH * 8; i += 256) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[i];
+#pragma unroll
+    for (int j = 0; j < L - 1; ++j) {
+        const float* src = a.params + kH * 8 + j * (kH * kH + kH);
+        float* dst = sWc + j * kConn;
+        for (int i = tid; i < kH * kH; i += 256) dst[(i >> 6) * kLdW2 + (i & 63)] = src[i] * a.inv_keep;
+        if (tid < kH) dst[kH * kLdW2 + tid] = src[kH * kH + tid];
+    }
+    if (tid < kH) sWo[tid] = a.params[kH * 8 + (L - 1) * (kH * kH + kH) + tid] * a.inv_keep;
+    if (tid == 0) sBo[0] = a.params[kH * 8 + (L - 1) * (kH * kH + kH) + kH];
+    __syncthreads();
+
+    v16f gW[L - 1][2][2];
+    v4f gW1[4];  // 16x16 tiles: units 16*mt4 + 4*(lane/16) + r, input column lane%16 (< 8 exist)
+    float gb[L - 1][2], gwo[2] = {0.0f, 0.0f}, gbo = 0.0f, loss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < L - 1; ++j) {
+        gb[j][0] = gb[j][1] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gW[j][i][0][r] = gW[j][i][1][r] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gW1[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += nwaves) {
         const int64_t row = (int64_t)tile * 32 + c;
         const bool live = row < a.nrows;
-        const float4 xin = xnext;
-        float4 x = xin;
+        float4 x = xnext;
         float y = x.w;                 // upper half-wave: column 7 is the target ...
         if (h == 1) x.w = 1.0f;        // ... and its slot carries the bias input
         y = __shfl(y, c + 32, 64);
@@ -231,126 +232,143 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_train_kernel(MlpTrainArgs a)
         tX[st_idx(4 * h + 2, c)] = x.z;
         tX[st_idx(4 * h + 3, c)] = x.w;
 
-        // ---- layer 1: Z1^T [64 x 32] = W1a [64 x 8] * Xa^T [8 x 32]; k-step s <-> inputs s, s+4
-        v16f h1[2];
+        // ---- layer 0: Z^T [64 x 32] = W1a [64 x 8] * Xa^T [8 x 32]; k-step s <-> inputs s, s+4
+        v16f act[L][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h1[mt][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) act[0][mt][r] = 0.0f;
             const float* wr = sW1 + (32 * mt + c) * kLdW1 + 4 * h;
-            h1[mt] = mfma(wr[0], x.x, h1[mt]);
-            h1[mt] = mfma(wr[1], x.y, h1[mt]);
-            h1[mt] = mfma(wr[2], x.z, h1[mt]);
-            h1[mt] = mfma(wr[3], x.w, h1[mt]);
+            act[0][mt] = mfma(wr[0], x.x, act[0][mt]);
+            act[0][mt] = mfma(wr[1], x.y, act[0][mt]);
+            act[0][mt] = mfma(wr[2], x.z, act[0][mt]);
+            act[0][mt] = mfma(wr[3], x.w, act[0][mt]);
         }
         // next tile's rows: issued once this tile's are consumed (a wait on the older load would
         // otherwise drain this one too), in flight for the rest of the tile
         xnext = fetch(tile + nwaves);
-        relu_dropout<false>(h1, (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
+        relu_dropout<false>(act[0], (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tH1[unit_base(mt, r) + so.wr[wr_sel(r)]] = h1[mt][r];
+            for (int r = 0; r < 16; ++r) patch[unit_base(mt, r) + so.wr[wr_sel(r)]] = act[0][mt][r];
 
-        // ---- layer 2: Z2^T = W2 * H1^T + b2; k-step (kt, s) <-> hidden units unit_of(kt, s, h)
-        v16f h2[2];
+        // ---- layers 1 .. L-1: Z_j^T = Ws_j * H_{j-1}^T + b_j; k-step (kt, s) <-> unit_of(kt, s, h)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int j = 1; j < L; ++j) {
+            const float* W = sWc + (j - 1) * kConn;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h2[mt][r] = sB2[unit_of(mt, r, h)];
-        }
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+                for (int r = 0; r < 16; ++r) act[j][mt][r] = W[kH * kLdW2 + unit_of(mt, r, h)];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int k = unit_of(kt, s, h);
-                h2[0] = mfma(sW2[(c)*kLdW2 + k], h1[kt][s], h2[0]);
-                h2[1] = mfma(sW2[(32 + c) * kLdW2 + k], h1[kt][s], h2[1]);
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int k = unit_of(kt, s, h);
+                    act[j][0] = mfma(W[(c)*kLdW2 + k], act[j - 1][kt][s], act[j][0]);
+                    act[j][1] = mfma(W[(32 + c) * kLdW2 + k], act[j - 1][kt][s], act[j][1]);
+                }
             }
+            relu_dropout<false>(act[j], (uint32_t)row, a.step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, a.keep16,
+                                a.inv_keep, a.k0, a.k1);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[j * kH * 32 + unit_base(mt, r) + so.wr[wr_sel(r)]] = act[j][mt][r];
         }
-        relu_dropout<false>(h2, (uint32_t)row, a.step, 0x200u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
 
-        // ---- H2 to its patch (the weight-gradient products read it back unit-major)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tDZ[unit_base(mt, r) + so.wr[wr_sel(r)]] = h2[mt][r];
         // ---- output, loss, d(loss)/d(out)
         float o = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o = __builtin_fmaf(sW3[unit_of(mt, r, h)], h2[mt][r], o);
+            for (int r = 0; r < 16; ++r) o = __builtin_fmaf(sWo[unit_of(mt, r, h)], act[L - 1][mt][r], o);
         o += __shfl_xor(o, 32, 64);
-        o += sB3[0];
+        o += sBo[0];
         const float diff = live ? o - y : 0.0f;
         const float dout = diff * a.two_over_b;
         if (h == 0) {
             loss = __builtin_fmaf(diff, diff, loss);
-            gb3 += dout;
+            gbo += dout;
             tX[8 * 32 + c] = dout;
         }
-        // ---- back through layer 2's activation; h2 becomes dZ2 (B operand of the dH1 product)
+        // ---- back through the last activation: dz = dZ_{L-1}, B operand of the first dH product
+        v16f dz[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                h2[mt][r] = h2[mt][r] > 0.0f ? sW3[unit_of(mt, r, h)] * dout : 0.0f;
+                dz[mt][r] = act[L - 1][mt][r] > 0.0f ? sWo[unit_of(mt, r, h)] * dout : 0.0f;
         wave_sync_lds();
 
-        // ---- gW2 [i][k] += sum_rows dZ2[i][row] * H1[k][row]; k-step <-> rows 16h + 4q + j.
-        // This lane owns units c and 32 + c here: dZ2 of those units is rebuilt from H2, and
-        // gw3 [i] += sum_rows dout[row] * H2[i][row], gb2 [i] += sum_rows dZ2[i][row] come along.
-        const float w3s0 = sW3[c], w3s1 = sW3[32 + c];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 e0 = *reinterpret_cast<const float4*>(tDZ + so.rd[q]);
-            const float4 e1 = *reinterpret_cast<const float4*>(tDZ + 32 * 32 + so.rd[q]);
-            const float4 dq = *reinterpret_cast<const float4*>(tX + 8 * 32 + 16 * h + 4 * q);
-            const float4 b0 = *reinterpret_cast<const float4*>(tH1 + so.rd[q]);
-            const float4 b1 = *reinterpret_cast<const float4*>(tH1 + 32 * 32 + so.rd[q]);
-            const float hv0[4] = {e0.x, e0.y, e0.z, e0.w}, hv1[4] = {e1.x, e1.y, e1.z, e1.w};
-            const float dv[4] = {dq.x, dq.y, dq.z, dq.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+        for (int j = L - 1; j >= 1; --j) {
+            const float* W = sWc + (j - 1) * kConn;
+            const float* pA = patch + j * kH * 32;        // H_j (j = L-1: dZ_j is rebuilt from it) or dZ_j
+            const float* pB = patch + (j - 1) * kH * 32;  // H_{j-1}
+            // ---- gW_j [i][k] += sum_rows dZ_j[i][row] * H_{j-1}[k][row]; k-step <-> rows 16h + 4q + jj.
+            // This lane owns units c and 32 + c here.  For the last hidden layer dZ of those units is
+            // rebuilt from H (dZ = [H > 0] wo dout) and the output-weight gradient sum_rows dout * H
+            // comes along; bias gradients are the row sums of dZ.
+            const float wo0 = sWo[c], wo1 = sWo[32 + c];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                gw3[0] = __builtin_fmaf(dv[j], hv0[j], gw3[0]);
-                gw3[1] = __builtin_fmaf(dv[j], hv1[j], gw3[1]);
-                const float av0 = hv0[j] > 0.0f ? w3s0 * dv[j] : 0.0f;
-                const float av1 = hv1[j] > 0.0f ? w3s1 * dv[j] : 0.0f;
-                gb2[0] += av0;
-                gb2[1] += av1;
-                gW2[0][0] = mfma(av0, bv0[j], gW2[0][0]);
-                gW2[0][1] = mfma(av0, bv1[j], gW2[0][1]);
-                gW2[1][0] = mfma(av1, bv0[j], gW2[1][0]);
-                gW2[1][1] = mfma(av1, bv1[j], gW2[1][1]);
+            for (int q = 0; q < 4; ++q) {
+                const float4 e0 = *reinterpret_cast<const float4*>(pA + so.rd[q]);
+                const float4 e1 = *reinterpret_cast<const float4*>(pA + 32 * 32 + so.rd[q]);
+                const float4 dq = *reinterpret_cast<const float4*>(tX + 8 * 32 + 16 * h + 4 * q);
+                const float4 b0 = *reinterpret_cast<const float4*>(pB + so.rd[q]);
+                const float4 b1 = *reinterpret_cast<const float4*>(pB + 32 * 32 + so.rd[q]);
+                const float ev0[4] = {e0.x, e0.y, e0.z, e0.w}, ev1[4] = {e1.x, e1.y, e1.z, e1.w};
+                const float dv[4] = {dq.x, dq.y, dq.z, dq.w};
+                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float av0 = ev0[jj], av1 = ev1[jj];
+                    if (j == L - 1) {
+                        gwo[0] = __builtin_fmaf(dv[jj], ev0[jj], gwo[0]);
+                        gwo[1] = __builtin_fmaf(dv[jj], ev1[jj], gwo[1]);
+                        av0 = ev0[jj] > 0.0f ? wo0 * dv[jj] : 0.0f;
+                        av1 = ev1[jj] > 0.0f ? wo1 * dv[jj] : 0.0f;
+                    }
+                    gb[j - 1][0] += av0;
+                    gb[j - 1][1] += av1;
+                    gW[j - 1][0][0] = mfma(av0, bv0[jj], gW[j - 1][0][0]);
+                    gW[j - 1][0][1] = mfma(av0, bv1[jj], gW[j - 1][0][1]);
+                    gW[j - 1][1][0] = mfma(av1, bv0[jj], gW[j - 1][1][0]);
+                    gW[j - 1][1][1] = mfma(av1, bv1[jj], gW[j - 1][1][1]);
+                }
             }
+            // ---- dH_{j-1}^T = Ws_j^T * dZ_j^T, then through layer j-1's activation
+            v16f d[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[mt][r] = 0.0f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float* wr = W + unit_of(it, s, h) * kLdW2 + c;
+                    d[0] = mfma(wr[0], dz[it][s], d[0]);
+                    d[1] = mfma(wr[32], dz[it][s], d[1]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz[mt][r] = act[j - 1][mt][r] > 0.0f ? d[mt][r] : 0.0f;
+            wave_sync_lds();  // the product above has read patch j-1 (H_{j-1})
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[(j - 1) * kH * 32 + unit_base(mt, r) + so.wr[wr_sel(r)]] = dz[mt][r];
+            wave_sync_lds();
         }
 
-        // ---- dH1^T = W2^T * dZ2^T, then through layer 1's activation
-        v16f d1[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d1[mt][r] = 0.0f;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float* wr = sW2 + unit_of(it, s, h) * kLdW2 + c;
-                d1[0] = mfma(wr[0], h2[it][s], d1[0]);
-                d1[1] = mfma(wr[32], h2[it][s], d1[1]);
-            }
-        }
-        wave_sync_lds();  // gW2's reads of tDZ are done
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                tDZ[unit_base(mt, r) + so.wr[wr_sel(r)]] = h1[mt][r] > 0.0f ? d1[mt][r] : 0.0f;
-        wave_sync_lds();
-
-        // ---- gW1a [i][n] += sum_rows dZ1[i][row] * Xa[n][row]; only input columns n < 8 exist, so
+        // ---- gW1a [i][n] += sum_rows dZ_0[i][row] * Xa[n][row]; only input columns n < 8 exist, so
         // this product runs on 16x16x4 tiles (unit = lane%16 + 16*mt4, column = lane%16); k-slot
         // kq = lane/16 of step s stands for row 8*kq + s: a lane reads its 8 rows as two quads
         {
@@ -365,8 +383,8 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_train_kernel(MlpTrainArgs a)
             float av[4][8];
 #pragma unroll
             for (int mt4 = 0; mt4 < 4; ++mt4) {
-                const float4 aq0 = *reinterpret_cast<const float4*>(tDZ + 16 * 32 * mt4 + o0);
-                const float4 aq1 = *reinterpret_cast<const float4*>(tDZ + 16 * 32 * mt4 + o1);
+                const float4 aq0 = *reinterpret_cast<const float4*>(patch + 16 * 32 * mt4 + o0);
+                const float4 aq1 = *reinterpret_cast<const float4*>(patch + 16 * 32 * mt4 + o1);
                 av[mt4][0] = aq0.x; av[mt4][1] = aq0.y; av[mt4][2] = aq0.z; av[mt4][3] = aq0.w;
                 av[mt4][4] = aq1.x; av[mt4][5] = aq1.y; av[mt4][6] = aq1.z; av[mt4][7] = aq1.w;
             }
@@ -381,51 +399,53 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_train_kernel(MlpTrainArgs a)
     // ---- per-lane partials -> per-wave sums (a lane holds the rows of its half-wave only)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        gb2[mt] += __shfl_xor(gb2[mt], 32, 64);
-        gw3[mt] += __shfl_xor(gw3[mt], 32, 64);
+        gwo[mt] += __shfl_xor(gwo[mt], 32, 64);
+#pragma unroll
+        for (int j = 0; j < L - 1; ++j) gb[j][mt] += __shfl_xor(gb[j][mt], 32, 64);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
-        gb3 += __shfl_xor(gb3, m, 64);
+        gbo += __shfl_xor(gbo, m, 64);
         loss += __shfl_xor(loss, m, 64);
     }
 
     // ---- the whole LDS allocation (weights are no longer needed) is re-cut into one gradient
     // vector per wave: plain stores, nothing to wait for; then the workgroup adds the copies in
     // wave order on the way out
+    constexpr int GS = g_stride(L), NP = train_params(L);
     __syncthreads();
-    float* G = lds + wave * kGStride;
+    float* G = lds + wave * GS;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int j = 0; j < L - 1; ++j) {
+        float* Gj = G + kH * 8 + j * (kH * kH + kH);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = unit_of(mi, r, h);
-            G[kOW2 + i * kH + c] = gW2[mi][0][r] * a.inv_keep;
-            G[kOW2 + i * kH + 32 + c] = gW2[mi][1][r] * a.inv_keep;
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = unit_of(mi, r, h);
+                Gj[i * kH + c] = gW[j][mi][0][r] * a.inv_keep;
+                Gj[i * kH + 32 + c] = gW[j][mi][1][r] * a.inv_keep;
+            }
+            if (h == 0) Gj[kH * kH + 32 * mi + c] = gb[j][mi];
         }
-        if (h == 0) {
-            G[kOB2 + 32 * mi + c] = gb2[mi];
-            G[kOW3 + 32 * mi + c] = gw3[mi] * a.inv_keep;
-        }
+    }
+    if (h == 0) {
+        G[NP - 1 - kH + c] = gwo[0] * a.inv_keep;
+        G[NP - 1 - kH + 32 + c] = gwo[1] * a.inv_keep;
     }
     if ((lane & 15) < 8) {
 #pragma unroll
         for (int mt4 = 0; mt4 < 4; ++mt4)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) G[kOW1 + (16 * mt4 + 4 * (lane >> 4) + r) * 8 + (lane & 15)] = gW1[mt4][r];
+            for (int r = 0; r < 4; ++r) G[(16 * mt4 + 4 * (lane >> 4) + r) * 8 + (lane & 15)] = gW1[mt4][r];
     }
     if (lane == 0) {
-        G[kOB3] = gb3;
-        G[kMlpParams] = loss;
+        G[NP - 1] = gbo;
+        G[NP] = loss;
     }
     __syncthreads();
-    float* out = a.partial + (size_t)blockIdx.x * kMlpPartialStride;
-    for (int i = tid; i <= kMlpParams; i += NT) {
-        float g = lds[i];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) g += lds[w * kGStride + i];
-        out[i] = g;
-    }
+    float* out = a.partial + (size_t)blockIdx.x * GS;
+    for (int i = tid; i <= NP; i += 256) out[i] = ((lds[i] + lds[GS + i]) + lds[2 * GS + i]) + lds[3 * GS + i];
 }
 
 struct MlpAdamArgs {
@@ -434,7 +454,7 @@ struct MlpAdamArgs {
     float* v;
     const float* partial;
     double* loss_acc;  // running sum of batch-mean losses of the epoch
-    int nparts;
+    int nparts, nparams, stride;  // the loss slot is index nparams
     float inv_b, lr_t, inv_sqrt_bc2, beta1, beta2, eps, wd;
 };
 
@@ -447,17 +467,17 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a)
     const int j = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int p = blockIdx.x * 16 + j;
     float g = 0.0f;
-    if (p <= kMlpParams) {
+    if (p <= a.nparams) {
 #pragma unroll 16
-        for (int w = slice; w < a.nparts; w += 16) g += a.partial[(size_t)w * kMlpPartialStride + p];
+        for (int w = slice; w < a.nparts; w += 16) g += a.partial[(size_t)w * a.stride + p];
     }
     red[slice][j] = g;
     __syncthreads();
-    if (slice != 0 || p > kMlpParams) return;
+    if (slice != 0 || p > a.nparams) return;
     g = 0.0f;
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) g += red[s2][j];
-    if (p == kMlpParams) {  // the loss slot
+    if (p == a.nparams) {  // the loss slot
         *a.loss_acc += (double)g * (double)a.inv_b;
         return;
     }
@@ -853,7 +873,12 @@ __global__ __launch_bounds__(256) void mlp_shuffle_kernel(Shuffle s, int64_t* ou
 
 }  // namespace
 
-size_t mlp_partial_bytes() { return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride; }
+size_t mlp_partial_bytes() { return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride3; }
+
+int mlp_train_param_count(int hidden, int layers)
+{
+    return (hidden == 64 && (layers == 2 || layers == 3)) ? train_params(layers) : -1;
+}
 
 hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out)
 {
@@ -863,21 +888,14 @@ hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, 
     return hipGetLastError();
 }
 
-hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
+template <int L>
+static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
 {
     static bool attr_set = false;
-    // workgroup size: 4 waves (one per SIMD).  OMC_MLP_WAVES=8 runs two per SIMD; measured no
-    // faster: float32 MFMA executes on the SIMD's float32 lanes (it has the vector rate), so a
-    // second wave's vector arithmetic cannot run underneath it
-    static const int waves = (getenv("OMC_MLP_WAVES") && atoi(getenv("OMC_MLP_WAVES")) == 8) ? 8 : 4;
-    const size_t lds_bytes = sizeof(float) * (size_t)lds_floats(waves);
+    const size_t lds_bytes = sizeof(float) * (size_t)train_lds_floats(L);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_kernel<4>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(float) * lds_floats(4)));
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_kernel<8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * lds_floats(8)));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_kernel<L>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -900,10 +918,9 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         a.step = (uint32_t)step;
         a.k0 = (uint32_t)t.seed;
         a.k1 = (uint32_t)(t.seed >> 32);
-        int groups = (a.ntiles + waves - 1) / waves;
+        int groups = (a.ntiles + 3) / 4;
         if (groups > kMlpMaxGroups) groups = kMlpMaxGroups;
-        if (waves == 4) hipLaunchKernelGGL(mlp_train_kernel<4>, dim3(groups), dim3(256), lds_bytes, st, a);
-        else hipLaunchKernelGGL(mlp_train_kernel<8>, dim3(groups), dim3(512), lds_bytes, st, a);
+        hipLaunchKernelGGL(mlp_train_kernel<L>, dim3(groups), dim3(256), lds_bytes, st, a);
         MlpAdamArgs b;
         b.params = t.params;
         b.m = t.adam_m;
@@ -911,6 +928,8 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         b.partial = t.partial;
         b.loss_acc = t.loss_acc;
         b.nparts = groups;
+        b.nparams = train_params(L);
+        b.stride = g_stride(L);
         b.inv_b = (float)(1.0 / (double)nb);
         const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
         b.lr_t = (float)(t.lr / bc1);
@@ -919,9 +938,16 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         b.beta2 = (float)t.beta2;
         b.eps = (float)t.eps;
         b.wd = (float)t.weight_decay;
-        hipLaunchKernelGGL(mlp_adam_kernel, dim3((kMlpParams + 16) / 16), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(mlp_adam_kernel, dim3((train_params(L) + 16) / 16), dim3(256), 0, st, b);
     }
     return hipGetLastError();
+}
+
+hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
+{
+    if (t.layers == 2) return train_steps<2>(st, t);
+    if (t.layers == 3) return train_steps<3>(st, t);
+    return hipErrorInvalidValue;
 }
 
 int mlp_apply_param_count(int hidden, int layers)

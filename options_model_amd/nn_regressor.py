@@ -218,9 +218,9 @@ def _linear_shape(net):
 
 
 def fused_trainer_supports(net):
-    """The hand-written trainer (omc_mlp_train_epoch) covers the network BASELINE config 5
-    names: 7 -> 64 -> 64 -> 1."""
-    return _linear_shape(net) == (64, 2)
+    """The hand-written trainer (omc_mlp_train_epoch) covers 64 hidden units x 2 hidden layers (the
+    network BASELINE config 5 names) or 3 (the depth the reference's SingleLSMNet always has)."""
+    return _linear_shape(net) in ((64, 2), (64, 3))
 
 
 def fused_apply_supports(net):
@@ -244,16 +244,21 @@ def flatten_params(net):
 
 
 def unflatten_params(net, flat):
+    """Inverse of flatten_params: write the flat vector back into the network's Linear layers."""
     torch = _torch()
-    l1, l2, l3 = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    H = lin[0].out_features
     with torch.no_grad():
-        w1 = flat[:512].view(64, 8)
-        l1.weight.copy_(w1[:, :7])
-        l1.bias.copy_(w1[:, 7])
-        l2.weight.copy_(flat[512:4608].view(64, 64))
-        l2.bias.copy_(flat[4608:4672])
-        l3.weight.copy_(flat[4672:4736].view(1, 64))
-        l3.bias.copy_(flat[4736:4737])
+        w1 = flat[:H * 8].view(H, 8)
+        lin[0].weight.copy_(w1[:, :7])
+        lin[0].bias.copy_(w1[:, 7])
+        o = H * 8
+        for m in lin[1:-1]:
+            m.weight.copy_(flat[o:o + H * H].view(H, H))
+            m.bias.copy_(flat[o + H * H:o + H * H + H])
+            o += H * H + H
+        lin[-1].weight.copy_(flat[o:o + H].view(1, H))
+        lin[-1].bias.copy_(flat[o + H:o + H + 1])
 
 
 def _dropout_of(net):
@@ -285,7 +290,7 @@ def _train_fused(net, data, epochs, lr, bs, verbose):
         # the epoch's shuffle (:575 randperm) is a keyed permutation evaluated inside the kernel
         avg, step = ctx.mlp_train_epoch(data.data_ptr(), R, bs, params.data_ptr(), m.data_ptr(), v.data_ptr(),
                                         step, sched.optimizer.param_groups[0]["lr"], p_drop, seed,
-                                        shuffle_key=(seed ^ (0x9E3779B97F4A7C15 * (epoch + 1))) % (1 << 64) or 1)
+                                        hidden=64, layers=_linear_shape(net)[1], shuffle_key=(seed ^ (0x9E3779B97F4A7C15 * (epoch + 1))) % (1 << 64) or 1)
         t_kernels += time.perf_counter() - t1
         sched.step(avg)
         if avg < best - 1e-6:
@@ -305,7 +310,7 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
           use_graph=True, trainer="auto"):
     """:565-613: Adam(lr, wd 1e-5), MSE, shuffled minibatches, ReduceLROnPlateau on the epoch-mean
     loss, early stop after 8 non-improving epochs, best-weights restore.
-    trainer: "hip" = the library's fused MFMA kernels (7->64->64->1 only), "torch" = PyTorch-ROCm
+    trainer: "hip" = the library's fused MFMA kernels (64 units x 2 or 3 hidden layers), "torch" = PyTorch-ROCm
     autograd (any SingleLSMNet shape), "auto" = hip where it applies."""
     torch = _torch()
     R = x.numel()
@@ -318,7 +323,7 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
     if trainer not in ("auto", "hip", "torch"):
         raise ValueError("trainer must be 'auto', 'hip' or 'torch'")
     if trainer == "hip" and not fused_trainer_supports(net):
-        raise ValueError("trainer='hip' covers SingleLSMNet(7, 64, 2) only")
+        raise ValueError("trainer='hip' covers SingleLSMNet(7, 64, 2 or 3) only")
     if trainer != "torch" and fused_trainer_supports(net):
         return dict(_train_fused(net, data, epochs, lr, bs, verbose), seconds_matrix=t_m)
     # state snapshots for the warm-up steps of the graph capture must not leak into training
