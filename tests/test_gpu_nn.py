@@ -112,6 +112,27 @@ def test_config1_nn_end_to_end_band(torch_cuda, golden):
     assert p.rng_manager.get_child_seed() == golden["scalars"]["rng_manager_42_child_seeds"][2]
 
 
+def test_config1_nn_hidden64_all_hip_lands_in_the_reference_band(torch_cuda, golden):
+    """Same flow with nn_hidden=64: SingleLSMNet(7, 64, 3) -- here the network is trained by the
+    library's fused MFMA trainer and applied by its pass-2 kernel (no PyTorch autograd, no PyTorch
+    forward).  The reference's own prices for this setting over four seeds are in
+    scalars.json["reference_nn_seed_band_h64"] (tools/capture_reference_band.py --hidden 64, ~75 s of
+    CPU each); ours must land in that band, and their mean inside its range."""
+    from options_model_amd import AdvancedOptionPricer, RNGManager
+    refs = list(golden["scalars"]["reference_nn_seed_band_h64"].values())
+    assert len(refs) >= 4
+    lo, hi = min(refs), max(refs)
+    prices = []
+    for seed in (42, 1, 2, 3):
+        p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(seed),
+                                 use_control_variate=False, regressor="nn", nn_hidden=64)
+        prices.append(p.price_american_option(100.0, 1.0, 10000, 50))
+        info = p.last_result
+        assert info["trainer"] == "hip" and info["pass2"] == "hip" and info["batch"] == 256
+        assert lo - 0.3 < prices[-1] < hi + 0.3, (prices, refs)
+    assert lo - 0.1 < sum(prices) / len(prices) < hi + 0.1, (prices, refs)
+
+
 def test_facade_nn_regressor_2x64(torch_cuda):
     from options_model_amd import price_american_option
     res = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 40_000, 25, regressor="nn", seed=3)
