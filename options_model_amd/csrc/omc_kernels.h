@@ -91,13 +91,12 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
 hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval);
 
 // ---- continuation-value network of the NN flow (omc_mlp.hip): 7 -> 64 -> 64 (-> 64) -> 1
-constexpr int kMlpParams = 64 * 8 + 64 * 64 + 64 + 64 + 1;  // two hidden layers: W1|b1 [64][8], W2, b2, w3, b3
 constexpr int kMlpPartialStride2 = 4800;                   // gradient partial per workgroup, 2 / 3 hidden layers
 constexpr int kMlpPartialStride3 = 8960;                   // (>= parameters + 1 loss slot, multiple of 64)
 constexpr int kMlpMaxGroups = 256;                         // one workgroup per CU
 struct MlpTrainPlan {
     const float* data;  // [nrows][8] float32: 7 inputs + target
-    float* params;      // [kMlpParams], updated in place
+    float* params;      // [mlp_train_param_count(64, layers)], updated in place
     float* adam_m;
     float* adam_v;
     float* partial;     // mlp_partial_bytes()
