@@ -80,6 +80,7 @@ struct omc_ctx {
     double D_r = 0, D_T = 0;
     const double* D_ptr = nullptr;
     double hres[8];
+    double* hres_pin = nullptr;  // pinned: the result copy of the fused pricing call is truly asynchronous
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int gbm_vec = 0, heston_vec = 0;
     int world = 1;  // ranks whose sums the hook adds up (equal shards)
@@ -115,6 +116,19 @@ int bind(omc_ctx* c)
 {
     if (!c) return fail(-7, "null context.");
     HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+// Wait for the stream by polling: a pricing lasts well under a millisecond, and the wake-up
+// latency of a blocking hipStreamSynchronize is a visible fraction of that.
+int wait_stream(omc_ctx* c)
+{
+    for (int i = 0; i < 400000; ++i) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) HIP_TRY(q);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -278,6 +292,8 @@ int omc_ctx_create(int device, void* hip_stream, omc_ctx** out)
             HIP_TRY(e);
         }
     }
+    if (hipHostMalloc((void**)&c->hres_pin, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess)
+        c->hres_pin = nullptr;  // fall back to the pageable member
     *out = c;
     return 0;
 }
@@ -293,6 +309,7 @@ int omc_ctx_destroy(omc_ctx* c)
         b->release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (c->hres_pin) (void)hipHostFree(c->hres_pin);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -574,10 +591,11 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     if ((rc = enqueue_lsm(c, prob, w, p->semantics, false))) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    double* hres = c->hres_pin ? c->hres_pin : c->hres;
+    HIP_TRY(hipMemcpyAsync(hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = wait_stream(c))) return rc;
     memset(res, 0, sizeof *res);
-    fill_result(res, c->hres, c->hook ? M * c->world : M);  // hook: sums are global
+    fill_result(res, hres, c->hook ? M * c->world : M);  // hook: sums are global
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     res->ms_paths = ms;
