@@ -167,9 +167,9 @@ int omc_heston_price_strikes(omc_ctx* ctx, int64_t n_paths, int n_steps, double 
 /* ---- NN continuation-value regressor: fused training of the network ------------------------ */
 /* replaces the minibatch loop of price_american_enhanced_lsm (options_model_3.py:565-600:
  * SingleLSMNet(7, hidden, layers) :85-103, nn.MSELoss, optim.Adam(lr, weight_decay), shuffled
- * minibatches) for hidden = 64 with layers = 2 (the network BASELINE config 5 names, 7 -> 64 ->
- * 64 -> 1) or layers = 3 (the depth SingleLSMNet always has in the reference); anything else
- * returns -9 (omc_mlp_param_count also knows the shapes that only omc_lsm_apply_mlp supports).
+ * minibatches) for hidden = 64 or 128 with layers = 2 (BASELINE config 5 names 7 -> 64 -> 64 -> 1)
+ * or 3 (the depth SingleLSMNet always has in the reference; 3 x 128 is its default) -- see
+ * omc_mlp_train_supported for the batch sizes; anything else returns -9.
  * One call = one epoch over `n_rows` rows of
  * `data` ([n_rows][8] float32 device memory: 7 normalised features + normalised target):
  * ceil(n_rows / batch) optimizer steps of float32 MFMA forward/backward + Adam.  The epoch
@@ -205,6 +205,9 @@ int omc_lsm_apply_mlp(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
  * their population variances (two passes: mean first, then squared deviations).  out16: host. */
 int omc_nn_feature_stats(omc_ctx* ctx, const double* x, const int32_t* t, const double* y,
                          int64_t n_rows, double T, double dt, double* out16);
+/* 1 if omc_mlp_train_epoch covers this network shape at this minibatch size: hidden 64 with 2 or 3
+ * hidden layers at any batch; hidden 128 (the reference's default width) up to batch 8192. */
+int omc_mlp_train_supported(int hidden, int layers, int64_t batch);
 int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t batch, int hidden,
                         int layers, float* params, float* adam_m, float* adam_v, int64_t* step,
                         double lr, double beta1, double beta2, double eps, double weight_decay,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "omc_price_american_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_price_european_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_mlp_param_count": (C.c_int, [_I, _I]),
+    "omc_mlp_train_supported": (C.c_int, [_I, _I, _I64]),
     "omc_mlp_train_epoch": (C.c_int, [_P, _P, _I64, _I64, _I, _I, _P, _P, _P, C.POINTER(C.c_int64)]
                             + [_D] * 6 + [_U64, _U64, C.POINTER(C.c_double)]),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),

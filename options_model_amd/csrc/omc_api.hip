@@ -72,7 +72,7 @@ struct omc_ctx {
     bool own_stream = false;
     DevBuf S, sx, tex, D, part, gmom, betas, part1, result, scratch;
     DevBuf bslab, btable, bres, bdisc;  // batched path: problem slab, table, results, discounts
-    DevBuf mlp_part, mlp_loss;          // NN training: gradient partials, epoch loss
+    DevBuf mlp_part, mlp_loss, mlp_wt;  // NN training: gradient partials, epoch loss, transposed connections
     std::vector<char> h_table;
     std::vector<double> h_disc, h_bres;
     std::vector<double> hD;
@@ -305,7 +305,7 @@ int omc_ctx_destroy(omc_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc, &c->mlp_part,
-                      &c->mlp_loss})
+                      &c->mlp_loss, &c->mlp_wt})
         b->release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -768,6 +768,11 @@ int omc_price_european_batch(omc_ctx* c, const omc_params* p, int n, omc_result*
 
 int omc_mlp_param_count(int hidden, int layers) { return omc::mlp_apply_param_count(hidden, layers); }
 
+int omc_mlp_train_supported(int hidden, int layers, int64_t batch)
+{
+    return omc::mlp_train_kernel_choice(hidden, layers, batch) != 0;
+}
+
 int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
                       double r, double T, int is_put, int hidden, int layers, const float* params,
                       const double* feat_mean, const double* feat_std, double y_mean, double y_std,
@@ -853,19 +858,22 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
 {
     int rc = bind(c);
     if (rc) return rc;
-    if (omc::mlp_train_param_count(hidden, layers) < 0)
-        return fail(-9, "the fused trainer supports hidden = 64 with 2 or 3 hidden layers.");
+    if (omc::mlp_train_kernel_choice(hidden, layers, batch) == 0)
+        return fail(-9, "the fused trainer supports hidden = 64 (any batch) or 128 (batch <= 8192) "
+                        "with 2 or 3 hidden layers.");
     if (!data || !params || !adam_m || !adam_v || !step || !mean_loss) return fail(-7, "null pointer.");
     if (n_rows <= 0 || batch <= 0 || *step < 0) return fail(-3, "n_rows, batch must be positive.");
     if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
     if (!(lr > 0.0)) return fail(-4, "learning rate must be positive.");
-    if ((rc = c->mlp_part.ensure(omc::mlp_partial_bytes()))) return rc;
+    if ((rc = c->mlp_part.ensure(omc::mlp_partial_bytes(hidden, layers, batch)))) return rc;
+    if ((rc = c->mlp_wt.ensure(omc::mlp_wt_bytes(hidden, layers)))) return rc;
     if ((rc = c->mlp_loss.ensure(sizeof(double)))) return rc;
     HIP_TRY(hipMemsetAsync(c->mlp_loss.p, 0, sizeof(double), c->stream));
     omc::MlpTrainPlan t;
     t.data = data; t.params = params; t.adam_m = adam_m; t.adam_v = adam_v;
     t.partial = (float*)c->mlp_part.p; t.loss_acc = (double*)c->mlp_loss.p;
-    t.nrows = n_rows; t.batch = batch; t.first_step = *step; t.layers = layers;
+    t.nrows = n_rows; t.batch = batch; t.first_step = *step; t.hidden = hidden; t.layers = layers;
+    t.wt = (float*)c->mlp_wt.p;
     t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.weight_decay = weight_decay;
     t.dropout = dropout; t.seed = seed; t.shuffle_key = shuffle_key;
     HIP_TRY(omc::mlp_train_steps(c->stream, t));

@@ -94,6 +94,7 @@ hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorksp
 constexpr int kMlpPartialStride2 = 4800;                   // gradient partial per workgroup, 2 / 3 hidden layers
 constexpr int kMlpPartialStride3 = 8960;                   // (>= parameters + 1 loss slot, multiple of 64)
 constexpr int kMlpMaxGroups = 256;                         // one workgroup per CU
+constexpr int kMlpTileMax = 256;                           // tile-per-wave trainer: at most this many 32-row tiles per step
 struct MlpTrainPlan {
     const float* data;  // [nrows][8] float32: 7 inputs + target
     float* params;      // [mlp_train_param_count(64, layers)], updated in place
@@ -102,13 +103,16 @@ struct MlpTrainPlan {
     float* partial;     // mlp_partial_bytes()
     double* loss_acc;   // += batch-mean loss of every step
     int64_t nrows, batch, first_step;  // optimizer steps taken before this call
-    int layers;                        // hidden layers: 2 or 3 (64 units each)
+    int hidden, layers;                // 64 or 128 units x 2 or 3 hidden layers
+    float* wt;                         // mlp_wt_bytes(): transposed connections (tile-per-wave trainer)
     double lr, beta1, beta2, eps, weight_decay, dropout;
     uint64_t seed;         // dropout bits
     uint64_t shuffle_key;  // 0: rows in storage order; else a keyed pseudo-random permutation
 };
-size_t mlp_partial_bytes();
-int mlp_train_param_count(int hidden, int layers);  // -1: shape not covered by the trainer
+size_t mlp_partial_bytes(int hidden, int layers, int64_t batch);
+size_t mlp_wt_bytes(int hidden, int layers);
+int mlp_train_param_count(int hidden, int layers);               // -1: shape not covered by a trainer
+int mlp_train_kernel_choice(int hidden, int layers, int64_t batch);  // 0: this batch size is not covered
 // pass 2 of the NN flow: sticky sweep with the network as continuation value -> (sx, tex)
 // hidden in {64, 128}, layers (hidden layers) in {2, 3}; mlp_apply_param_count: floats, -1 otherwise
 int mlp_apply_param_count(int hidden, int layers);

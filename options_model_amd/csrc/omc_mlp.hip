@@ -456,6 +456,8 @@ struct MlpAdamArgs {
     double* loss_acc;  // running sum of batch-mean losses of the epoch
     int nparts, nparams, stride;  // the loss slot is index nparams
     float inv_b, lr_t, inv_sqrt_bc2, beta1, beta2, eps, wd;
+    float* wt;  // optional transposed copies of the connections (tile-per-wave trainer), else null
+    int H, L;
 };
 
 // 16 parameters per workgroup, 16 threads per parameter: thread (slice, j) sums partials
@@ -488,7 +490,18 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a)
     a.m[p] = m;
     a.v[p] = v;
     const float denom = __builtin_amdgcn_sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
-    a.params[p] = w0 - a.lr_t * (m / denom);
+    const float w1 = w0 - a.lr_t * (m / denom);
+    a.params[p] = w1;
+    if (a.wt) {
+        const int conn = a.H * a.H + a.H, q = p - a.H * 8;
+        if (q >= 0 && q < (a.L - 1) * conn) {
+            const int jc = q / conn, rem = q - jc * conn;
+            if (rem < a.H * a.H) {
+                const int i = rem / a.H, k = rem - i * a.H;
+                a.wt[(size_t)jc * a.H * a.H + (size_t)k * a.H + i] = w1;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ feature statistics
@@ -594,6 +607,299 @@ __device__ __forceinline__ void relu_dropout_n(v16f (&z)[NT], uint32_t row, uint
         relu_dropout<true>(pair, row, step, tag + 0x1000u * (uint32_t)p, keep16, inv_keep, k0, k1);
         z[p] = pair[0];
         z[p + 1] = pair[1];
+    }
+}
+
+// ------------------------------------------------------------------ tile-per-wave trainer
+// The same training step for the shapes and batch sizes the workgroup kernel above does not fit:
+// 128 hidden units (two 128 x 128 matrices do not fit LDS beside the staging patches) and small
+// minibatches (the reference's own batch of 256 rows is 8 tiles).  One wave = one 32-row tile =
+// one workgroup; the A operands (weights) come straight from global memory / L2 -- tiles are few,
+// so that traffic is small -- and because a wave sees exactly one tile there is nothing to
+// accumulate across tiles: each 32 x H strip of a weight gradient is complete after its 16 k-steps
+// and goes directly to the tile's gradient partial in global memory.
+//
+// Units are dealt to the 32-unit MFMA tiles round-robin: slot 32*mt + rho <-> unit NT*rho + mt
+// (NT = H / 32).  A lane that owns tile-row rho = c then needs, for one k, the NT consecutive
+// weights W[k][NT*c .. NT*c + NT-1]: one 16-byte load feeds NT MFMAs, and the NT accumulators of a
+// gradient strip store as one 16-byte chunk per register.  LDS staging is addressed by slot (same
+// patches and swizzle as above), global parameters and gradients by unit.  Forward products read a
+// TRANSPOSED copy of each connection (kept up to date by the Adam kernel) so that those loads are
+// row-contiguous too.
+struct MlpTileArgs {
+    const float* data;
+    const float* params;  // canonical layout, mlp_params_of(H, L)
+    const float* wt;      // (L-1) x [H][H]: connection j transposed, wt_j[k][i] = W_j[i][k]
+    float* partial;       // [ntiles][pstride]
+    int64_t row0, nrows;
+    Shuffle shuf;
+    int ntiles, pstride;
+    float two_over_b, inv_keep;
+    uint32_t keep16, step, k0, k1;
+};
+
+template <int NT>
+struct VecN;
+template <>
+struct VecN<2> { typedef float2 type; };
+template <>
+struct VecN<4> { typedef float4 type; };
+template <int NT>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[NT])
+{
+    const typename VecN<NT>::type x = *reinterpret_cast<const typename VecN<NT>::type*>(p);
+    v[0] = x.x; v[1] = x.y;
+    if constexpr (NT == 4) { v[2] = x.z; v[3] = x.w; }
+}
+template <int NT>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[NT])
+{
+    typename VecN<NT>::type x;
+    x.x = v[0]; x.y = v[1];
+    if constexpr (NT == 4) { x.z = v[2]; x.w = v[3]; }
+    *reinterpret_cast<typename VecN<NT>::type*>(p) = x;
+}
+
+template <int NT, bool SCALE>
+__device__ __forceinline__ void relu_dropout_t(v16f (&z)[NT], uint32_t row, uint32_t step, uint32_t tag,
+                                               uint32_t keep16, float inv_keep, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int p = 0; p < NT; p += 2) {
+        v16f pair[2] = {z[p], z[p + 1]};
+        relu_dropout<SCALE>(pair, row, step, tag + 0x1000u * (uint32_t)p, keep16, inv_keep, k0, k1);
+        z[p] = pair[0];
+        z[p + 1] = pair[1];
+    }
+}
+
+__host__ __device__ constexpr int tile_lds_floats(int H, int L) { return L * H * 32 + 9 * 32 + (L - 1) * H + H + 4; }
+__host__ __device__ constexpr int tile_pstride(int H, int L) { return (mlp_params_of(H, L) + 1 + 63) / 64 * 64; }
+
+template <int H, int L>
+__global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
+{
+    constexpr int NT = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H;
+    extern __shared__ float lds[];
+    float* patch = lds;                    // [L][H slots][32 rows]
+    float* tX = patch + L * H * 32;        // [8][32] inputs + [32] d(loss)/d(out)
+    float* sB = tX + 9 * 32;               // (L-1) x [H] biases, by slot
+    float* sWo = sB + (L - 1) * H;         // output weights, by slot
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    auto rho = [&](int r) { return (r >> 2) * 8 + 4 * h + (r & 3); };  // tile row of accumulator register r
+    const float* Wo = a.params + H * 8 + (L - 1) * CONN;
+    for (int sl = lane; sl < H; sl += 64) {
+        const int unit = NT * (sl & 31) + (sl >> 5);
+#pragma unroll
+        for (int j = 0; j < L - 1; ++j) sB[j * H + sl] = a.params[H * 8 + j * CONN + H * H + unit];
+        sWo[sl] = Wo[unit];
+    }
+    const StageOfs so = stage_offsets(c, h);
+    const int64_t row = (int64_t)tile * 32 + c;
+    const bool live = row < a.nrows;
+    float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live) x = reinterpret_cast<const float4*>(a.data + shuffle_index(a.shuf, (uint64_t)(a.row0 + row)) * 8)[h];
+    float y = x.w;
+    if (h == 1) x.w = 1.0f;
+    y = __shfl(y, c + 32, 64);
+    tX[st_idx(4 * h + 0, c)] = x.x;
+    tX[st_idx(4 * h + 1, c)] = x.y;
+    tX[st_idx(4 * h + 2, c)] = x.z;
+    tX[st_idx(4 * h + 3, c)] = x.w;
+    float* out = a.partial + (size_t)tile * a.pstride;
+
+    // ---- layer 0
+    v16f act[L][NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[0][mt][r] = 0.0f;
+        const float4 w = *reinterpret_cast<const float4*>(a.params + (NT * c + mt) * 8 + 4 * h);
+        act[0][mt] = mfma(w.x, x.x, act[0][mt]);
+        act[0][mt] = mfma(w.y, x.y, act[0][mt]);
+        act[0][mt] = mfma(w.z, x.z, act[0][mt]);
+        act[0][mt] = mfma(w.w, x.w, act[0][mt]);
+    }
+    relu_dropout_t<NT, true>(act[0], (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[unit_base(mt, r) + so.wr[wr_sel(r)]] = act[0][mt][r];
+    wave_sync_lds();  // biases, inputs
+
+    // ---- layers 1 .. L-1: A = Wt_j[k][NT*c ..], one vector load per k-step feeds the NT tiles
+#pragma unroll
+    for (int j = 1; j < L; ++j) {
+        const float* Wt = a.wt + (size_t)(j - 1) * H * H;
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) act[j][mt][r] = sB[(j - 1) * H + 32 * mt + rho(r)];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float w[NT];
+                load_vec<NT>(Wt + (size_t)(NT * rho(s) + kt) * H + NT * c, w);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) act[j][mt] = mfma(w[mt], act[j - 1][kt][s], act[j][mt]);
+            }
+        }
+        relu_dropout_t<NT, true>(act[j], (uint32_t)row, a.step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, a.keep16,
+                                 a.inv_keep, a.k0, a.k1);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[j * H * 32 + unit_base(mt, r) + so.wr[wr_sel(r)]] = act[j][mt][r];
+    }
+
+    // ---- output, loss, d(loss)/d(out)
+    float o = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o = __builtin_fmaf(sWo[32 * mt + rho(r)], act[L - 1][mt][r], o);
+    o += __shfl_xor(o, 32, 64);
+    o += Wo[H];
+    const float diff = live ? o - y : 0.0f;
+    const float dout = diff * a.two_over_b;
+    if (h == 0) tX[8 * 32 + c] = dout;
+    v16f dz[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            dz[mt][r] = act[L - 1][mt][r] > 0.0f ? sWo[32 * mt + rho(r)] * dout * a.inv_keep : 0.0f;
+    wave_sync_lds();
+
+#pragma unroll
+    for (int j = L - 1; j >= 1; --j) {
+        const float* W = a.params + H * 8 + (size_t)(j - 1) * CONN;
+        float* gWj = out + H * 8 + (size_t)(j - 1) * CONN;
+        const float* pA = patch + j * H * 32;
+        const float* pB = patch + (j - 1) * H * 32;
+        // ---- gW_j strip by strip: rows i = slots 32*mi + c, all H columns; complete after 16 k-steps
+#pragma unroll
+        for (int mi = 0; mi < NT; ++mi) {
+            v16f acc[NT];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
+            const float woi = sWo[32 * mi + c] * a.inv_keep;
+            float gbs = 0.0f, gws = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 e = *reinterpret_cast<const float4*>(pA + 32 * 32 * mi + so.rd[q]);
+                const float4 dq = *reinterpret_cast<const float4*>(tX + 8 * 32 + 16 * h + 4 * q);
+                const float ev[4] = {e.x, e.y, e.z, e.w}, dv[4] = {dq.x, dq.y, dq.z, dq.w};
+                float bv[NT][4];
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    const float4 b = *reinterpret_cast<const float4*>(pB + 32 * 32 * ni + so.rd[q]);
+                    bv[ni][0] = b.x; bv[ni][1] = b.y; bv[ni][2] = b.z; bv[ni][3] = b.w;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float av = ev[jj];
+                    if (j == L - 1) {
+                        gws = __builtin_fmaf(dv[jj], ev[jj], gws);
+                        av = ev[jj] > 0.0f ? woi * dv[jj] : 0.0f;
+                    }
+                    gbs += av;
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) acc[ni] = mfma(av, bv[ni][jj], acc[ni]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v[NT];
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) v[ni] = acc[ni][r];
+                store_vec<NT>(gWj + (size_t)(NT * rho(r) + mi) * H + NT * c, v);
+            }
+            gbs += __shfl_xor(gbs, 32, 64);
+            gws += __shfl_xor(gws, 32, 64);
+            if (h == 0) {
+                gWj[H * H + NT * c + mi] = gbs;
+                if (j == L - 1) out[H * 8 + (L - 1) * CONN + NT * c + mi] = gws;
+            }
+        }
+        // ---- dH_{j-1} = W_j^T dZ_j: A = W_j[i][NT*c ..]
+        v16f d[NT];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[mt][r] = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float w[NT];
+                load_vec<NT>(W + (size_t)(NT * rho(s) + it) * H + NT * c, w);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) d[mt] = mfma(w[mt], dz[it][s], d[mt]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[mt][r] = act[j - 1][mt][r] > 0.0f ? d[mt][r] * a.inv_keep : 0.0f;
+        wave_sync_lds();
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[(j - 1) * H * 32 + unit_base(mt, r) + so.wr[wr_sel(r)]] = dz[mt][r];
+        wave_sync_lds();
+    }
+
+    // ---- gW1a: 16x16x4 tiles over slots 16*mt4 + lane%16, k-slot lane/16 of step s <-> row 8*kq + s
+    {
+        const int l16 = lane & 15, kq = lane >> 4, sw = ((l16 >> 1) & 7) << 2;
+        const int o0 = l16 * 32 + ((8 * kq) ^ sw), o1 = l16 * 32 + ((8 * kq + 4) ^ sw);
+        float4 bq0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), bq1 = bq0;
+        if (l16 < 8) {
+            bq0 = *reinterpret_cast<const float4*>(tX + o0);
+            bq1 = *reinterpret_cast<const float4*>(tX + o1);
+        }
+        const float bv[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
+#pragma unroll
+        for (int mt4 = 0; mt4 < H / 16; ++mt4) {
+            const float4 aq0 = *reinterpret_cast<const float4*>(patch + 16 * 32 * mt4 + o0);
+            const float4 aq1 = *reinterpret_cast<const float4*>(patch + 16 * 32 * mt4 + o1);
+            const float av[8] = {aq0.x, aq0.y, aq0.z, aq0.w, aq1.x, aq1.y, aq1.z, aq1.w};
+            v4f g = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) g = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8], bv[s8], g, 0, 0, 0);
+            if (l16 < 8) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = 16 * mt4 + 4 * (lane >> 4) + r;
+                    out[(NT * (slot & 31) + (slot >> 5)) * 8 + l16] = g[r];
+                }
+            }
+        }
+    }
+    float gbo = h == 0 ? dout : 0.0f, loss = h == 0 ? diff * diff : 0.0f;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        gbo += __shfl_xor(gbo, m, 64);
+        loss += __shfl_xor(loss, m, 64);
+    }
+    if (lane == 0) {
+        out[NP - 1] = gbo;
+        out[NP] = loss;
+    }
+}
+
+// wt_j[k][i] = W_j[i][k] for the L-1 connections (start of an epoch; Adam keeps it current)
+__global__ __launch_bounds__(256) void mlp_transpose_kernel(const float* params, float* wt, int H, int L)
+{
+    const int n = (L - 1) * H * H;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        const int j = idx / (H * H), rem = idx - j * H * H, k = rem / H, i = rem - k * H;
+        wt[idx] = params[H * 8 + j * (H * H + H) + i * H + k];
     }
 }
 
@@ -873,12 +1179,33 @@ __global__ __launch_bounds__(256) void mlp_shuffle_kernel(Shuffle s, int64_t* ou
 
 }  // namespace
 
-size_t mlp_partial_bytes() { return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride3; }
+// Which kernel trains (hidden, layers) at this minibatch size: 1 = workgroup kernel (64 units,
+// weights in LDS, any batch), 2 = tile-per-wave kernel (64 or 128 units, at most kMlpTileMax
+// tiles of 32 rows), 0 = neither.
+int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
+{
+    if (layers != 2 && layers != 3) return 0;
+    const int64_t tiles = (batch + 31) / 32;
+    if (hidden == 64) return tiles <= 32 ? 2 : 1;
+    if (hidden == 128) return tiles <= kMlpTileMax ? 2 : 0;
+    return 0;
+}
 
 int mlp_train_param_count(int hidden, int layers)
 {
-    return (hidden == 64 && (layers == 2 || layers == 3)) ? train_params(layers) : -1;
+    if ((hidden != 64 && hidden != 128) || (layers != 2 && layers != 3)) return -1;
+    return mlp_params_of(hidden, layers);
 }
+
+size_t mlp_partial_bytes(int hidden, int layers, int64_t batch)
+{
+    const int choice = mlp_train_kernel_choice(hidden, layers, batch);
+    if (choice == 1) return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride3;
+    if (choice == 2) return sizeof(float) * (size_t)((batch + 31) / 32) * tile_pstride(hidden, layers);
+    return 0;
+}
+
+size_t mlp_wt_bytes(int hidden, int layers) { return sizeof(float) * (size_t)(layers - 1) * hidden * hidden; }
 
 hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out)
 {
@@ -930,6 +1257,7 @@ static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
         b.nparts = groups;
         b.nparams = train_params(L);
         b.stride = g_stride(L);
+        b.wt = nullptr; b.H = kH; b.L = L;
         b.inv_b = (float)(1.0 / (double)nb);
         const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
         b.lr_t = (float)(t.lr / bc1);
@@ -943,10 +1271,71 @@ static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
     return hipGetLastError();
 }
 
+template <int H, int L>
+static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
+{
+    static bool attr_set = false;
+    const size_t lds_bytes = sizeof(float) * (size_t)tile_lds_floats(H, L);
+    if (!attr_set && lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
+    const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
+    int64_t step = t.first_step;
+    for (int64_t o = 0; o < t.nrows; o += t.batch) {
+        const int64_t nb = (t.nrows - o < t.batch) ? t.nrows - o : t.batch;
+        ++step;
+        MlpTileArgs a;
+        a.data = t.data;
+        a.params = t.params;
+        a.wt = t.wt;
+        a.partial = t.partial;
+        a.row0 = o;
+        a.nrows = nb;
+        a.shuf = sh;
+        a.ntiles = (int)((nb + 31) / 32);
+        a.pstride = tile_pstride(H, L);
+        a.two_over_b = (float)(2.0 / (double)nb);
+        a.keep16 = t.dropout > 0.0 ? (uint32_t)llround((1.0 - t.dropout) * 65536.0) : 65536u;
+        a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
+        a.step = (uint32_t)step;
+        a.k0 = (uint32_t)t.seed;
+        a.k1 = (uint32_t)(t.seed >> 32);
+        hipLaunchKernelGGL((mlp_train_tile_kernel<H, L>), dim3(a.ntiles), dim3(64), lds_bytes, st, a);
+        MlpAdamArgs b;
+        b.params = t.params;
+        b.m = t.adam_m;
+        b.v = t.adam_v;
+        b.partial = t.partial;
+        b.loss_acc = t.loss_acc;
+        b.nparts = a.ntiles;
+        b.nparams = mlp_params_of(H, L);
+        b.stride = a.pstride;
+        b.wt = t.wt; b.H = H; b.L = L;
+        b.inv_b = (float)(1.0 / (double)nb);
+        const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
+        b.lr_t = (float)(t.lr / bc1);
+        b.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        b.beta1 = (float)t.beta1;
+        b.beta2 = (float)t.beta2;
+        b.eps = (float)t.eps;
+        b.wd = (float)t.weight_decay;
+        hipLaunchKernelGGL(mlp_adam_kernel, dim3((mlp_params_of(H, L) + 16) / 16), dim3(256), 0, st, b);
+    }
+    return hipGetLastError();
+}
+
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
 {
-    if (t.layers == 2) return train_steps<2>(st, t);
-    if (t.layers == 3) return train_steps<3>(st, t);
+    const int choice = mlp_train_kernel_choice(t.hidden, t.layers, t.batch);
+    if (choice == 1) return t.layers == 2 ? train_steps<2>(st, t) : train_steps<3>(st, t);
+    if (choice == 2) {
+        if (t.hidden == 64) return t.layers == 2 ? tile_steps<64, 2>(st, t) : tile_steps<64, 3>(st, t);
+        return t.layers == 2 ? tile_steps<128, 2>(st, t) : tile_steps<128, 3>(st, t);
+    }
     return hipErrorInvalidValue;
 }
 

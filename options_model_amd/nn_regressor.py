@@ -217,10 +217,15 @@ def _linear_shape(net):
     return H, len(dims) - 1
 
 
-def fused_trainer_supports(net):
-    """The hand-written trainer (omc_mlp_train_epoch) covers 64 hidden units x 2 hidden layers (the
-    network BASELINE config 5 names) or 3 (the depth the reference's SingleLSMNet always has)."""
-    return _linear_shape(net) in ((64, 2), (64, 3))
+def fused_trainer_supports(net, batch=256):
+    """The hand-written trainers (omc_mlp_train_epoch) cover 64 hidden units x 2 or 3 hidden layers at
+    any minibatch size (workgroup kernel, weights in LDS; BASELINE config 5 names 2 x 64) and 128
+    units -- the reference's default width -- up to a minibatch of 8192 rows (tile-per-wave kernel)."""
+    shape = _linear_shape(net)
+    if shape is None:
+        return False
+    lib = _ffi.load_library()
+    return bool(lib.omc_mlp_train_supported(int(shape[0]), int(shape[1]), int(batch)))
 
 
 def fused_apply_supports(net):
@@ -290,7 +295,7 @@ def _train_fused(net, data, epochs, lr, bs, verbose):
         # the epoch's shuffle (:575 randperm) is a keyed permutation evaluated inside the kernel
         avg, step = ctx.mlp_train_epoch(data.data_ptr(), R, bs, params.data_ptr(), m.data_ptr(), v.data_ptr(),
                                         step, sched.optimizer.param_groups[0]["lr"], p_drop, seed,
-                                        hidden=64, layers=_linear_shape(net)[1], shuffle_key=(seed ^ (0x9E3779B97F4A7C15 * (epoch + 1))) % (1 << 64) or 1)
+                                        hidden=_linear_shape(net)[0], layers=_linear_shape(net)[1], shuffle_key=(seed ^ (0x9E3779B97F4A7C15 * (epoch + 1))) % (1 << 64) or 1)
         t_kernels += time.perf_counter() - t1
         sched.step(avg)
         if avg < best - 1e-6:
@@ -310,7 +315,7 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
           use_graph=True, trainer="auto"):
     """:565-613: Adam(lr, wd 1e-5), MSE, shuffled minibatches, ReduceLROnPlateau on the epoch-mean
     loss, early stop after 8 non-improving epochs, best-weights restore.
-    trainer: "hip" = the library's fused MFMA kernels (64 units x 2 or 3 hidden layers), "torch" = PyTorch-ROCm
+    trainer: "hip" = the library's fused MFMA kernels (64 or 128 units x 2 or 3 hidden layers), "torch" = PyTorch-ROCm
     autograd (any SingleLSMNet shape), "auto" = hip where it applies."""
     torch = _torch()
     R = x.numel()
@@ -322,9 +327,9 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
     t_m = time.perf_counter() - t_m
     if trainer not in ("auto", "hip", "torch"):
         raise ValueError("trainer must be 'auto', 'hip' or 'torch'")
-    if trainer == "hip" and not fused_trainer_supports(net):
-        raise ValueError("trainer='hip' covers SingleLSMNet(7, 64, 2 or 3) only")
-    if trainer != "torch" and fused_trainer_supports(net):
+    if trainer == "hip" and not fused_trainer_supports(net, bs):
+        raise ValueError("trainer='hip' covers SingleLSMNet(7, 64 | 128, 2 | 3); 128 units up to batch 8192")
+    if trainer != "torch" and fused_trainer_supports(net, bs):
         return dict(_train_fused(net, data, epochs, lr, bs, verbose), seconds_matrix=t_m)
     # state snapshots for the warm-up steps of the graph capture must not leak into training
     init_state = copy.deepcopy(net.state_dict())

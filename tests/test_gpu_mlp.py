@@ -42,14 +42,17 @@ def _flat_grads(torch, nnr, net):
     return nnr.flatten_params(g)
 
 
-@pytest.mark.parametrize("layers", [2, 3])
-@pytest.mark.parametrize("rows", [32, 100, 4096, 50_000])
-def test_gradients_and_loss_match_autograd(env, ctx, rows, layers):
+@pytest.mark.parametrize("hidden,layers", [(64, 2), (64, 3), (128, 2), (128, 3)])
+@pytest.mark.parametrize("rows", [32, 100, 1000, 4096, 50_000])
+def test_gradients_and_loss_match_autograd(env, ctx, rows, hidden, layers):
     """After ONE Adam step from zero moments, m = (1 - beta1) * (grad + wd * w): the first-moment
-    buffer exposes the kernel's gradient."""
+    buffer exposes the kernel's gradient.  64 units: <= 1024 rows run the tile-per-wave kernel, more
+    the workgroup kernel; 128 units: the tile-per-wave kernel (<= 8192 rows per step)."""
     torch, nnr, dev = env
+    if not ctx.lib.omc_mlp_train_supported(hidden, layers, rows):
+        pytest.skip("batch size outside the tile-per-wave trainer's range")
     torch.manual_seed(3)
-    net = nnr.make_net(7, 64, layers, 0.0).to(dev)
+    net = nnr.make_net(7, hidden, layers, 0.0).to(dev)
     data = _data(torch, dev, rows, 11)
     loss_t = _torch_grads(torch, net, data)
     gref = _flat_grads(torch, nnr, net)
@@ -57,8 +60,8 @@ def test_gradients_and_loss_match_autograd(env, ctx, rows, layers):
     p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
     torch.cuda.synchronize()
     loss, step = ctx.mlp_train_epoch(data.data_ptr(), rows, rows, p.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                     0, 1e-3, 0.0, 5, weight_decay=0.0, layers=layers)
-    assert step == 1 and p.numel() == ctx.lib.omc_mlp_param_count(64, layers)
+                                     0, 1e-3, 0.0, 5, weight_decay=0.0, hidden=hidden, layers=layers)
+    assert step == 1 and p.numel() == ctx.lib.omc_mlp_param_count(hidden, layers)
     assert loss == pytest.approx(float(loss_t.detach()), rel=2e-5)
     g = (m / 0.1).cpu().numpy()
     ref = gref.cpu().numpy()
@@ -70,18 +73,18 @@ def test_gradients_and_loss_match_autograd(env, ctx, rows, layers):
     assert torch.allclose(p[big], expect[big], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("layers", [2, 3])
-def test_many_steps_track_torch_adam(env, ctx, layers):
+@pytest.mark.parametrize("hidden,layers,bs", [(64, 2, 1000), (64, 3, 1000), (64, 2, 2500), (128, 3, 1000), (128, 2, 2500)])
+def test_many_steps_track_torch_adam(env, ctx, hidden, layers, bs):
     torch, nnr, dev = env
     torch.manual_seed(4)
-    net = nnr.make_net(7, 64, layers, 0.0).to(dev)
-    rows, bs = 10_000, 1000  # 10 steps, none ragged
+    net = nnr.make_net(7, hidden, layers, 0.0).to(dev)
+    rows = 10 * bs  # 10 steps, none ragged
     data = _data(torch, dev, rows, 12)
     p = nnr.flatten_params(net)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     torch.cuda.synchronize()
     loss, step = ctx.mlp_train_epoch(data.data_ptr(), rows, bs, p.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                     0, 1e-3, 0.0, 5, layers=layers)
+                                     0, 1e-3, 0.0, 5, hidden=hidden, layers=layers)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
     tot = 0.0
     for o in range(0, rows, bs):
@@ -96,7 +99,7 @@ def test_many_steps_track_torch_adam(env, ctx, layers):
     assert float(diff.max()) <= 2.5e-3 and float(diff.mean()) <= 2e-5
     # second epoch continues the step count (bias correction) and the loss keeps falling
     loss2, step2 = ctx.mlp_train_epoch(data.data_ptr(), rows, bs, p.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                       step, 1e-3, 0.0, 5, layers=layers)
+                                       step, 1e-3, 0.0, 5, hidden=hidden, layers=layers)
     assert step2 == 20 and loss2 < loss
 
 
@@ -170,21 +173,21 @@ def test_shuffled_epoch_visits_every_row_once(env, ctx):
     assert step == 13 and outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("layers", [2, 3])
-def test_dropout_is_inverted_bernoulli_and_deterministic(env, ctx, layers):
+@pytest.mark.parametrize("hidden,layers,rows", [(64, 2, 1 << 17), (64, 3, 1 << 17), (64, 2, 1024), (128, 3, 8192)])
+def test_dropout_is_inverted_bernoulli_and_deterministic(env, ctx, hidden, layers, rows):
     """All weights 0, all hidden biases 1, output weights 1/64, output bias 0, target 0: out = mean_j
-    keep_j / q over the last layer's units, so the batch loss is E[out^2] = 1 + (1 - q) / (64 q) for
+    keep_j / q over the last layer's H units, so the batch loss is E[out^2] = 1 + (1 - q) / (H q) for
     keep probability q = 1 - p."""
     torch, nnr, dev = env
-    rows = 1 << 17
+    H = hidden
     data = torch.zeros(rows, 8, device=dev)
-    n = ctx.lib.omc_mlp_param_count(64, layers)
+    n = ctx.lib.omc_mlp_param_count(H, layers)
     flat = torch.zeros(n, device=dev)
-    flat[:512].view(64, 8)[:, 7] = 1.0
+    flat[:H * 8].view(H, 8)[:, 7] = 1.0
     for j in range(layers - 1):
-        o = 512 + j * 4160
-        flat[o + 4096:o + 4160] = 1.0
-    flat[n - 65:n - 1] = 1.0 / 64
+        o = H * 8 + j * (H * H + H)
+        flat[o + H * H:o + H * H + H] = 1.0
+    flat[n - H - 1:n - 1] = 1.0 / H
     for p_drop in (0.1, 0.5):
         q = 1 - p_drop
         res = []
@@ -192,10 +195,10 @@ def test_dropout_is_inverted_bernoulli_and_deterministic(env, ctx, layers):
             p, m, v = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat)
             torch.cuda.synchronize()
             loss, _ = ctx.mlp_train_epoch(data.data_ptr(), rows, rows, p.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                          0, 1e-3, p_drop, seed, layers=layers)
+                                          0, 1e-3, p_drop, seed, hidden=hidden, layers=layers)
             res.append((loss, p.cpu().numpy()))
-        expect = 1 + (1 - q) / (64 * q)
-        sd = 2 * math.sqrt((1 - q) / (64 * q)) / math.sqrt(rows)
+        expect = 1 + (1 - q) / (H * q)
+        sd = 2 * math.sqrt((1 - q) / (H * q)) / math.sqrt(rows)
         assert abs(res[0][0] - expect) < 6 * sd + 1e-4
         assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])  # same seed: same bits
         assert res[0][0] != res[2][0]
@@ -269,7 +272,7 @@ def test_flatten_unflatten_roundtrip(env, hidden, layers):
     nnr.unflatten_params(b, flat)
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.equal(pa, pb)
-    assert nnr.fused_trainer_supports(a) == (hidden == 64)
+    assert nnr.fused_trainer_supports(a, 256) and nnr.fused_trainer_supports(a, 1 << 17) == (hidden == 64)
 
 
 def test_three_hidden_layers_train_and_price_through_the_kernels(env, ctx):
@@ -296,13 +299,16 @@ def test_unsupported_shapes_and_bad_arguments(env, ctx):
     p = torch.zeros(4737, device=dev)
     with pytest.raises(ValueError, match="hidden = 64"):
         ctx.mlp_train_epoch(d.data_ptr(), 64, 64, p.data_ptr(), p.data_ptr(), p.data_ptr(), 0, 1e-3, 0.0, 1,
-                            hidden=128, layers=3)
+                            hidden=32, layers=3)
+    assert lib.omc_mlp_train_supported(128, 3, 8192) == 1 and lib.omc_mlp_train_supported(128, 3, 8193) == 0
+    assert lib.omc_mlp_train_supported(64, 2, 1 << 20) == 1 and lib.omc_mlp_train_supported(64, 4, 256) == 0
     with pytest.raises(ValueError, match="dropout"):
         ctx.mlp_train_epoch(d.data_ptr(), 64, 64, p.data_ptr(), p.data_ptr(), p.data_ptr(), 0, 1e-3, 1.0, 1)
-    assert not nnr.fused_trainer_supports(nnr.make_net(7, 128, 3, 0.1))
+    assert nnr.fused_trainer_supports(nnr.make_net(7, 128, 3, 0.1), 256)
+    assert not nnr.fused_trainer_supports(nnr.make_net(7, 128, 3, 0.1), 1 << 17)
     assert nnr.fused_apply_supports(nnr.make_net(7, 128, 3, 0.1))
     with pytest.raises(ValueError, match="covers"):
-        nnr.train(nnr.make_net(7, 128, 3, 0.1).to(dev), torch.ones(10, device=dev, dtype=torch.float64),
+        nnr.train(nnr.make_net(7, 96, 3, 0.1).to(dev), torch.ones(10, device=dev, dtype=torch.float64),
                   torch.ones(10, device=dev, dtype=torch.int32), torch.ones(10, device=dev, dtype=torch.float64),
                   torch.zeros(7, device=dev, dtype=torch.float64), torch.ones(7, device=dev, dtype=torch.float64),
                   torch.zeros((), device=dev, dtype=torch.float64), torch.ones((), device=dev, dtype=torch.float64),
