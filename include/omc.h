@@ -205,8 +205,8 @@ int omc_lsm_apply_mlp(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
  * their population variances (two passes: mean first, then squared deviations).  out16: host. */
 int omc_nn_feature_stats(omc_ctx* ctx, const double* x, const int32_t* t, const double* y,
                          int64_t n_rows, double T, double dt, double* out16);
-/* 1 if omc_mlp_train_epoch covers this network shape at this minibatch size: hidden 64 with 2 or 3
- * hidden layers at any batch; hidden 128 (the reference's default width) up to batch 8192. */
+/* 1 if omc_mlp_train_epoch covers this network shape at this minibatch size: hidden 64 or 128 (the
+ * reference's default width) with 2 or 3 hidden layers, any batch. */
 int omc_mlp_train_supported(int hidden, int layers, int64_t batch);
 int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t batch, int hidden,
                         int layers, float* params, float* adam_m, float* adam_v, int64_t* step,

@@ -859,8 +859,7 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
     int rc = bind(c);
     if (rc) return rc;
     if (omc::mlp_train_kernel_choice(hidden, layers, batch) == 0)
-        return fail(-9, "the fused trainer supports hidden = 64 (any batch) or 128 (batch <= 8192) "
-                        "with 2 or 3 hidden layers.");
+        return fail(-9, "the fused trainer supports hidden = 64 or 128 with 2 or 3 hidden layers.");
     if (!data || !params || !adam_m || !adam_v || !step || !mean_loss) return fail(-7, "null pointer.");
     if (n_rows <= 0 || batch <= 0 || *step < 0) return fail(-3, "n_rows, batch must be positive.");
     if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");

@@ -94,7 +94,6 @@ hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorksp
 constexpr int kMlpPartialStride2 = 4800;                   // gradient partial per workgroup, 2 / 3 hidden layers
 constexpr int kMlpPartialStride3 = 8960;                   // (>= parameters + 1 loss slot, multiple of 64)
 constexpr int kMlpMaxGroups = 256;                         // one workgroup per CU
-constexpr int kMlpTileMax = 256;                           // tile-per-wave trainer: at most this many 32-row tiles per step
 struct MlpTrainPlan {
     const float* data;  // [nrows][8] float32: 7 inputs + target
     float* params;      // [mlp_train_param_count(64, layers)], updated in place

@@ -673,10 +673,12 @@ __device__ __forceinline__ void relu_dropout_t(v16f (&z)[NT], uint32_t row, uint
     }
 }
 
+// concurrent waves (= gradient partials) of the tile-per-wave trainer: what fits the chip at once
+__host__ __device__ constexpr int tile_waves_max(int H) { return H == 128 ? 768 : 1024; }
 __host__ __device__ constexpr int tile_lds_floats(int H, int L) { return L * H * 32 + 9 * 32 + (L - 1) * H + H + 4; }
 __host__ __device__ constexpr int tile_pstride(int H, int L) { return (mlp_params_of(H, L) + 1 + 63) / 64 * 64; }
 
-template <int H, int L>
+template <int H, int L, bool MULTI>
 __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
 {
     constexpr int NT = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H;
@@ -686,7 +688,6 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
     float* sB = tX + 9 * 32;               // (L-1) x [H] biases, by slot
     float* sWo = sB + (L - 1) * H;         // output weights, by slot
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x;
     auto rho = [&](int r) { return (r >> 2) * 8 + 4 * h + (r & 3); };  // tile row of accumulator register r
     const float* Wo = a.params + H * 8 + (L - 1) * CONN;
     for (int sl = lane; sl < H; sl += 64) {
@@ -696,6 +697,13 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
         sWo[sl] = Wo[unit];
     }
     const StageOfs so = stage_offsets(c, h);
+    float* out = a.partial + (size_t)blockIdx.x * a.pstride;
+    // A wave that gets more than one tile (large minibatches) adds the later tiles' gradients onto
+    // its partial in global memory: accumulators start from the stored strip instead of zero.
+    // (MULTI = false: launched with one wave per tile; the loop body runs once and `first` is a
+    // compile-time constant, which keeps the single-tile build free of the loop's register cost.)
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const bool first = !MULTI || tile == (int)blockIdx.x;
     const int64_t row = (int64_t)tile * 32 + c;
     const bool live = row < a.nrows;
     float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -703,11 +711,11 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
     float y = x.w;
     if (h == 1) x.w = 1.0f;
     y = __shfl(y, c + 32, 64);
+    wave_sync_lds();  // the previous tile's staging reads are done
     tX[st_idx(4 * h + 0, c)] = x.x;
     tX[st_idx(4 * h + 1, c)] = x.y;
     tX[st_idx(4 * h + 2, c)] = x.z;
     tX[st_idx(4 * h + 3, c)] = x.w;
-    float* out = a.partial + (size_t)tile * a.pstride;
 
     // ---- layer 0
     v16f act[L][NT];
@@ -784,9 +792,14 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
         for (int mi = 0; mi < NT; ++mi) {
             v16f acc[NT];
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
+            for (int r = 0; r < 16; ++r) {
+                float v[NT];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
+                for (int ni = 0; ni < NT; ++ni) v[ni] = 0.0f;
+                if (!first) load_vec<NT>(gWj + (size_t)(NT * rho(r) + mi) * H + NT * c, v);
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) acc[ni][r] = v[ni];
+            }
             const float woi = sWo[32 * mi + c] * a.inv_keep;
             float gbs = 0.0f, gws = 0.0f;
 #pragma unroll
@@ -822,8 +835,12 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
             gbs += __shfl_xor(gbs, 32, 64);
             gws += __shfl_xor(gws, 32, 64);
             if (h == 0) {
-                gWj[H * H + NT * c + mi] = gbs;
-                if (j == L - 1) out[H * 8 + (L - 1) * CONN + NT * c + mi] = gws;
+                float* pb = gWj + H * H + NT * c + mi;
+                *pb = first ? gbs : *pb + gbs;
+                if (j == L - 1) {
+                    float* pw = out + H * 8 + (L - 1) * CONN + NT * c + mi;
+                    *pw = first ? gws : *pw + gws;
+                }
             }
         }
         // ---- dH_{j-1} = W_j^T dZ_j: A = W_j[i][NT*c ..]
@@ -876,7 +893,8 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int slot = 16 * mt4 + 4 * (lane >> 4) + r;
-                    out[(NT * (slot & 31) + (slot >> 5)) * 8 + l16] = g[r];
+                    float* pg = out + (NT * (slot & 31) + (slot >> 5)) * 8 + l16;
+                    *pg = first ? g[r] : *pg + g[r];
                 }
             }
         }
@@ -888,9 +906,11 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
         loss += __shfl_xor(loss, m, 64);
     }
     if (lane == 0) {
-        out[NP - 1] = gbo;
-        out[NP] = loss;
+        out[NP - 1] = first ? gbo : out[NP - 1] + gbo;
+        out[NP] = first ? loss : out[NP] + loss;
     }
+    if (!MULTI) break;
+    }  // tiles of this wave
 }
 
 // wt_j[k][i] = W_j[i][k] for the L-1 connections (start of an epoch; Adam keeps it current)
@@ -1180,14 +1200,14 @@ __global__ __launch_bounds__(256) void mlp_shuffle_kernel(Shuffle s, int64_t* ou
 }  // namespace
 
 // Which kernel trains (hidden, layers) at this minibatch size: 1 = workgroup kernel (64 units,
-// weights in LDS, any batch), 2 = tile-per-wave kernel (64 or 128 units, at most kMlpTileMax
-// tiles of 32 rows), 0 = neither.
+// weights in LDS; large batches), 2 = tile-per-wave kernel (64 units at small batches, 128 units at
+// any batch), 0 = neither.
 int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
 {
     if (layers != 2 && layers != 3) return 0;
     const int64_t tiles = (batch + 31) / 32;
     if (hidden == 64) return tiles <= 32 ? 2 : 1;
-    if (hidden == 128) return tiles <= kMlpTileMax ? 2 : 0;
+    if (hidden == 128) return 2;
     return 0;
 }
 
@@ -1201,7 +1221,10 @@ size_t mlp_partial_bytes(int hidden, int layers, int64_t batch)
 {
     const int choice = mlp_train_kernel_choice(hidden, layers, batch);
     if (choice == 1) return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride3;
-    if (choice == 2) return sizeof(float) * (size_t)((batch + 31) / 32) * tile_pstride(hidden, layers);
+    if (choice == 2) {
+        const int64_t tiles = (batch + 31) / 32, cap = tile_waves_max(hidden);
+        return sizeof(float) * (size_t)(tiles < cap ? tiles : cap) * tile_pstride(hidden, layers);
+    }
     return 0;
 }
 
@@ -1277,8 +1300,11 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
     static bool attr_set = false;
     const size_t lds_bytes = sizeof(float) * (size_t)tile_lds_floats(H, L);
     if (!attr_set && lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -1304,14 +1330,18 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
         a.step = (uint32_t)step;
         a.k0 = (uint32_t)t.seed;
         a.k1 = (uint32_t)(t.seed >> 32);
-        hipLaunchKernelGGL((mlp_train_tile_kernel<H, L>), dim3(a.ntiles), dim3(64), lds_bytes, st, a);
+        const int waves = a.ntiles < tile_waves_max(H) ? a.ntiles : tile_waves_max(H);
+        if (waves == a.ntiles)
+            hipLaunchKernelGGL((mlp_train_tile_kernel<H, L, false>), dim3(waves), dim3(64), lds_bytes, st, a);
+        else
+            hipLaunchKernelGGL((mlp_train_tile_kernel<H, L, true>), dim3(waves), dim3(64), lds_bytes, st, a);
         MlpAdamArgs b;
         b.params = t.params;
         b.m = t.adam_m;
         b.v = t.adam_v;
         b.partial = t.partial;
         b.loss_acc = t.loss_acc;
-        b.nparts = a.ntiles;
+        b.nparts = waves;
         b.nparams = mlp_params_of(H, L);
         b.stride = a.pstride;
         b.wt = t.wt; b.H = H; b.L = L;

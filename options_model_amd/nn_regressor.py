@@ -219,8 +219,9 @@ def _linear_shape(net):
 
 def fused_trainer_supports(net, batch=256):
     """The hand-written trainers (omc_mlp_train_epoch) cover 64 hidden units x 2 or 3 hidden layers at
-    any minibatch size (workgroup kernel, weights in LDS; BASELINE config 5 names 2 x 64) and 128
-    units -- the reference's default width -- up to a minibatch of 8192 rows (tile-per-wave kernel)."""
+    any minibatch size (workgroup kernel with the weights in LDS, tile-per-wave kernel for small
+    minibatches; BASELINE config 5 names 2 x 64) and 128 units -- the reference's default width --
+    (tile-per-wave kernel)."""
     shape = _linear_shape(net)
     if shape is None:
         return False
@@ -328,7 +329,7 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
     if trainer not in ("auto", "hip", "torch"):
         raise ValueError("trainer must be 'auto', 'hip' or 'torch'")
     if trainer == "hip" and not fused_trainer_supports(net, bs):
-        raise ValueError("trainer='hip' covers SingleLSMNet(7, 64 | 128, 2 | 3); 128 units up to batch 8192")
+        raise ValueError("trainer='hip' covers SingleLSMNet(7, 64 | 128, 2 | 3)")
     if trainer != "torch" and fused_trainer_supports(net, bs):
         return dict(_train_fused(net, data, epochs, lr, bs, verbose), seconds_matrix=t_m)
     # state snapshots for the warm-up steps of the graph capture must not leak into training
