@@ -682,6 +682,7 @@ template <int H, int L, bool MULTI>
 __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
 {
     constexpr int NT = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H;
+    constexpr int kPF = 4;  // k-steps per prefetch group
     extern __shared__ float lds[];
     float* patch = lds;                    // [L][H slots][32 rows]
     float* tX = patch + L * H * 32;        // [8][32] inputs + [32] d(loss)/d(out)
@@ -744,14 +745,29 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) act[j][mt][r] = sB[(j - 1) * H + 32 * mt + rho(r)];
+        // weights of the next group of kPF k-steps are requested before the current group's MFMAs
+        // are issued: an L2 round trip is several MFMA groups long
+        {
+            float w[2][kPF][NT];
+            auto fetch_group = [&](int g, float (&dst)[kPF][NT]) {
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+                for (int i = 0; i < kPF; ++i) {
+                    const int ks = g * kPF + i, kt = ks >> 4, s = ks & 15;
+                    load_vec<NT>(Wt + (size_t)(NT * rho(s) + kt) * H + NT * c, dst[i]);
+                }
+            };
+            fetch_group(0, w[0]);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                float w[NT];
-                load_vec<NT>(Wt + (size_t)(NT * rho(s) + kt) * H + NT * c, w);
+            for (int g = 0; g < NT * 16 / kPF; ++g) {
+                if (g + 1 < NT * 16 / kPF) fetch_group(g + 1, w[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < NT; ++mt) act[j][mt] = mfma(w[mt], act[j - 1][kt][s], act[j][mt]);
+                for (int i = 0; i < kPF; ++i) {
+                    const int ks = g * kPF + i, kt = ks >> 4, s = ks & 15;
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt)
+                        act[j][mt] = mfma(w[g & 1][i][mt], act[j - 1][kt][s], act[j][mt]);
+                }
             }
         }
         relu_dropout_t<NT, true>(act[j], (uint32_t)row, a.step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, a.keep16,
@@ -849,14 +865,26 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[mt][r] = 0.0f;
+        {
+            float w[2][kPF][NT];
+            auto fetch_group = [&](int g, float (&dst)[kPF][NT]) {
 #pragma unroll
-        for (int it = 0; it < NT; ++it) {
+                for (int i = 0; i < kPF; ++i) {
+                    const int ks = g * kPF + i, it = ks >> 4, s = ks & 15;
+                    load_vec<NT>(W + (size_t)(NT * rho(s) + it) * H + NT * c, dst[i]);
+                }
+            };
+            fetch_group(0, w[0]);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                float w[NT];
-                load_vec<NT>(W + (size_t)(NT * rho(s) + it) * H + NT * c, w);
+            for (int g = 0; g < NT * 16 / kPF; ++g) {
+                if (g + 1 < NT * 16 / kPF) fetch_group(g + 1, w[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < NT; ++mt) d[mt] = mfma(w[mt], dz[it][s], d[mt]);
+                for (int i = 0; i < kPF; ++i) {
+                    const int ks = g * kPF + i, it = ks >> 4, s = ks & 15;
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt) d[mt] = mfma(w[g & 1][i][mt], dz[it][s], d[mt]);
+                }
             }
         }
 #pragma unroll
