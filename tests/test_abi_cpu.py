@@ -58,3 +58,21 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "omc_oracle" not in src and "libomc_oracle" not in src, f
+
+
+def test_c_host_example_compiles_against_the_header_and_library(tmp_path):
+    """examples/price_american.c is the binding a non-Python host would write: it must compile with
+    a plain C compiler against include/omc.h and link against libomc.so (no GPU needed for that)."""
+    import shutil
+    import subprocess
+    from options_model_amd import _build
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib = _build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "price_american"
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+           os.path.join(root, "examples", "price_american.c"), "-o", str(exe), "-L", os.path.dirname(lib), "-lomc",
+           "-lm", "-Wl,-rpath," + os.path.dirname(lib)]
+    subprocess.run(cmd, check=True)
+    assert exe.exists()

@@ -146,3 +146,24 @@ def test_v2_worker_surface_as_the_ui_calls_it():
     a = p.price_american_option(100.0, 1.0, 10000, 50)
     b = p.price_american_option(100.0, 1.0, 10000, 50)
     assert a == b  # v2 reseeds per pricing: identical inputs, identical price
+
+
+def test_c_host_example_prices_config2(tmp_path, ctx):
+    """The C example runs on the GPU and prints the same price the Python binding returns."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    from options_model_amd import _build, _ffi
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib = _build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "price_american"
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "price_american.c"),
+                    "-o", str(exe), "-L", os.path.dirname(lib), "-lomc", "-lm", "-Wl,-rpath," + os.path.dirname(lib)],
+                   check=True)
+    out = subprocess.run([str(exe), "200000", "50"], check=True, capture_output=True, text=True).stdout
+    price = float(re.search(r"price ([0-9.]+)", out).group(1))
+    ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=200000, n_steps=50, seed=42))
+    assert abs(price - ref["price"]) < 1e-6
