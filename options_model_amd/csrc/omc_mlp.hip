@@ -634,6 +634,7 @@ struct MlpTileArgs {
     int64_t row0, nrows;
     Shuffle shuf;
     int ntiles, pstride;
+    int tile0, accumulate;  // this launch: tiles tile0 .. tile0 + gridDim.x; add onto the partials?
     float two_over_b, inv_keep;
     uint32_t keep16, step, k0, k1;
 };
@@ -678,7 +679,7 @@ __host__ __device__ constexpr int tile_waves_max(int H) { return H == 128 ? 768 
 __host__ __device__ constexpr int tile_lds_floats(int H, int L) { return L * H * 32 + 9 * 32 + (L - 1) * H + H + 4; }
 __host__ __device__ constexpr int tile_pstride(int H, int L) { return (mlp_params_of(H, L) + 1 + 63) / 64 * 64; }
 
-template <int H, int L, bool MULTI>
+template <int H, int L>
 __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
 {
     constexpr int NT = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H;
@@ -699,12 +700,13 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
     }
     const StageOfs so = stage_offsets(c, h);
     float* out = a.partial + (size_t)blockIdx.x * a.pstride;
-    // A wave that gets more than one tile (large minibatches) adds the later tiles' gradients onto
-    // its partial in global memory: accumulators start from the stored strip instead of zero.
-    // (MULTI = false: launched with one wave per tile; the loop body runs once and `first` is a
-    // compile-time constant, which keeps the single-tile build free of the loop's register cost.)
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const bool first = !MULTI || tile == (int)blockIdx.x;
+    // A minibatch of more tiles than fit the chip at once is covered by several launches of this
+    // kernel: launch n handles tiles tile0 + blockIdx.x and, from the second launch on
+    // (`accumulate`), adds its gradients onto the wave's partial in global memory -- accumulators
+    // start from the stored strip instead of zero.
+    const int tile = a.tile0 + blockIdx.x;
+    if (tile >= a.ntiles) return;
+    const bool first = !a.accumulate;
     const int64_t row = (int64_t)tile * 32 + c;
     const bool live = row < a.nrows;
     float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -712,7 +714,6 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
     float y = x.w;
     if (h == 1) x.w = 1.0f;
     y = __shfl(y, c + 32, 64);
-    wave_sync_lds();  // the previous tile's staging reads are done
     tX[st_idx(4 * h + 0, c)] = x.x;
     tX[st_idx(4 * h + 1, c)] = x.y;
     tX[st_idx(4 * h + 2, c)] = x.z;
@@ -937,8 +938,6 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
         out[NP - 1] = first ? gbo : out[NP - 1] + gbo;
         out[NP] = first ? loss : out[NP] + loss;
     }
-    if (!MULTI) break;
-    }  // tiles of this wave
 }
 
 // wt_j[k][i] = W_j[i][k] for the L-1 connections (start of an epoch; Adam keeps it current)
@@ -1328,11 +1327,8 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
     static bool attr_set = false;
     const size_t lds_bytes = sizeof(float) * (size_t)tile_lds_floats(H, L);
     if (!attr_set && lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -1359,10 +1355,11 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
         a.k0 = (uint32_t)t.seed;
         a.k1 = (uint32_t)(t.seed >> 32);
         const int waves = a.ntiles < tile_waves_max(H) ? a.ntiles : tile_waves_max(H);
-        if (waves == a.ntiles)
-            hipLaunchKernelGGL((mlp_train_tile_kernel<H, L, false>), dim3(waves), dim3(64), lds_bytes, st, a);
-        else
-            hipLaunchKernelGGL((mlp_train_tile_kernel<H, L, true>), dim3(waves), dim3(64), lds_bytes, st, a);
+        for (int t0 = 0; t0 < a.ntiles; t0 += waves) {
+            a.tile0 = t0;
+            a.accumulate = t0 > 0;
+            hipLaunchKernelGGL((mlp_train_tile_kernel<H, L>), dim3(waves), dim3(64), lds_bytes, st, a);
+        }
         MlpAdamArgs b;
         b.params = t.params;
         b.m = t.adam_m;
