@@ -62,6 +62,20 @@ def main():
                              price=res.price, stderr=res.stderr, seconds=dt,
                              path_steps_per_s=1_000_000 * 252 / dt, R=res.sum_nitm, timings_ms=res.timings_ms))
             print(json.dumps(rows[-1]), flush=True)
+    if "C5r" in only:  # config 5 with the network the reference itself would build: SingleLSMNet(7, 128, 3)
+        from options_model_amd import nn_regressor
+        nn_regressor.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, seed=1, nn_epochs=2,
+                                              nn_hidden=128, nn_layers=3)
+        for trainer in [t for t in ("hip", "torch") if not ({"hip", "torch"} & only) or t in only]:
+            t0 = time.perf_counter()
+            res = nn_regressor.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 1_000_000, 252, seed=42,
+                                                        nn_hidden=128, nn_layers=3, nn_trainer=trainer)
+            dt = time.perf_counter() - t0
+            rows.append(dict(config="C5r", paths=1_000_000, steps=252, trainer=trainer,
+                             regressor="nn 3x128 (SingleLSMNet(7,128,3), the reference's default shape), 25 epochs max",
+                             price=res.price, stderr=res.stderr, seconds=dt, path_steps_per_s=1_000_000 * 252 / dt,
+                             R=res.sum_nitm, timings_ms=res.timings_ms, info=res.info))
+            print(json.dumps(rows[-1]), flush=True)
 
 
 if __name__ == "__main__":
