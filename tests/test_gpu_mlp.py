@@ -72,6 +72,30 @@ def test_gradients_and_loss_match_autograd(env, ctx, rows, hidden, layers):
     assert torch.allclose(p[big], expect[big], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("hidden,layers", [(64, 2), (128, 3)])
+@pytest.mark.parametrize("rows,bs", [(1, 1), (2, 2), (31, 31), (33, 33), (65, 64), (97, 40), (1500, 1100)])
+def test_ragged_tiny_batches(env, ctx, hidden, layers, rows, bs):
+    """Edge sizes: fewer rows than a tile, one row over a tile, ragged last batches, on both kernels
+    (64 units switch from the tile-per-wave to the workgroup kernel above 1024 rows per step)."""
+    torch, nnr, dev = env
+    torch.manual_seed(7)
+    net = nnr.make_net(7, hidden, layers, 0.0).to(dev)
+    data = _data(torch, dev, rows, 17)
+    p = nnr.flatten_params(net)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    torch.cuda.synchronize()
+    loss, step = ctx.mlp_train_epoch(data.data_ptr(), rows, bs, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                     0, 1e-3, 0.0, 5, hidden=hidden, layers=layers)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    tot, n = 0.0, 0
+    for o in range(0, rows, bs):
+        tot += float(_torch_grads(torch, net, data[o:o + bs]).detach())
+        opt.step()
+        n += 1
+    assert step == n and bool(torch.isfinite(p).all())
+    assert loss == pytest.approx(tot / n, rel=1e-4, abs=1e-7)
+
+
 @pytest.mark.parametrize("hidden,layers,bs", [(64, 2, 1000), (64, 3, 1000), (64, 2, 2500), (128, 3, 1000), (128, 2, 2500)])
 def test_many_steps_track_torch_adam(env, ctx, hidden, layers, bs):
     torch, nnr, dev = env
