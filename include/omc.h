@@ -199,6 +199,17 @@ int omc_lsm_apply_mlp(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
                       double r, double T, int is_put, int hidden, int layers, const float* params,
                       const double* feat_mean, const double* feat_std, double y_mean, double y_std,
                       double dropout, uint64_t seed, omc_result* res, float* sx_out, int32_t* tex_out);
+/* Pass 1 of the NN flow (options_model_3.py:482-563) straight from a device path matrix: every
+ * in-the-money (step, path), steps N-1 down to 1 and paths ascending within a step (the reference's
+ * order), becomes one row of `data` ([rows][8] float32, device): the 7 features [1, x, x^2, x^3,
+ * max(x-1,0), s, x*s] of x = S/K, s = sqrt(max(T - t dt, 1e-6)), normalised by their means and
+ * population stds over all rows (zero std -> 1), and the target (terminal payoff discounted to t)
+ * normalised likewise.  *n_rows = number of rows; with data == NULL only the count is made (call
+ * once to size the buffer, then again with data and cap_rows >= *n_rows).  stats16 (host) =
+ * feat_mean[7], feat_std[7], y_mean, y_std. */
+int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                      double r, double T, int is_put, float* data, int64_t cap_rows, int64_t* n_rows,
+                      double* stats16);
 /* Normalisers of the training rows (options_model_3.py:550-563) in float64: for rows i < n_rows
  * with x[i] = S/K, step index t[i] and target y[i] (device arrays), out16[0..6] = means of
  * [x, x^2, x^3, max(x-1,0), s, x*s, y] with s = sqrt(max(T - t*dt, 1e-6)), out16[8..14] =

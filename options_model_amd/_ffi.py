@@ -85,6 +85,7 @@ SIGNATURES = {
                                     C.POINTER(Result), _P, _P]),
     "omc_localvol_param_count": (C.c_int, [_I, _I]),
     "omc_localvol_paths_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _D, _I, _I, _P, _D, _D, _D, _P]),
+    "omc_nn_build_rows": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _P, _I64, C.POINTER(C.c_int64), _P]),
     "omc_nn_feature_stats": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P]),
 }
 
@@ -406,6 +407,18 @@ class Context:
         if want_state:
             out["sx"], out["tex"] = sx, tex
         return out
+
+    def nn_build_rows(self, S_ptr, ld, n_paths, n_steps, K, r, T, is_put, data_ptr=None, cap_rows=0):
+        """Pass 1 of the NN flow from a device path matrix.  data_ptr None -> row count only;
+        else -> (rows, feat_mean[7], feat_std[7], y_mean, y_std) with the rows written to data_ptr."""
+        n = C.c_int64(0)
+        st = np.zeros(16)
+        _check(self.lib, self.lib.omc_nn_build_rows(
+            self.handle, int(S_ptr), int(ld), int(n_paths), int(n_steps), float(K), float(r), float(T),
+            int(bool(is_put)), int(data_ptr) if data_ptr else None, int(cap_rows), C.byref(n), st.ctypes.data))
+        if not data_ptr:
+            return n.value
+        return n.value, st[:7].copy(), st[7:14].copy(), float(st[14]), float(st[15])
 
     def nn_feature_stats(self, x_ptr, t_ptr, y_ptr, n_rows, T, dt):
         """-> (means[7], variances[7]) of [x, x^2, x^3, max(x-1,0), s, x*s, y] over device rows."""

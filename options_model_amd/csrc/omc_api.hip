@@ -825,6 +825,51 @@ int omc_localvol_paths_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, in
     return 0;
 }
 
+int omc_nn_build_rows(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r,
+                      double T, int is_put, float* data, int64_t cap_rows, int64_t* n_rows, double* stats16)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_market(1.0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (!n_rows) return fail(-7, "null pointer.");
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, false, &w))) return rc;
+    if ((rc = c->scratch.ensure(omc::nn_rows_scratch_bytes(n_paths, n_steps)))) return rc;
+    omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
+    const int64_t* total_dev = nullptr;
+    HIP_TRY(omc::nn_rows_count(c->stream, p, w.D, c->scratch.p, &total_dev));
+    int64_t R = 0;
+    HIP_TRY(hipMemcpyAsync(&R, total_dev, sizeof R, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n_rows = R;
+    if (!data) return 0;  // count only
+    if (!stats16) return fail(-7, "null pointer.");
+    if (cap_rows < R) return fail(-6, "row buffer smaller than the number of in-the-money (step, path) pairs.");
+    for (int i = 0; i < 16; ++i) stats16[i] = i < 7 ? 0.0 : 1.0;
+    stats16[0] = 1.0;  // the constant feature: mean 1, std 0 -> 1
+    stats16[14] = 0.0;
+    if (R == 0) return 0;
+    double sums[8], mean[8], dev[8];
+    HIP_TRY(omc::nn_rows_stats(c->stream, p, w.D, c->scratch.p, 0, nullptr, sums));
+    for (int q = 0; q < 8; ++q) mean[q] = sums[q] / (double)R;
+    HIP_TRY(omc::nn_rows_stats(c->stream, p, w.D, c->scratch.p, 1, mean, dev));
+    // layout: feat_mean[0..6], feat_std[7..13], y_mean [14], y_std [15]; zero std -> 1 (:551-563)
+    for (int q = 0; q < 6; ++q) {
+        const double sd = std::sqrt(dev[q] / (double)R);
+        stats16[1 + q] = mean[q];
+        stats16[8 + q] = sd > 1e-13 * std::fabs(mean[q]) ? sd : 1.0;
+    }
+    const double ysd = std::sqrt(dev[6] / (double)R);
+    stats16[14] = mean[6];
+    stats16[15] = ysd > 1e-13 * std::fabs(mean[6]) ? ysd : 1.0;
+    HIP_TRY(omc::nn_rows_write(c->stream, p, w.D, c->scratch.p, stats16, stats16 + 7, stats16[14], stats16[15], data,
+                               cap_rows));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const double* y, int64_t n_rows,
                          double T, double dt, double* out16)
 {

@@ -123,6 +123,13 @@ int localvol_param_count(int hidden, int layers);
 hipError_t localvol_paths(hipStream_t st, float* S, int64_t ld, int64_t M, int N, int layers, const float* params,
                           const float* Z, double S0, double r, double T, double K, double m_scale,
                           double tau_scale, double eps_out);
+// pass 1 of the NN flow straight from the path matrix (omc_rows.hip): count -> scan -> statistics -> rows
+size_t nn_rows_scratch_bytes(int64_t M, int N);
+hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const int64_t** total_dev);
+hipError_t nn_rows_stats(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, int pass,
+                         const double* mean_host, double* sums_host);
+hipError_t nn_rows_write(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const double* feat_mean,
+                         const double* feat_std, double y_mean, double y_std, float* data, int64_t cap);
 // float64 means / population variances of the regression features and the target over n rows
 size_t nn_stats_scratch_bytes();
 hipError_t nn_feature_stats(hipStream_t st, const double* x, const int32_t* t, const double* y, int64_t n,

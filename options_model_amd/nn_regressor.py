@@ -312,26 +312,51 @@ def _train_fused(net, data, epochs, lr, bs, verbose):
                 trainer="hip", seconds_train_kernels=t_kernels)
 
 
+def build_rows_fused(S, K, r, T, is_put):
+    """Pass 1 (:482-563) by the library (omc_nn_build_rows): the [R, 8] float32 training matrix in the
+    reference's row order plus the normalisers, straight from the path matrix -- no x / t / y
+    temporaries.  -> (data, feat_mean, feat_std, y_mean, y_std) or None if nothing is in the money."""
+    torch = _torch()
+    dev = S.device
+    N, M = S.shape[0] - 1, S.shape[1]
+    ctx = _ctx_on_torch_stream(dev.index or 0)
+    torch.cuda.current_stream(dev).synchronize()
+    R = ctx.nn_build_rows(S.data_ptr(), S.stride(0), M, N, K, r, T, is_put)
+    if R == 0:
+        return None
+    data = torch.empty((R, 8), dtype=torch.float32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()
+    _, fm, fs, ym, ysd = ctx.nn_build_rows(S.data_ptr(), S.stride(0), M, N, K, r, T, is_put, data.data_ptr(), R)
+    f64 = dict(dtype=torch.float64, device=dev)
+    return (data, torch.tensor(fm, **f64), torch.tensor(fs, **f64), torch.tensor(ym, **f64), torch.tensor(ysd, **f64))
+
+
 def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbose=False,
           use_graph=True, trainer="auto"):
+    """:565-613 on the rows (x, t, y) of collect_rows: builds the training matrix, then train_on_matrix."""
+    torch = _torch()
+    t_m = time.perf_counter()
+    data = build_training_matrix(x, t, y, fm, fs, ym, ysd, T, dt)
+    torch.cuda.synchronize(x.device)
+    t_m = time.perf_counter() - t_m
+    return dict(train_on_matrix(net, data, epochs, lr, nn_batch, verbose, use_graph, trainer), seconds_matrix=t_m)
+
+
+def train_on_matrix(net, data, epochs, lr, nn_batch=None, verbose=False, use_graph=True, trainer="auto"):
     """:565-613: Adam(lr, wd 1e-5), MSE, shuffled minibatches, ReduceLROnPlateau on the epoch-mean
     loss, early stop after 8 non-improving epochs, best-weights restore.
     trainer: "hip" = the library's fused MFMA kernels (64 or 128 units x 2 or 3 hidden layers), "torch" = PyTorch-ROCm
     autograd (any SingleLSMNet shape), "auto" = hip where it applies."""
     torch = _torch()
-    R = x.numel()
+    R = data.shape[0]
     bs = pick_batch(R, nn_batch)
-    dev = x.device
-    t_m = time.perf_counter()
-    data = build_training_matrix(x, t, y, fm, fs, ym, ysd, T, dt)
-    torch.cuda.synchronize(dev)
-    t_m = time.perf_counter() - t_m
+    dev = data.device
     if trainer not in ("auto", "hip", "torch"):
         raise ValueError("trainer must be 'auto', 'hip' or 'torch'")
     if trainer == "hip" and not fused_trainer_supports(net, bs):
         raise ValueError("trainer='hip' covers SingleLSMNet(7, 64 | 128, 2 | 3)")
     if trainer != "torch" and fused_trainer_supports(net, bs):
-        return dict(_train_fused(net, data, epochs, lr, bs, verbose), seconds_matrix=t_m)
+        return _train_fused(net, data, epochs, lr, bs, verbose)
     # state snapshots for the warm-up steps of the graph capture must not leak into training
     init_state = copy.deepcopy(net.state_dict())
     lr_t = torch.tensor(float(lr), dtype=torch.float32, device=dev)
@@ -382,7 +407,7 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
     if best_state is not None:
         net.load_state_dict(best_state)
     return dict(batch=bs, optimizer_steps=steps, epochs_run=epoch + 1, best_loss=best, graphed=graphed,
-                trainer="torch", seconds_matrix=t_m)
+                trainer="torch")
 
 
 def pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, path_chunk=1 << 20):
@@ -444,19 +469,36 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
     dt = T / N
     torch.manual_seed(int(torch_seed))  # :455
     t0 = time.perf_counter()
-    rows = collect_rows(S, K, r, T, is_put)
-    if rows is None:  # :518-519 nothing ever in the money
-        payT = (K - S[N].double()).clamp_(min=0) if is_put else (S[N].double() - K).clamp_(min=0)
-        cf = payT * math.exp(-r * dt * (N - 1))
-        return dict(price=float(cf.mean()), R=0, n_paths=M, n_exercised=0)
-    x, t, y, _ = rows
-    torch.cuda.synchronize(S.device)
-    t_c = time.perf_counter()
-    fm, fs, ym, ysd = normalisers(x, t, y, T, dt)
     net = make_net(7, nn_hidden, nn_layers, nn_dropout).to(S.device)
-    torch.cuda.synchronize(S.device)
-    t1 = time.perf_counter()
-    info = train(net, x, t, y, fm, fs, ym, ysd, T, dt, nn_epochs, nn_lr, nn_batch, verbose, trainer=trainer)
+    if trainer != "torch":
+        # pass 1 by the library: rows + normalisers straight from S
+        built = build_rows_fused(S, K, r, T, is_put)
+        if built is None:  # :518-519 nothing ever in the money
+            payT = (K - S[N].double()).clamp_(min=0) if is_put else (S[N].double() - K).clamp_(min=0)
+            cf = payT * math.exp(-r * dt * (N - 1))
+            return dict(price=float(cf.mean()), R=0, n_paths=M, n_exercised=0)
+        data, fm, fs, ym, ysd = built
+        R = data.shape[0]
+        torch.cuda.synchronize(S.device)
+        t_c = t1 = time.perf_counter()
+        info = dict(train_on_matrix(net, data, nn_epochs, nn_lr, nn_batch, verbose, trainer=trainer), rows="hip")
+        del data
+    else:
+        rows = collect_rows(S, K, r, T, is_put)
+        if rows is None:  # :518-519 nothing ever in the money
+            payT = (K - S[N].double()).clamp_(min=0) if is_put else (S[N].double() - K).clamp_(min=0)
+            cf = payT * math.exp(-r * dt * (N - 1))
+            return dict(price=float(cf.mean()), R=0, n_paths=M, n_exercised=0)
+        x, t, y, _ = rows
+        R = int(x.numel())
+        torch.cuda.synchronize(S.device)
+        t_c = time.perf_counter()
+        fm, fs, ym, ysd = normalisers(x, t, y, T, dt)
+        torch.cuda.synchronize(S.device)
+        t1 = time.perf_counter()
+        info = dict(train(net, x, t, y, fm, fs, ym, ysd, T, dt, nn_epochs, nn_lr, nn_batch, verbose, trainer=trainer),
+                    rows="torch")
+        del x, t, y
     torch.cuda.synchronize(S.device)
     t2 = time.perf_counter()
     if trainer != "torch" and fused_apply_supports(net):
@@ -468,7 +510,7 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
         res = dict(price=price, std=math.sqrt(var), n_exercised=int(ex.sum()),
                    zero_prob=float((cf == 0).double().mean()), pass2="torch")
     t3 = time.perf_counter()
-    info.update(res, stderr=res["std"] / math.sqrt(M), R=int(x.numel()), n_paths=M,
+    info.update(res, stderr=res["std"] / math.sqrt(M), R=R, n_paths=M,
                 Y_mean=float(ym), Y_std=float(ysd), seconds_collect=t_c - t0, seconds_normalise=t1 - t_c,
                 seconds_train=t2 - t1, seconds_pass2=t3 - t2, net=net, feat_mean=fm, feat_std=fs)
     return info
@@ -513,5 +555,5 @@ def price_american_option_nn(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", 
                        n_exercised=out.get("n_exercised", 0), sum_nitm=out.get("R", 0), model=model_l,
                        semantics="two_pass", option_type=option_type,
                        timings_ms={k: 1e3 * v for k, v in out.items() if k.startswith("seconds_")},
-                       info={k: out[k] for k in ("trainer", "pass2", "batch", "epochs_run", "optimizer_steps",
+                       info={k: out[k] for k in ("trainer", "pass2", "rows", "batch", "epochs_run", "optimizer_steps",
                                                  "best_loss", "graphed") if k in out})

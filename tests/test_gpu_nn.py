@@ -40,6 +40,50 @@ def test_pass1_rows_and_normalisers_match_reference(torch_cuda, golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["gbm_put", "heston_call"])
+def test_hip_rows_and_normalisers_match_reference(torch_cuda, golden, tag):
+    """omc_nn_build_rows (count, scan, statistics and row kernels) on the reference's paths rounded to
+    float32: the reference's row count R and its normalisers; the rows themselves equal the ones the
+    PyTorch restatement builds from the same float32 matrix, in the same order."""
+    torch = torch_cuda
+    from options_model_amd import nn_regressor as nr
+    nn = golden["nn"]
+    S0, K, r, sig, T, is_put, hidden = nn[f"{tag}_params"]
+    S = torch.from_numpy(nn[f"{tag}_S"]).float().cuda().contiguous()
+    N = S.shape[0] - 1
+    data, fm, fs, ym, ysd = nr.build_rows_fused(S, K, r, T, bool(is_put))
+    assert abs(data.shape[0] - int(nn[f"{tag}_R"])) <= 2  # float32 rounding of a spot sitting on the strike
+    assert np.allclose(fm.cpu().numpy(), nn[f"{tag}_feat_mean"], rtol=2e-6, atol=1e-9)
+    assert np.allclose(fs.cpu().numpy(), nn[f"{tag}_feat_std"], rtol=2e-5, atol=1e-9)
+    assert float(ym) == pytest.approx(nn[f"{tag}_Y_mean_std"][0], rel=2e-6)
+    assert float(ysd) == pytest.approx(nn[f"{tag}_Y_mean_std"][1], rel=2e-6)
+    x, t, y, _ = nr.collect_rows(S, K, r, T, bool(is_put))
+    fm2, fs2, ym2, ysd2 = nr.normalisers(x, t, y, T, T / N)
+    ref = nr.build_training_matrix(x, t, y, fm2, fs2, ym2, ysd2, T, T / N)
+    assert ref.shape == data.shape
+    assert np.allclose(fm.cpu().numpy(), fm2.cpu().numpy(), rtol=1e-12, atol=1e-15)
+    assert np.allclose(fs.cpu().numpy(), fs2.cpu().numpy(), rtol=1e-9, atol=1e-15)
+    assert float((data - ref).abs().max()) <= 2e-6  # same order, float32 rounding of the last operation
+
+
+def test_hip_rows_ragged_sizes_and_empty(torch_cuda):
+    torch = torch_cuda
+    from options_model_amd import nn_regressor as nr
+    dev = torch.device("cuda", 0)
+    c2 = nr._ctx_on_torch_stream(0)
+    for M, N in ((2, 2), (254, 3), (258, 5), (1000, 33), (4096, 7)):
+        S = torch.empty((N + 1, M), dtype=torch.float32, device=dev)
+        nr.generate_paths(c2, S, dict(model="gbm"), 100.0, 0.05, 0.3, 1.0, 5)
+        built = nr.build_rows_fused(S, 100.0, 0.05, 1.0, True)
+        x, t, y, _ = nr.collect_rows(S, 100.0, 0.05, 1.0, True)
+        assert built is not None and built[0].shape[0] == x.numel()
+        fm2, fs2, ym2, ysd2 = nr.normalisers(x, t, y, 1.0, 1.0 / N)
+        ref = nr.build_training_matrix(x, t, y, fm2, fs2, ym2, ysd2, 1.0, 1.0 / N)
+        assert float((built[0] - ref).abs().max()) <= 5e-6, (M, N)
+    S = torch.full((4, 64), 200.0, dtype=torch.float32, device=dev)  # a put that is never in the money
+    assert nr.build_rows_fused(S, 100.0, 0.05, 1.0, True) is None
+
+
+@pytest.mark.parametrize("tag", ["gbm_put", "heston_call"])
 def test_pass2_with_reference_weights_reproduces_reference_decisions(torch_cuda, golden, tag):
     torch = torch_cuda
     from options_model_amd import nn_regressor as nr
