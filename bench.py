@@ -83,13 +83,16 @@ def main():
     ap.add_argument("--model", default="gbm", choices=["gbm", "heston"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + --single-device rehearses world_size > 1 on one GPU")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="go through torch.distributed/RCCL even with one rank (rehearsal of the N>1 path)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if a.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     M, N = a.paths_per_gpu, a.n_steps
 
     import torch
@@ -103,7 +106,10 @@ def main():
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group("gloo", rank=rank, world_size=world)
         pricer = omc_dist.ShardedPricer(local_rank, force_hook=a.force_dist)
         barrier = td.barrier
     else:

@@ -149,3 +149,26 @@ def test_sharded_pricer_world_size_one():
         sp.close()
     finally:
         td.destroy_process_group()
+
+
+def test_two_ranks_through_bench_equal_the_unsharded_price(ctx, tmp_path):
+    """world_size 2 end to end (torch.distributed.run, two processes sharing this GPU, gloo standing in
+    for RCCL): the sharded pricing returns the price of the unsharded 2x-path problem."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from options_model_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29613", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--paths-per-gpu", "100000", "--n-steps", "50", "--backend", "gloo", "--single-device",
+           "--no-variants", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "path-sharded x2"
+    ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=200000, n_steps=50, seed=42, stream=1))
+    assert d["price"] == pytest.approx(ref["price"], rel=1e-10)
