@@ -80,7 +80,8 @@ struct omc_ctx {
     double D_r = 0, D_T = 0;
     const double* D_ptr = nullptr;
     double hres[8];
-    double* hres_pin = nullptr;  // pinned: the result copy of the fused pricing call is truly asynchronous
+    double* hres_pin = nullptr;  // pinned + mapped: the fused pricing call's last kernel writes its 8 sums here
+    double* hres_dev = nullptr;  // device-side address of hres_pin
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int gbm_vec = 0, heston_vec = 0;
     int world = 1;  // ranks whose sums the hook adds up (equal shards)
@@ -292,8 +293,11 @@ int omc_ctx_create(int device, void* hip_stream, omc_ctx** out)
             HIP_TRY(e);
         }
     }
-    if (hipHostMalloc((void**)&c->hres_pin, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess)
-        c->hres_pin = nullptr;  // fall back to the pageable member
+    if (hipHostMalloc((void**)&c->hres_pin, sizeof(double) * 8, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->hres_dev, c->hres_pin, 0) != hipSuccess) {
+        if (c->hres_pin) (void)hipHostFree(c->hres_pin);
+        c->hres_pin = c->hres_dev = nullptr;  // fall back to a device buffer + copy into the pageable member
+    }
     *out = c;
     return 0;
 }
@@ -589,10 +593,16 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
                                          p->theta, p->xi, p->rho, p->seed, (uint32_t)p->stream,
                                          p->pair_offset, p->heston_scheme, c->heston_vec));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    // Single GPU: the finalize kernel stores its 8 sums straight into host-mapped pinned memory (no copy
+    // kernel, no extra dependent launch).  With an all-reduce hook the sums stay in device memory for
+    // the collective and are copied afterwards.
+    const bool zero_copy = c->hres_dev && !c->hook;
+    if (zero_copy) w.result = c->hres_dev;
     if ((rc = enqueue_lsm(c, prob, w, p->semantics, false))) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     double* hres = c->hres_pin ? c->hres_pin : c->hres;
-    HIP_TRY(hipMemcpyAsync(hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!zero_copy)
+        HIP_TRY(hipMemcpyAsync(hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
     if ((rc = wait_stream(c))) return rc;
     memset(res, 0, sizeof *res);
     fill_result(res, hres, c->hook ? M * c->world : M);  // hook: sums are global
