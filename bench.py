@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--model", default="gbm", choices=["gbm", "heston"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--group", type=int, default=10,
+                    help="single GPU: pricings enqueued per omc_price_american_seq call (one host wait per group)")
+    ap.add_argument("--sync-every-step", action="store_true",
+                    help="single GPU: one synchronous omc_price_american call per step instead")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --single-device rehearses world_size > 1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
@@ -133,13 +137,30 @@ def main():
     t0 = time.perf_counter()
     ms_paths = ms_lsm = ms_p1 = ms_p2 = 0.0
     price = 0.0
-    for i in range(a.steps):
-        out, loc = one_step(i)
-        ms_paths += loc["ms_paths"]
-        ms_lsm += loc["ms_lsm"]
-        ms_p1 += loc.get("ms_pass1", 0.0)
-        ms_p2 += loc.get("ms_pass2", 0.0)
-        price = out["price"]
+    if pricer is None and not a.sync_every_step:
+        # Single GPU: the K pricings are enqueued through omc_price_american_seq in groups of `--group`
+        # (no host synchronisation inside a group: pricing i + 1 is launched while pricing i runs);
+        # every group's first pricing carries the HIP events the per-kernel times come from.
+        nsamp = 0
+        for lo in range(0, a.steps, a.group):
+            outs = ctx.price_american_seq([_ffi.make_params(n_paths=M, stream=i, **kw)
+                                           for i in range(lo, min(lo + a.group, a.steps))])
+            ms_paths += outs[0]["ms_paths"]
+            ms_lsm += outs[0]["ms_lsm"] if len(outs) == 1 else sum(o["ms_total"] for o in outs) / len(outs) - outs[0]["ms_paths"]
+            ms_p1 += outs[0].get("ms_pass1", 0.0)
+            ms_p2 += outs[0].get("ms_pass2", 0.0)
+            nsamp += 1
+            price = outs[-1]["price"]
+        scale = a.steps / nsamp  # the averages below divide by a.steps
+        ms_paths *= scale; ms_lsm *= scale; ms_p1 *= scale; ms_p2 *= scale
+    else:
+        for i in range(a.steps):
+            out, loc = one_step(i)
+            ms_paths += loc["ms_paths"]
+            ms_lsm += loc["ms_lsm"]
+            ms_p1 += loc.get("ms_pass1", 0.0)
+            ms_p2 += loc.get("ms_pass2", 0.0)
+            price = out["price"]
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

@@ -240,6 +240,14 @@ int omc_localvol_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, 
                            double r, double T, double K, int hidden, int layers, const float* params,
                            double m_scale, double tau_scale, double epsilon, const float* Z);
 
+/* ---- a sequence of pricings without host synchronisation in between ------------------------- */
+/* n independent pricings enqueued back to back on the context's stream (pricing i + 1 is launched while
+ * pricing i runs; every pricing's result sums land in their own slot of a host-mapped buffer; one wait
+ * at the end).  res[i] equals what omc_price_american(p[i]) returns, bit for bit; ms_paths / ms_pass1 /
+ * ms_pass2 are measured on the first pricing, ms_total is the average over the sequence.  With an
+ * all-reduce hook installed (multi-GPU) the pricings run one at a time. */
+int omc_price_american_seq(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
+
 /* ---- many small pricings in one go ------------------------------------------------------- */
 /* replaces the curve loops compute_curve_for_S0 (options_model_3.py:697-713, Options_model.py:
  * 190-211, options_model_2.py:336-355) and their ProcessPoolExecutor fan-out: n independent

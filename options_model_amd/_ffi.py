@@ -74,6 +74,7 @@ SIGNATURES = {
     "omc_price_american": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result), _P, _I64]),
     "omc_price_european": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result)]),
     "omc_heston_price_strikes": (C.c_int, [_P, _I64, _I] + [_D] * 8 + [_U64, _U64, _I, _P, _I, _I, _P, _P]),
+    "omc_price_american_seq": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_price_american_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_price_european_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_mlp_param_count": (C.c_int, [_I, _I]),
@@ -443,6 +444,15 @@ class Context:
             _check(self.lib, fn(self.handle, arr, n, res))
             out.extend(r.as_dict() for r in res)
         return out
+
+    def price_american_seq(self, params_list):
+        """n pricings back to back on the stream, one wait at the end -> list of result dicts."""
+        plist = list(params_list)
+        n = len(plist)
+        arr = (Params * n)(*plist)
+        res = (Result * n)()
+        _check(self.lib, self.lib.omc_price_american_seq(self.handle, arr, n, res))
+        return [r.as_dict() for r in res]
 
     def price_american_batch(self, params_list):
         return self._batch(self.lib.omc_price_american_batch, list(params_list))

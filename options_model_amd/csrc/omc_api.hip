@@ -82,6 +82,9 @@ struct omc_ctx {
     double hres[8];
     double* hres_pin = nullptr;  // pinned + mapped: the fused pricing call's last kernel writes its 8 sums here
     double* hres_dev = nullptr;  // device-side address of hres_pin
+    double *seq_pin = nullptr, *seq_dev = nullptr;  // omc_price_american_seq: one 8-double slot per pricing
+    int seq_cap = 0;
+    hipEvent_t ev_seq = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int gbm_vec = 0, heston_vec = 0;
     int world = 1;  // ranks whose sums the hook adds up (equal shards)
@@ -296,6 +299,8 @@ int omc_ctx_create(int device, void* hip_stream, omc_ctx** out)
     if (hipHostMalloc((void**)&c->hres_pin, sizeof(double) * 8, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->hres_dev, c->hres_pin, 0) != hipSuccess) {
         if (c->hres_pin) (void)hipHostFree(c->hres_pin);
+    if (c->seq_pin) (void)hipHostFree(c->seq_pin);
+    if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
         c->hres_pin = c->hres_dev = nullptr;  // fall back to a device buffer + copy into the pageable member
     }
     *out = c;
@@ -314,6 +319,8 @@ int omc_ctx_destroy(omc_ctx* c)
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->hres_pin) (void)hipHostFree(c->hres_pin);
+    if (c->seq_pin) (void)hipHostFree(c->seq_pin);
+    if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -564,12 +571,13 @@ static int check_params(const omc_params* p)
     return 0;
 }
 
-int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* S_keep, int64_t ld)
+// Enqueue one whole pricing (paths + backward induction) on the context's stream; its 8 result sums
+// go to `result_dev` (device-visible memory) or, when null, to the workspace's device buffer, which is
+// returned through *result_out.  Events are recorded only when `timed`.
+static int enqueue_pricing(omc_ctx* c, const omc_params* p, float* S_keep, int64_t ld, double* result_dev,
+                           bool timed, double** result_out)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
-    if ((rc = check_params(p))) return rc;
-    if (!res) return fail(-7, "null result pointer.");
     const int64_t M = p->n_paths;
     const int N = p->n_steps;
     float* S = S_keep;
@@ -583,8 +591,10 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     omc::LsmWorkspace w;
     if ((rc = prepare_lsm(c, M, N, p->r, p->T, p->semantics == OMC_SEM_TWO_PASS, false, &w))) return rc;
     omc::LsmProblem prob{S, ld, M, N, p->is_put ? 1 : 0, p->K, p->r, p->T};
-    w.ev_p1_begin = c->ev[3]; w.ev_p1_end = c->ev[4]; w.ev_p2_begin = c->ev[5]; w.ev_p2_end = c->ev[6];
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (timed) {
+        w.ev_p1_begin = c->ev[3]; w.ev_p1_end = c->ev[4]; w.ev_p2_begin = c->ev[5]; w.ev_p2_end = c->ev[6];
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    }
     if (p->model == OMC_MODEL_GBM)
         HIP_TRY(omc::launch_gbm_paths(c->stream, S, ld, M, N, p->S0, p->r, p->sigma, p->T, p->seed,
                                       (uint32_t)p->stream, p->pair_offset, p->antithetic, c->gbm_vec));
@@ -592,31 +602,98 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
         HIP_TRY(omc::launch_heston_paths(c->stream, S, ld, M, N, p->S0, p->r, p->T, p->v0, p->kappa,
                                          p->theta, p->xi, p->rho, p->seed, (uint32_t)p->stream,
                                          p->pair_offset, p->heston_scheme, c->heston_vec));
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    // Single GPU: the finalize kernel stores its 8 sums straight into host-mapped pinned memory (no copy
-    // kernel, no extra dependent launch).  With an all-reduce hook the sums stay in device memory for
-    // the collective and are copied afterwards.
-    const bool zero_copy = c->hres_dev && !c->hook;
-    if (zero_copy) w.result = c->hres_dev;
+    if (timed) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if (result_dev) w.result = result_dev;
     if ((rc = enqueue_lsm(c, prob, w, p->semantics, false))) return rc;
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    double* hres = c->hres_pin ? c->hres_pin : c->hres;
-    if (!zero_copy)
-        HIP_TRY(hipMemcpyAsync(hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-    if ((rc = wait_stream(c))) return rc;
-    memset(res, 0, sizeof *res);
-    fill_result(res, hres, c->hook ? M * c->world : M);  // hook: sums are global
+    if (result_out) *result_out = w.result;
+    return 0;
+}
+
+static int read_kernel_times(omc_ctx* c, const omc_params* p, omc_result* res)
+{
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     res->ms_paths = ms;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
     res->ms_lsm = ms;
     res->ms_total = res->ms_paths + res->ms_lsm;
-    if (p->semantics == OMC_SEM_TWO_PASS && N >= 2) {
+    if (p->semantics == OMC_SEM_TWO_PASS && p->n_steps >= 2) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
         res->ms_pass1 = ms;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[5], c->ev[6]));
         res->ms_pass2 = ms;
+    }
+    return 0;
+}
+
+int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* S_keep, int64_t ld)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_params(p))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    // Single GPU: the finalize kernel stores its 8 sums straight into host-mapped pinned memory (no copy
+    // kernel, no extra dependent launch).  With an all-reduce hook the sums stay in device memory for
+    // the collective and are copied afterwards.
+    const bool zero_copy = c->hres_dev && !c->hook;
+    double* result = nullptr;
+    if ((rc = enqueue_pricing(c, p, S_keep, ld, zero_copy ? c->hres_dev : nullptr, true, &result))) return rc;
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    double* hres = c->hres_pin ? c->hres_pin : c->hres;
+    if (!zero_copy)
+        HIP_TRY(hipMemcpyAsync(hres, result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    memset(res, 0, sizeof *res);
+    fill_result(res, hres, c->hook ? p->n_paths * c->world : p->n_paths);  // hook: sums are global
+    return read_kernel_times(c, p, res);
+}
+
+// n pricings back to back on the stream with NO host synchronisation in between: pricing i + 1 is
+// enqueued while pricing i runs, every pricing's sums land in their own slot of a host-mapped buffer,
+// one wait at the end.  Results are those of n omc_price_american calls; kernel times are measured on
+// the first pricing, ms_total is the average over the sequence (first launch to last completion).
+int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* res)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!p || !res || n <= 0) return fail(-7, "null pointer or empty sequence.");
+    for (int i = 0; i < n; ++i)
+        if ((rc = check_params(&p[i]))) return rc;
+    if (c->hook || !c->hres_dev) {  // collectives are host-driven: one pricing at a time
+        for (int i = 0; i < n; ++i)
+            if ((rc = omc_price_american(c, &p[i], &res[i], nullptr, 0))) return rc;
+        return 0;
+    }
+    if (c->seq_cap < n) {
+        if (c->seq_pin) (void)hipHostFree(c->seq_pin);
+        c->seq_pin = c->seq_dev = nullptr;
+        c->seq_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->seq_pin, sizeof(double) * 8 * (size_t)n, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&c->seq_dev, c->seq_pin, 0));
+        c->seq_cap = n;
+    }
+    hipEvent_t ev_end = c->ev[2];
+    for (int i = 0; i < n; ++i) {
+        if ((rc = enqueue_pricing(c, &p[i], nullptr, 0, c->seq_dev + 8 * (size_t)i, i == 0, nullptr))) return rc;
+        if (i == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    }
+    if (!c->ev_seq) HIP_TRY(hipEventCreate(&c->ev_seq));
+    ev_end = c->ev_seq;
+    HIP_TRY(hipEventRecord(ev_end, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    float ms_all = 0;
+    HIP_TRY(hipEventElapsedTime(&ms_all, c->ev[0], ev_end));
+    omc_result first;
+    memset(&first, 0, sizeof first);
+    if ((rc = read_kernel_times(c, &p[0], &first))) return rc;
+    for (int i = 0; i < n; ++i) {
+        memset(&res[i], 0, sizeof res[i]);
+        fill_result(&res[i], c->seq_pin + 8 * (size_t)i, p[i].n_paths);
+        res[i].ms_paths = first.ms_paths;
+        res[i].ms_pass1 = first.ms_pass1;
+        res[i].ms_pass2 = first.ms_pass2;
+        res[i].ms_total = ms_all / (float)n;
+        res[i].ms_lsm = res[i].ms_total - first.ms_paths;
     }
     return 0;
 }

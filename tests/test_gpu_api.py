@@ -167,3 +167,19 @@ def test_c_host_example_prices_config2(tmp_path, ctx):
     price = float(re.search(r"price ([0-9.]+)", out).group(1))
     ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=200000, n_steps=50, seed=42))
     assert abs(price - ref["price"]) < 1e-6
+
+
+def test_sequence_of_pricings_equals_individual_calls(ctx):
+    """omc_price_american_seq: n pricings enqueued back to back, one wait -> bit for bit the results of
+    n omc_price_american calls (different contracts, sizes and flows in one sequence)."""
+    from options_model_amd import _ffi
+    ps = [_ffi.make_params(semantics="two_pass", n_paths=100_000, n_steps=50, seed=42, stream=i) for i in range(4)]
+    ps += [_ffi.make_params(semantics="reference", n_paths=20_000, n_steps=20, seed=7, K=95.0),
+           _ffi.make_params(model="heston", is_put=False, semantics="two_pass", n_paths=40_000, n_steps=30, seed=9),
+           _ffi.make_params(semantics="textbook", n_paths=30_002, n_steps=12, seed=3, T=0.5)]
+    seq = ctx.price_american_seq(ps)
+    for p, s in zip(ps, seq):
+        one = ctx.price_american(p)
+        for k in ("price", "sum", "sumsq", "n_exercised", "n_zero", "sum_nitm", "n_paths"):
+            assert s[k] == one[k], k
+    assert all(s["ms_total"] > 0 for s in seq)
