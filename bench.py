@@ -84,9 +84,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--group", type=int, default=10,
-                    help="single GPU: pricings enqueued per omc_price_american_seq call (one host wait per group)")
+                    help="pricings enqueued per omc_price_american_seq call (one host wait per group)")
     ap.add_argument("--sync-every-step", action="store_true",
-                    help="single GPU: one synchronous omc_price_american call per step instead")
+                    help="one synchronous omc_price_american call per step instead")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --single-device rehearses world_size > 1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
@@ -106,7 +106,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist_mode = world > 1 or a.force_dist
+    stdout_fd = None
     if dist_mode:
+        # RCCL prints a version banner on stdout when its first communicator comes up; the contract
+        # is ONE JSON line on stdout, so everything before it goes to stderr at the descriptor level
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -137,20 +143,26 @@ def main():
     t0 = time.perf_counter()
     ms_paths = ms_lsm = ms_p1 = ms_p2 = 0.0
     price = 0.0
-    if pricer is None and not a.sync_every_step:
-        # Single GPU: the K pricings are enqueued through omc_price_american_seq in groups of `--group`
-        # (no host synchronisation inside a group: pricing i + 1 is launched while pricing i runs);
-        # every group's first pricing carries the HIP events the per-kernel times come from.
+    if not a.sync_every_step:
+        # The K pricings are enqueued through omc_price_american_seq in groups of `--group` (no host
+        # synchronisation inside a group: pricing i + 1 is launched while pricing i runs; with several
+        # ranks the all-reduces are stream-ordered too); every group's first pricing carries the HIP
+        # events the per-kernel times come from.
         nsamp = 0
         for lo in range(0, a.steps, a.group):
-            outs = ctx.price_american_seq([_ffi.make_params(n_paths=M, stream=i, **kw)
-                                           for i in range(lo, min(lo + a.group, a.steps))])
+            ids = list(range(lo, min(lo + a.group, a.steps)))
+            if pricer is not None:
+                louts = pricer.price_american_seq(M * world, ids, **kw)
+                outs = [o["local"] for o in louts]
+                price = louts[-1]["price"]
+            else:
+                outs = ctx.price_american_seq([_ffi.make_params(n_paths=M, stream=i, **kw) for i in ids])
+                price = outs[-1]["price"]
             ms_paths += outs[0]["ms_paths"]
             ms_lsm += outs[0]["ms_lsm"] if len(outs) == 1 else sum(o["ms_total"] for o in outs) / len(outs) - outs[0]["ms_paths"]
             ms_p1 += outs[0].get("ms_pass1", 0.0)
             ms_p2 += outs[0].get("ms_pass2", 0.0)
             nsamp += 1
-            price = outs[-1]["price"]
         scale = a.steps / nsamp  # the averages below divide by a.steps
         ms_paths *= scale; ms_lsm *= scale; ms_p1 *= scale; ms_p2 *= scale
     else:
@@ -268,6 +280,10 @@ def main():
         line["cpu_baseline"] = cpu_baseline(M, N, a.semantics)
     elif rank == 0:
         line["cpu_baseline"] = None
+    if stdout_fd is not None:
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist_mode:

@@ -244,8 +244,9 @@ int omc_localvol_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, 
 /* n independent pricings enqueued back to back on the context's stream (pricing i + 1 is launched while
  * pricing i runs; every pricing's result sums land in their own slot of a host-mapped buffer; one wait
  * at the end).  res[i] equals what omc_price_american(p[i]) returns, bit for bit; ms_paths / ms_pass1 /
- * ms_pass2 are measured on the first pricing, ms_total is the average over the sequence.  With an
- * all-reduce hook installed (multi-GPU) the pricings run one at a time. */
+ * ms_pass2 are measured on the first pricing, ms_total is the average over the sequence.  An installed
+ * all-reduce hook (multi-GPU) is called as usual; it must only ENQUEUE its collective on the stream
+ * (as torch.distributed does), then the sequence stays free of host waits across ranks too. */
 int omc_price_american_seq(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
 
 /* ---- many small pricings in one go ------------------------------------------------------- */

@@ -659,7 +659,7 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     if (!p || !res || n <= 0) return fail(-7, "null pointer or empty sequence.");
     for (int i = 0; i < n; ++i)
         if ((rc = check_params(&p[i]))) return rc;
-    if (c->hook || !c->hres_dev) {  // collectives are host-driven: one pricing at a time
+    if (!c->hres_dev) {  // no host-mapped memory on this system: one pricing at a time
         for (int i = 0; i < n; ++i)
             if ((rc = omc_price_american(c, &p[i], &res[i], nullptr, 0))) return rc;
         return 0;
@@ -674,7 +674,15 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     }
     hipEvent_t ev_end = c->ev[2];
     for (int i = 0; i < n; ++i) {
-        if ((rc = enqueue_pricing(c, &p[i], nullptr, 0, c->seq_dev + 8 * (size_t)i, i == 0, nullptr))) return rc;
+        // with an all-reduce hook the sums stay in device memory for the collective (which the hook
+        // enqueues on the stream, no host wait) and are copied to the slot afterwards
+        double* result = nullptr;
+        if ((rc = enqueue_pricing(c, &p[i], nullptr, 0, c->hook ? nullptr : c->seq_dev + 8 * (size_t)i, i == 0,
+                                  &result)))
+            return rc;
+        if (c->hook)
+            HIP_TRY(hipMemcpyAsync(c->seq_pin + 8 * (size_t)i, result, sizeof(double) * 8, hipMemcpyDeviceToHost,
+                                   c->stream));
         if (i == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     }
     if (!c->ev_seq) HIP_TRY(hipEventCreate(&c->ev_seq));
@@ -688,7 +696,7 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     if ((rc = read_kernel_times(c, &p[0], &first))) return rc;
     for (int i = 0; i < n; ++i) {
         memset(&res[i], 0, sizeof res[i]);
-        fill_result(&res[i], c->seq_pin + 8 * (size_t)i, p[i].n_paths);
+        fill_result(&res[i], c->seq_pin + 8 * (size_t)i, c->hook ? p[i].n_paths * c->world : p[i].n_paths);
         res[i].ms_paths = first.ms_paths;
         res[i].ms_pass1 = first.ms_pass1;
         res[i].ms_pass2 = first.ms_pass2;

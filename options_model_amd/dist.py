@@ -98,5 +98,20 @@ class ShardedPricer:
         out["local"] = res
         return out
 
+    def price_american_seq(self, n_paths_global: int, streams, **kw) -> list:
+        """len(streams) pricings (one Philox stream id each) enqueued back to back, one wait at the end;
+        the hook's all-reduces are stream-ordered, so no rank waits on the host in between."""
+        anti = kw.get("antithetic", True)
+        n_local, off = shard(n_paths_global, self.world, self.rank, anti)
+        ps = [self._ffi.make_params(n_paths=n_local, pair_offset=off, stream=int(s), **kw) for s in streams]
+        with self.torch.cuda.stream(self.stream):
+            res = self.ctx.price_american_seq(ps)
+        outs = []
+        for r in res:
+            out = merge(r, lambda v: v)
+            out["local"] = r
+            outs.append(out)
+        return outs
+
     def close(self):
         self.ctx.close()
