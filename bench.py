@@ -50,6 +50,18 @@ def cpu_baseline(M, N, semantics, budget_s=25.0):
         threads = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) is the real core count
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            quota, period = parse(open(path).read())
+            if period is None:
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1"):
+                threads = max(1, min(threads, int(float(quota) / float(period) + 0.5)))
+            break
+        except Exception:
+            continue
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     # size the sample so the CPU leg stays ~10-30 s: probe with 1/50 of the paths
     probe = max(2000, (M // 50) // 4 * 4)
