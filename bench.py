@@ -7,22 +7,32 @@ Longstaff-Schwartz backward induction -> discounted mean.  Nothing is cached bet
 steps (each step uses a fresh Philox sub-stream); inputs are scalars, so there is no
 host->device data and `value` is the HBM-resident rate by construction.
 
-Workload (BASELINE.json configs[1]): GBM American put, S0=K=100, r=5%, sigma=20%, T=1,
-1,000,000 paths x 252 steps per GPU, polynomial LSM.  With N GPUs every rank prices its
-own 1M-path shard of an N x 1M-path problem (weak scaling; BASELINE configs[2] is the
-same thing at 8M paths per GPU: --paths-per-gpu 8000000), moments and sums all-reduced
-over RCCL.
+Workload (BASELINE.json configs[1], `--config c2`): GBM American put, S0=K=100, r=5%, sigma=20%,
+T=1, 1,000,000 paths x 252 steps per GPU, polynomial LSM.  `--config c3` is BASELINE configs[2]'s
+per-GPU shard (8,000,000 paths per GPU: 64M paths over 8 GPUs), `--config c4` configs[3] (Heston
+call, 4,000,000 paths).  With N GPUs every rank prices its own shard of an N x paths-per-GPU problem
+(weak scaling), regression moments and payoff sums all-reduced over RCCL.
+
+`--gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts N rank processes itself,
+BEFORE this process makes any GPU call; under `python -m torch.distributed.run` the ranks are the
+launcher's.  Either way: world size must equal --gpus, the node must have that many devices, and
+the JSON carries the communicator's own rank count (`rccl_ranks`).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline          the dominant kernel (largest time share): algorithmic bytes per launch / mean
                     HIP-event duration of that launch inside the timed region, vs 8 TB/s HBM peak
   roofline_pathgen  the path-generation kernel named by north_star: (n_steps+1)*n_paths*4 bytes
-  roofline_kernels  every big kernel of the pricing, same accounting (+ PMC traffic if profiled)
-  cpu_baseline  the C oracle (oracle/, a port: the reference is Python) on this host
+  roofline_kernels  every big kernel of the pricing, same accounting (+ PMC traffic, source labelled)
+  roofline_per_step the per-timestep kernel north_star specifies (reference per-step flow), always
+  price_check       GPU vs CPU oracle on the SAME Philox (seed, stream), bounded slice
+  sustained         >= 1 s of back-to-back pricings (steady clocks), same kernels
+  cpu_baseline      the C oracle (oracle/, a port: the reference is Python) on this host
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,19 +42,30 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
 
+CONFIGS = {  # BASELINE.json configs[1..3]
+    "c2": dict(model="gbm", paths_per_gpu=1_000_000),
+    "c3": dict(model="gbm", paths_per_gpu=8_000_000),
+    "c4": dict(model="heston", paths_per_gpu=4_000_000),
+}
+MARKET = dict(S0=100.0, K=100.0, r=0.05, sigma=0.2, T=1.0)
+HESTON = dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7)
+
+
+def step_bytes_per_path(semantics: str) -> float:
+    """what one launch of lsm_step_kernel must move per path."""
+    # reference: S_t, S_t-1, S_N (4 each) + 1 flag byte; textbook: S_t, S_t-1, sx, tex
+    return 13.0 if semantics == "reference" else 16.0
+
 
 def lsm_algorithmic_bytes(semantics: str, M: int, N: int) -> float:
     """DESIGN.md 'Algorithmic bytes': what the backward induction must move per pricing."""
     if semantics == "two_pass":
         # pass 1 reads S rows 1..N-1 once (+ terminal row), pass 2 reads them again
         return 2.0 * 4 * M * N
-    # per-step sweep t: S_t, S_{t-1} (4+4), state sx/tex (4+4) per path
-    return 16.0 * M * (N - 1) + 12.0 * M
+    return step_bytes_per_path(semantics) * M * (N - 1) + 12.0 * M
 
 
-def cpu_baseline(M, N, semantics, budget_s=25.0):
-    """Oracle port timed on this host, bounded sample of the same workload."""
-    from oracle import cpu as orc
+def cpu_threads() -> int:
     threads = os.cpu_count() or 1
     try:
         threads = len(os.sched_getaffinity(0))
@@ -62,114 +83,221 @@ def cpu_baseline(M, N, semantics, budget_s=25.0):
             break
         except Exception:
             continue
+    return threads
+
+
+def oracle_price(model, M, N, semantics, is_put, seed, stream):
+    """The CPU oracle on the Philox (seed, stream) the GPU used -> (result dict, t_paths, t_lsm)."""
+    from oracle import cpu as orc
+    t0 = time.perf_counter()
+    if model == "gbm":
+        S = orc.gbm_paths(M, N, MARKET["S0"], MARKET["r"], MARKET["sigma"], MARKET["T"], seed, stream)
+    else:
+        S = orc.heston_paths(M, N, MARKET["S0"], MARKET["r"], MARKET["T"], HESTON["v0"], HESTON["kappa"],
+                             HESTON["theta"], HESTON["xi"], HESTON["rho"], seed, stream, 0, 1)  # full truncation
+    t1 = time.perf_counter()
+    res = orc.lsm_poly(S, MARKET["K"], MARKET["r"], MARKET["T"], is_put, semantics)
+    t2 = time.perf_counter()
+    return res, t1 - t0, t2 - t1
+
+
+def cpu_baseline(model, M, N, semantics, is_put, seed, stream, budget_s=25.0):
+    """Oracle port timed on this host, bounded sample of the same workload (same seed / stream)."""
+    threads = cpu_threads()
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     # size the sample so the CPU leg stays ~10-30 s: probe with 1/50 of the paths
     probe = max(2000, (M // 50) // 4 * 4)
-    t0 = time.perf_counter()
-    S = orc.gbm_paths(probe, N, 100.0, 0.05, 0.2, 1.0, 42)
-    orc.lsm_poly(S, 100.0, 0.05, 1.0, True, semantics)
-    dt = time.perf_counter() - t0
-    frac = min(1.0, budget_s / max(dt * M / probe, 1e-9))
+    _, ta, tb = oracle_price(model, probe, N, semantics, is_put, seed, stream)
+    frac = min(1.0, budget_s / max((ta + tb) * M / probe, 1e-9))
     Ms = max(probe, int(M * frac) // 4 * 4)
-    t0 = time.perf_counter()
-    S = orc.gbm_paths(Ms, N, 100.0, 0.05, 0.2, 1.0, 42)
-    t1 = time.perf_counter()
-    res = orc.lsm_poly(S, 100.0, 0.05, 1.0, True, semantics)
-    t2 = time.perf_counter()
+    res, ta, tb = oracle_price(model, Ms, N, semantics, is_put, seed, stream)
     return {
-        "value": Ms * N / (t2 - t0), "unit": "path-steps/s", "cores": threads, "kind": "port",
-        "sample": f"{Ms} paths x {N} steps, same workload/semantics; path-gen {t1 - t0:.2f}s "
-                  f"+ LSM sweeps {t2 - t1:.2f}s, both OpenMP x{threads}; C oracle, f32 paths/f64 sums",
+        "value": Ms * N / (ta + tb), "unit": "path-steps/s", "cores": threads, "kind": "port",
+        "sample": f"{Ms} paths x {N} steps (first {Ms} paths of Philox seed {seed} stream {stream}), same "
+                  f"workload/semantics; path-gen {ta:.2f}s + LSM sweeps {tb:.2f}s, both OpenMP x{threads}; "
+                  f"C oracle, f32 paths/f64 sums",
         "price": res["price"],
     }
 
 
+# ---------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """Parent of a `--gpus N` run without a launcher: start N rank processes (this script again, with
+    the rank environment) and relay rank 0's JSON line.  No GPU call is made here; a child that fails
+    takes the job down with a non-zero exit code (children are never re-exec'd or retried)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMC_BENCH_RANK_PROCESS="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:  # exactly the processes started above
+                    procs[q].terminate()
+        if alive:
+            time.sleep(0.05)
+    out = procs[0].stdout.read().decode()
+    if rc == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(out)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--paths-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
+                    help="c2: GBM put 1M paths/GPU (default); c3: 8M paths/GPU (64M over 8); c4: Heston call 4M")
+    ap.add_argument("--paths-per-gpu", type=int, default=None, help="override the config's paths per GPU")
     ap.add_argument("--n-steps", type=int, default=252)
     ap.add_argument("--semantics", default="two_pass", choices=["two_pass", "reference", "textbook"])
-    ap.add_argument("--model", default="gbm", choices=["gbm", "heston"])
+    ap.add_argument("--model", default=None, choices=["gbm", "heston"], help="override the config's model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--group", type=int, default=10,
                     help="pricings enqueued per omc_price_american_seq call (one host wait per group)")
     ap.add_argument("--sync-every-step", action="store_true",
                     help="one synchronous omc_price_american call per step instead")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend; gloo + --single-device rehearses world_size > 1 on one GPU")
+    ap.add_argument("--backend", default=None, choices=["rccl", "nccl", "gloo"],
+                    help="rccl (default): RCCL called from inside libomc.so, no torch; nccl: torch.distributed "
+                         "over RCCL; gloo (default with --single-device): CPU-side rehearsal of world_size > 1")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="go through torch.distributed/RCCL even with one rank (rehearsal of the N>1 path)")
+                    help="go through the communicator even with one rank (rehearsal of the N>1 path)")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))  # nothing above touched the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(`python bench.py --gpus N`, or torch.distributed.run --nproc-per-node N ... --gpus N)")
     local_rank = 0 if a.single_device else int(os.environ.get("LOCAL_RANK", "0"))
-    M, N = a.paths_per_gpu, a.n_steps
+    cfg = CONFIGS[a.config]
+    model = a.model or cfg["model"]
+    M = a.paths_per_gpu or cfg["paths_per_gpu"]
+    N = a.n_steps
+    is_put = model == "gbm"
+    backend = a.backend or ("gloo" if a.single_device and world > 1 else "rccl")
 
-    import torch
-    from options_model_amd import _ffi, dist as omc_dist
+    from options_model_amd import _ffi
 
-    if not torch.cuda.is_available() or _ffi.device_count() < 1:
+    ndev = _ffi.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if not a.single_device and ndev < world:
+        raise SystemExit(f"bench.py: --gpus {world} but this node shows {ndev} HIP device(s)")
+
     dist_mode = world > 1 or a.force_dist
     stdout_fd = None
+    pricer = None
+    comm = "none"
     if dist_mode:
         # RCCL prints a version banner on stdout when its first communicator comes up; the contract
         # is ONE JSON line on stdout, so everything before it goes to stderr at the descriptor level
         sys.stdout.flush()
         stdout_fd = os.dup(1)
         os.dup2(2, 1)
-        import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        if a.backend == "nccl":
-            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            td.init_process_group("gloo", rank=rank, world_size=world)
-        pricer = omc_dist.ShardedPricer(local_rank, force_hook=a.force_dist)
-        barrier = td.barrier
+        from options_model_amd import dist as omc_dist
+        if backend == "rccl":
+            try:
+                pricer = omc_dist.RcclPricer(local_rank, rank, world)
+                comm = "rccl-native (ncclAllReduce enqueued by libomc.so)"
+            except Exception as e:  # library missing / init refused: same collectives through torch
+                print(f"bench.py rank {rank}: native RCCL unavailable ({e}); using torch.distributed nccl",
+                      file=sys.stderr)
+                backend = "nccl"
+        if pricer is None:
+            import torch
+            import torch.distributed as td
+            torch.cuda.set_device(local_rank)
+            if backend == "nccl":
+                td.init_process_group("nccl", rank=rank, world_size=world,
+                                      device_id=torch.device("cuda", local_rank))
+            else:
+                td.init_process_group("gloo", rank=rank, world_size=world)
+            pricer = omc_dist.ShardedPricer(local_rank, force_hook=a.force_dist)
+            comm = f"torch.distributed {backend} (all-reduce hook)"
+        ctx = pricer.ctx
+        barrier = pricer.barrier
+        rccl_ranks = pricer.comm_ranks()
+        if rccl_ranks != world:
+            raise SystemExit(f"bench.py: communicator has {rccl_ranks} ranks, expected {world}")
     else:
-        pricer = None
         ctx = _ffi.Context(local_rank)
         barrier = lambda: None  # noqa: E731
+        rccl_ranks = 0
 
-    kw = dict(model=a.model, is_put=(a.model == "gbm"), semantics=a.semantics, n_steps=N, seed=42)
+    def params(sem, stream, n_paths=M, pair_offset=0):
+        return _ffi.make_params(model=model, is_put=is_put, semantics=sem, n_steps=N, seed=42, stream=stream,
+                                n_paths=n_paths, pair_offset=pair_offset,
+                                heston_scheme="full_truncation" if model == "heston" else "reference")
+
+    kw = dict(model=model, is_put=is_put, semantics=a.semantics, n_steps=N, seed=42,
+              heston_scheme="full_truncation" if model == "heston" else "reference")
+
+    def price_group(ids, sem=a.semantics):
+        """Enqueue the pricings `ids` (Philox stream ids) back to back -> (price of the last, local results)."""
+        if pricer is not None:
+            louts = pricer.price_american_seq(M * world, ids, **dict(kw, semantics=sem))
+            return louts[-1]["price"], [o["local"] for o in louts]
+        outs = ctx.price_american_seq([params(sem, i) for i in ids])
+        return outs[-1]["price"], outs
 
     def one_step(i):
         if pricer is not None:
             out = pricer.price_american(M * world, stream=i, **kw)
-            return out, out["local"]
-        out = ctx.price_american(_ffi.make_params(n_paths=M, stream=i, **kw))
-        return out, out
+            return out["price"], out["local"]
+        out = ctx.price_american(params(a.semantics, i))
+        return out["price"], out
 
     for i in range(a.warmup):
         one_step(1000 + i)
     barrier()
-    torch.cuda.synchronize()
+    ctx.sync()
     t0 = time.perf_counter()
     ms_paths = ms_lsm = ms_p1 = ms_p2 = 0.0
     price = 0.0
+    last_stream = a.steps - 1
     if not a.sync_every_step:
         # The K pricings are enqueued through omc_price_american_seq in groups of `--group` (no host
         # synchronisation inside a group: pricing i + 1 is launched while pricing i runs; with several
         # ranks the all-reduces are stream-ordered too); every group's first pricing carries the HIP
-        # events the per-kernel times come from.
+        # events (on the library's own stream) the per-kernel times come from.
         nsamp = 0
         for lo in range(0, a.steps, a.group):
             ids = list(range(lo, min(lo + a.group, a.steps)))
-            if pricer is not None:
-                louts = pricer.price_american_seq(M * world, ids, **kw)
-                outs = [o["local"] for o in louts]
-                price = louts[-1]["price"]
-            else:
-                outs = ctx.price_american_seq([_ffi.make_params(n_paths=M, stream=i, **kw) for i in ids])
-                price = outs[-1]["price"]
+            price, outs = price_group(ids)
             ms_paths += outs[0]["ms_paths"]
             ms_lsm += outs[0]["ms_lsm"] if len(outs) == 1 else sum(o["ms_total"] for o in outs) / len(outs) - outs[0]["ms_paths"]
             ms_p1 += outs[0].get("ms_pass1", 0.0)
@@ -179,20 +307,16 @@ def main():
         ms_paths *= scale; ms_lsm *= scale; ms_p1 *= scale; ms_p2 *= scale
     else:
         for i in range(a.steps):
-            out, loc = one_step(i)
+            price, loc = one_step(i)
             ms_paths += loc["ms_paths"]
             ms_lsm += loc["ms_lsm"]
             ms_p1 += loc.get("ms_pass1", 0.0)
             ms_p2 += loc.get("ms_pass2", 0.0)
-            price = out["price"]
     barrier()
-    torch.cuda.synchronize()
+    ctx.sync()
     elapsed = time.perf_counter() - t0
     if dist_mode:
-        import torch.distributed as td
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = pricer.allreduce_max(elapsed)
 
     ms_paths /= a.steps
     ms_lsm /= a.steps
@@ -208,14 +332,16 @@ def main():
         "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{a.model.upper()} American {'put' if a.model == 'gbm' else 'call'}, "
+        "config": {"workload": f"{model.upper()} American {'put' if is_put else 'call'}, "
                                f"S0=K=100 r=0.05 sigma=0.2 T=1, {M} paths x {N} steps per GPU, "
                                f"polynomial LSM [1,u,u^2] ({a.semantics} flow)",
-                   "paths_per_gpu": M, "n_steps": N, "semantics": a.semantics,
+                   "baseline_config": a.config, "paths_per_gpu": M, "n_steps": N, "semantics": a.semantics,
                    "parallelism": f"path-sharded x{world}" if world > 1 else "single GPU",
-                   "rng": "Philox4x32-10 + Box-Muller, antithetic"},
+                   "rng": "Philox4x32-10 + Box-Muller, antithetic",
+                   "arithmetic": "f32 paths, f64 moments / solve / decisions / sums"},
         "paths_x252_per_sec_per_gpu": M * N * a.steps / elapsed / 252.0,
-        "price": price,
+        "price": price, "price_stream": last_stream,
+        "rccl_ranks": rccl_ranks, "comm": comm,
     }
 
     # ---- roofline: every big kernel of the pricing, HIP-event time per launch inside the timed
@@ -225,23 +351,29 @@ def main():
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "ms_per_launch": ms,
-                "launches_per_pricing": launches, "traffic": None}
+                "launches_per_pricing": launches, "traffic": None, "traffic_source": None}
 
-    kernels = [rf(f"{a.model}_paths_kernel", b_gen, ms_paths)]
+    kernels = [rf(f"{model}_paths_kernel", b_gen, ms_paths)]
     if a.semantics == "two_pass":
         kernels.append(rf("lsm_pass1_kernel", 4.0 * M * N, ms_p1))  # rows 1..N-1 + terminal row
         kernels.append(rf("lsm_pass2_kernel", 4.0 * M * N, ms_p2))  # rows N..1 (upper bound)
     else:
-        kernels.append(rf("lsm_step_kernel", 16.0 * M, ms_lsm / N, launches=N))  # S_t, S_t-1, sx, tex
+        kernels.append(rf("lsm_step_kernel", step_bytes_per_path(a.semantics) * M, ms_lsm / N, launches=N))
+    # HBM bytes per launch are PMC counters: they exist only in a rocprofv3 --pmc pass (two separate
+    # passes, FETCH_SIZE doubled per the gfx950 note), so an ordinary run quotes the committed summary
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):  # measured HBM bytes per launch (rocprofv3 --pmc passes, see profiles/)
+    if os.path.exists(prof):
         try:
-            pk = json.load(open(prof)).get("kernels", {})
+            pj = json.load(open(prof))
+            pk = pj.get("kernels", {})
+            same = pj.get("config", "c2") == a.config and pj.get("paths_per_gpu", 1_000_000) == M
             for k in kernels:
                 stem = k["kernel"].replace("gbm_", "").replace("heston_", "")
                 for name, v in pk.items():
-                    if stem in name:
+                    if stem in name and same:
                         k["traffic"] = v["read_bytes"] + v["write_bytes"]
+                        k["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
+                                              f"{pj.get('round', 'r01')}; not measured in this run)"
         except Exception:
             pass
     dominant = max(kernels, key=lambda k: k["ms_per_launch"] * k["launches_per_pricing"])
@@ -249,47 +381,108 @@ def main():
     line["roofline_pathgen"] = kernels[0]
     line["roofline_kernels"] = kernels
     line["roofline_lsm_total"] = {"bytes_per_pricing": b_lsm, "ms_per_pricing": ms_lsm,
-                                  "achieved": b_lsm / (ms_lsm * 1e-3) / 1e9, "unit": "GB/s"}
+                                  "achieved": b_lsm / (ms_lsm * 1e-3) / 1e9 if ms_lsm > 0 else 0.0, "unit": "GB/s"}
+
+    # ---- the per-timestep kernel north_star specifies, as a first-class number: the reference per-step
+    # flow on the same workload, HIP-event time of its N launches (boundaries included) / N
+    if a.semantics != "reference":
+        price_group([900, 901], "reference")  # warm (graph capture, workspaces)
+        barrier(); ctx.sync()
+        t1 = time.perf_counter()
+        reps = max(5, a.steps // 2)
+        pr, outs = price_group(list(range(reps)), "reference")
+        barrier(); ctx.sync()
+        dt = time.perf_counter() - t1
+        if dist_mode:
+            dt = pricer.allreduce_max(dt)
+        ms_sweep = sum(o["ms_total"] for o in outs) / len(outs) - outs[0]["ms_paths"]
+        r = rf("lsm_step_kernel", step_bytes_per_path("reference") * M, ms_sweep / N, launches=N)
+        r.update(flow="reference (per-step sticky flow: Options_model.py:108-157)", price=pr,
+                 ms_per_pricing=1e3 * dt / reps, path_steps_per_s=world * M * N * reps / dt,
+                 note="ms_per_launch = HIP-event time of the whole N-launch sweep / N (kernel boundaries included)")
+        line["roofline_per_step"] = r
+    else:
+        line["roofline_per_step"] = kernels[1]
+
+    # ---- >= 1 s of back-to-back pricings with the same kernels: steady clocks
+    if not a.no_sustained:
+        target_s = 1.0
+        n = max(a.group, int(target_s / max(elapsed / a.steps, 1e-6)) + 1)
+        n = min(n, 20000)
+        barrier(); ctx.sync()
+        t1 = time.perf_counter()
+        done = 0
+        while done < n:
+            ids = list(range(2000 + done, 2000 + min(done + 50, n)))
+            price_group(ids)
+            done += len(ids)
+        barrier(); ctx.sync()
+        dt = time.perf_counter() - t1
+        if dist_mode:
+            dt = pricer.allreduce_max(dt)
+        line["sustained"] = {"pricings": n, "seconds": dt, "ms_per_step": 1e3 * dt / n,
+                             "value": world * M * N * n / dt, "unit": "path-steps/s",
+                             "vs_timed_region": (world * M * N * n / dt) / line["value"]}
+
+    # ---- parity in the bench line: GPU vs the CPU oracle on the SAME Philox (seed, stream), bounded slice
+    if rank == 0:
+        Mc = min(M, 200_000) // 4 * 4
+        try:
+            g = _ffi.Context(local_rank) if dist_mode else ctx  # unsharded, no communicator
+            gp = g.price_american(params(a.semantics, last_stream, n_paths=Mc))["price"]
+            if g is not ctx:
+                g.close()
+            op = oracle_price(model, Mc, N, a.semantics, is_put, 42, last_stream)[0]["price"]
+            line["price_check"] = {"gpu": gp, "oracle": op, "abs_err": abs(gp - op),
+                                   "rel_err": abs(gp - op) / abs(op), "tolerance_rel": 1e-3,
+                                   "same_stream": True, "seed": 42, "stream": last_stream, "paths": Mc,
+                                   "note": "oracle = oracle/omc_oracle.c (f64 restatement pinned to the reference's "
+                                           "fixtures) on the identical Philox normals"}
+        except Exception as e:  # never lose the throughput line to the checker
+            line["price_check"] = {"error": repr(e)}
 
     if not dist_mode and not a.no_variants:
         var = {}
         for sem in ("two_pass", "reference", "textbook"):
             if sem == a.semantics:
                 continue
-            k2 = dict(kw, semantics=sem)
-            ctx.price_american(_ffi.make_params(n_paths=M, stream=77, **k2))
-            torch.cuda.synchronize()
+            ctx.price_american(params(sem, 77))
+            ctx.sync()
             t1 = time.perf_counter()
             reps = max(3, a.steps // 4)
             for i in range(reps):
-                o = ctx.price_american(_ffi.make_params(n_paths=M, stream=i, **k2))
-            torch.cuda.synchronize()
+                o = ctx.price_american(params(sem, i))
+            ctx.sync()
             dt = (time.perf_counter() - t1) / reps
             var[sem] = {"path_steps_per_s": M * N / dt, "ms_per_pricing": 1e3 * dt, "ms_lsm": o["ms_lsm"],
                         "price": o["price"]}
-        if a.model == "gbm":
+        if model == "gbm" and a.config == "c2":
             # BASELINE config 5: the NN regressor (7->64->64->1) on the same paths x steps; the
             # network is trained by the library's fused float32-MFMA kernels (omc_mlp_train_epoch)
-            from options_model_amd import nn_regressor as nnr
-            nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, seed=1, nn_epochs=2)  # warm
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            o = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, M, N, seed=42)
-            dt = time.perf_counter() - t1
-            tk = o.timings_ms.get("seconds_train_kernels", 0.0) * 1e-3
-            flop = 2 * (8 * 64 + 64 * 64 + 64) + 2 * 2 * 64 * 64 + 2 * 8 * 64  # per row: fwd, dH1, gW2, gW1
-            rows_seen = o.sum_nitm * o.info.get("epochs_run", 0)
-            var["nn_2x64"] = {"path_steps_per_s": M * N / dt, "seconds": dt, "price": o.price,
-                              "rows": o.sum_nitm, "train_kernel_seconds": tk, "info": o.info,
-                              "timings_ms": {k: round(v, 3) for k, v in o.timings_ms.items()}}
-            if rows_seen and tk > 0:
-                var["nn_2x64"]["train_mfma"] = {"bound": "mfma", "achieved": rows_seen * flop / tk / 1e12,
-                                                "peak": 157.3, "unit": "TFLOP/s",
-                                                "frac": rows_seen * flop / tk / 1e12 / 157.3}
+            try:
+                import torch
+                from options_model_amd import nn_regressor as nnr
+                nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, seed=1, nn_epochs=2)  # warm
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                o = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, M, N, seed=42)
+                dt = time.perf_counter() - t1
+                tk = o.timings_ms.get("train_kernels", 0.0) * 1e-3
+                flop = 2 * (8 * 64 + 64 * 64 + 64) + 2 * 2 * 64 * 64 + 2 * 8 * 64  # per row: fwd, dH1, gW2, gW1
+                rows_seen = o.sum_nitm * o.info.get("epochs_run", 0)
+                var["nn_2x64"] = {"path_steps_per_s": M * N / dt, "seconds": dt, "price": o.price,
+                                  "rows": o.sum_nitm, "train_kernel_seconds": tk, "info": o.info,
+                                  "timings_ms": {k: round(v, 3) for k, v in o.timings_ms.items()}}
+                if rows_seen and tk > 0:
+                    var["nn_2x64"]["train_mfma"] = {"bound": "mfma", "achieved": rows_seen * flop / tk / 1e12,
+                                                    "peak": 157.3, "unit": "TFLOP/s",
+                                                    "frac": rows_seen * flop / tk / 1e12 / 157.3}
+            except Exception as e:
+                var["nn_2x64"] = {"error": repr(e)}
         line["variants"] = var
 
-    if rank == 0 and not dist_mode and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(M, N, a.semantics)
+    if rank == 0 and a.gpus == 1 and not a.force_dist and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(model, M, N, a.semantics, is_put, 42, last_stream)
     elif rank == 0:
         line["cpu_baseline"] = None
     if stdout_fd is not None:
@@ -299,9 +492,11 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist_mode:
-        import torch.distributed as td
+        barrier()
         pricer.close()
-        td.destroy_process_group()
+        if comm.startswith("torch"):
+            import torch.distributed as td
+            td.destroy_process_group()
     else:
         ctx.close()
 

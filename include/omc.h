@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OMC_ABI_VERSION 2
+#define OMC_ABI_VERSION 3
 
 typedef struct omc_ctx omc_ctx;
 
@@ -87,7 +87,8 @@ int omc_free(omc_ctx* ctx, void* dptr);
 int omc_memcpy_h2d(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
 int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* knobs: "gbm_vec" / "heston_vec" (pairs per thread: 1,2,4; 0 = auto), "world_size" (ranks behind
- * the all-reduce hook, see below) */
+ * the all-reduce hook, see below), "step_graph" (1 / 0: replay the per-step sweep as one captured HIP
+ * graph or launch its kernels one by one; -1 = default, on) */
 int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
 
 /* ---- path generation ------------------------------------------------------------------- */
@@ -133,6 +134,17 @@ int omc_lsm_apply_frozen(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_pat
                          double K, double r, double T, int is_put, const double* betas,
                          omc_result* res, float* sx_out, int32_t* tex_out);
 
+/* the per-step flows (semantics 0 / 1) driven by EXTERNALLY supplied continuation values instead of
+ * the fitted polynomial: cont is a device float32 matrix [n_steps+1][ldc] (row t = continuation value of
+ * every path at step t, the float32 a torch module returns; entries of paths that are out of the money
+ * or, under semantics 0, already exercised are never read).  Replays a recorded run of the reference's
+ * own per-step loop -- Options_model.py:108-157 / options_model_2.py:278-313, whose ContNet outputs are
+ * the `continuation` of :141-142 -- through the kernel that implements its mask, discounting, strict `>`
+ * and (mean, std, zero_prob) statistics. */
+int omc_lsm_apply_values(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps,
+                         double K, double r, double T, int is_put, int semantics, const float* cont,
+                         int64_t ldc, omc_result* res, float* sx_out, int32_t* tex_out);
+
 /* multi-GPU: paths shard by antithetic pair, only regression moments and the final sums
  * cross GPUs.  `hook(user, dptr, count)` must all-reduce (sum) `count` DEVICE doubles in place,
  * ordered on the context's stream (RCCL via torch.distributed on the host side).  It is called
@@ -143,6 +155,22 @@ int omc_lsm_apply_frozen(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_pat
  * n_paths * world_size (omc_set_option(ctx, "world_size", W); shards are equal). */
 typedef int (*omc_allreduce_fn)(void* user, double* dptr, int count);
 int omc_set_allreduce_hook(omc_ctx* ctx, omc_allreduce_fn fn, void* user);
+
+/* The same exchange with RCCL called from inside the library (no host callback, no PyTorch):
+ * librccl.so is opened on first use.  Rank 0 makes a 128-byte unique id (omc_comm_unique_id) and hands
+ * it to the other ranks by any means (options_model_amd/rendezvous.py uses a file on the node); every
+ * rank then calls omc_comm_init on its context (collective: ncclCommInitRank on the context's device).
+ * From then on the context's pricing calls enqueue ncclAllReduce(sum, double) on its stream for the
+ * moment table(s) and the 8 result sums exactly where the hook would have been called, the returned
+ * omc_result carries GLOBAL sums, and "world_size" is the communicator's rank count.  The reference has
+ * no counterpart (no distributed code: SURVEY.md section 5.8).
+ * omc_comm_allreduce_f64: blocking all-reduce of a small HOST vector (op 0 = sum, 1 = max) through the
+ * same communicator -- barriers and max-over-ranks timings of a benchmark harness. */
+int omc_comm_unique_id(void* uid_out, size_t bytes);
+int omc_comm_init(omc_ctx* ctx, int rank, int world, const void* uid, size_t bytes);
+int omc_comm_destroy(omc_ctx* ctx);
+int omc_comm_info(omc_ctx* ctx, int* rank, int* world); /* world = 0: no communicator */
+int omc_comm_allreduce_f64(omc_ctx* ctx, double* host_inout, int count, int op);
 
 /* ---- fused pricing: paths -> LSM -> discounted mean ----------------------------------------- */
 /* replaces AdvancedOptionPricer.price_american_enhanced_lsm options_model_3.py:439-651 and

@@ -14,8 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomc.so")
-SOURCES = ["omc_paths.hip", "omc_lsm.hip", "omc_batch.hip", "omc_mlp.hip", "omc_rows.hip", "omc_api.hip"]
-HEADERS = ["omc_device.h", "omc_kernels.h", "omc_lsm_dev.h", "omc_paths_dev.h", "omc_batch.h",
+SOURCES = ["omc_paths.hip", "omc_lsm.hip", "omc_batch.hip", "omc_mlp.hip", "omc_rows.hip", "omc_comm.hip",
+           "omc_api.hip"]
+HEADERS = ["omc_device.h", "omc_kernels.h", "omc_lsm_dev.h", "omc_paths_dev.h", "omc_batch.h", "omc_comm.h",
            os.path.join("..", "..", "include", "omc.h")]
 ARCH = "gfx950"
 
@@ -55,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)

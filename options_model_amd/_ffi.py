@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
 MODELS = {"gbm": 0, "heston": 1}
@@ -70,7 +70,13 @@ SIGNATURES = {
     "omc_gbm_normals_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _U64, _U64, _U64]),
     "omc_lsm_poly": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, C.POINTER(Result), _P, _P, _P]),
     "omc_lsm_apply_frozen": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _P, C.POINTER(Result), _P, _P]),
+    "omc_lsm_apply_values": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _P, _I64, C.POINTER(Result), _P, _P]),
     "omc_set_allreduce_hook": (C.c_int, [_P, ALLREDUCE_FN, _P]),
+    "omc_comm_unique_id": (C.c_int, [_P, _SZ]),
+    "omc_comm_init": (C.c_int, [_P, _I, _I, _P, _SZ]),
+    "omc_comm_destroy": (C.c_int, [_P]),
+    "omc_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "omc_comm_allreduce_f64": (C.c_int, [_P, _P, _I, _I]),
     "omc_price_american": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result), _P, _I64]),
     "omc_price_european": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result)]),
     "omc_heston_price_strikes": (C.c_int, [_P, _I64, _I] + [_D] * 8 + [_U64, _U64, _I, _P, _I, _I, _P, _P]),
@@ -164,6 +170,14 @@ def _check(lib, rc):
     if rc < 0:
         raise ValueError(msg)
     raise OmcError(f"HIP error {rc}: {msg}")
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: a fresh RCCL unique id (128 bytes) for Context.comm_init on every rank."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    _check(lib, lib.omc_comm_unique_id(buf, 128))
+    return buf.raw
 
 
 def device_count() -> int:
@@ -351,6 +365,40 @@ class Context:
         d = res.as_dict()
         d.update(sx=sx, tex=tex)
         return d
+
+    def lsm_apply_values(self, S, K, r, T, is_put, cont, semantics="reference", want_state=True):
+        """Per-step sweep driven by a device float32 matrix of continuation values [N+1][M]."""
+        N, M = S.shape[0] - 1, S.shape[1]
+        assert cont.shape == (N + 1, M) and cont.dtype == np.float32
+        res = Result()
+        sx = np.zeros(M, np.float32) if want_state else None
+        tex = np.zeros(M, np.int32) if want_state else None
+        _check(self.lib, self.lib.omc_lsm_apply_values(self.handle, S.ptr, M, M, N, K, r, T, int(is_put),
+                                                        SEMANTICS[semantics], cont.ptr, M, C.byref(res),
+                                                        sx.ctypes.data if want_state else None,
+                                                        tex.ctypes.data if want_state else None))
+        d = res.as_dict()
+        d.update(sx=sx, tex=tex)
+        return d
+
+    # -- native RCCL communicator (no torch): see include/omc.h
+    def comm_init(self, rank: int, world: int, uid: bytes):
+        buf = C.create_string_buffer(bytes(uid), 128)
+        _check(self.lib, self.lib.omc_comm_init(self.handle, int(rank), int(world), buf, 128))
+
+    def comm_destroy(self):
+        _check(self.lib, self.lib.omc_comm_destroy(self.handle))
+
+    def comm_info(self):
+        """-> (rank, world) of the live communicator; world == 0: none."""
+        r, w = C.c_int(0), C.c_int(0)
+        _check(self.lib, self.lib.omc_comm_info(self.handle, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def comm_allreduce(self, values, op="sum"):
+        a = np.ascontiguousarray(values, np.float64).copy()
+        _check(self.lib, self.lib.omc_comm_allreduce_f64(self.handle, a.ctypes.data, a.size, 1 if op == "max" else 0))
+        return a
 
     # -- fused pricing
     def price_american(self, params: Params, keep_paths: DeviceArray | None = None):

@@ -9,7 +9,10 @@
 #include <vector>
 
 #include "../../include/omc.h"
+#include <sched.h>
+
 #include "omc_batch.h"
+#include "omc_comm.h"
 #include "omc_kernels.h"
 
 namespace {
@@ -70,7 +73,7 @@ struct omc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf S, sx, tex, D, part, gmom, betas, part1, result, scratch;
+    DevBuf S, sx, tex, ex, D, part, gmom, betas, part1, result, scratch, sweep_args;
     DevBuf bslab, btable, bres, bdisc;  // batched path: problem slab, table, results, discounts
     DevBuf mlp_part, mlp_loss, mlp_wt;  // NN training: gradient partials, epoch loss, transposed connections
     std::vector<char> h_table;
@@ -87,9 +90,22 @@ struct omc_ctx {
     hipEvent_t ev_seq = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int gbm_vec = 0, heston_vec = 0;
-    int world = 1;  // ranks whose sums the hook adds up (equal shards)
+    int world = 1;  // ranks whose sums the hook / communicator adds up (equal shards)
     omc_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
+    omc::Comm* comm = nullptr;  // native RCCL communicator (omc_comm_init); takes precedence over the hook
+    // captured per-step sweep (N launches + valuation + finalize), replayed for every pricing of the
+    // same geometry; its kernels read their arguments from `sweep_args`
+    hipGraph_t sweep_graph = nullptr;
+    hipGraphExec_t sweep_exec = nullptr;
+    int64_t sg_M = -1, sg_ld = -1;
+    int sg_N = -1, sg_sem = -1, sg_vec4 = -1, sg_failed = 0;
+    const void* sg_args = nullptr;
+    std::vector<char> sweep_img;   // last argument image uploaded to sweep_args
+    char* sweep_pin = nullptr;     // pinned upload ring
+    int sweep_pin_slot = 0;
+    int step_graph = -1;           // -1: environment default (on), 0 off, 1 on
+    bool distributed() const { return comm != nullptr || hook != nullptr; }
 };
 
 namespace {
@@ -124,13 +140,23 @@ int bind(omc_ctx* c)
 }
 
 // Wait for the stream by polling: a pricing lasts well under a millisecond, and the wake-up
-// latency of a blocking hipStreamSynchronize is a visible fraction of that.
+// latency of a blocking hipStreamSynchronize is a visible fraction of that.  The spin is bounded
+// in TIME (about 2 ms of polling, yielding the core between polls after the first 50 us), then the
+// call blocks: several ranks on a small CPU quota must not burn it all in spin loops.
 int wait_stream(omc_ctx* c)
 {
-    for (int i = 0; i < 400000; ++i) {
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0;; ++i) {
         const hipError_t q = hipStreamQuery(c->stream);
         if (q == hipSuccess) return 0;
         if (q != hipErrorNotReady) HIP_TRY(q);
+        if ((i & 15) == 15) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+            if (us > 2000.0) break;
+            if (us > 50.0) sched_yield();
+        }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -143,6 +169,7 @@ int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
     int rc;
     if ((rc = c->sx.ensure(sizeof(float) * (size_t)M))) return rc;
     if ((rc = c->tex.ensure(sizeof(int32_t) * (size_t)M))) return rc;
+    if ((rc = c->ex.ensure((size_t)M + 16))) return rc;
     if ((rc = c->D.ensure(sizeof(double) * (size_t)(N + 1)))) return rc;
     if ((rc = c->part.ensure(sizeof(double) * 2 * 8 * omc::kMaxLsmBlocks))) return rc;
     if ((rc = c->gmom.ensure(sizeof(double) * 8 * (size_t)(N + 1)))) return rc;
@@ -158,6 +185,7 @@ int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
     }
     w->sx = (float*)c->sx.p;
     w->tex = (int32_t*)c->tex.p;
+    w->ex = (uint8_t*)c->ex.p;
     w->D = (double*)c->D.p;
     w->part = (double*)c->part.p;
     w->gmom = (double*)c->gmom.p;
@@ -184,47 +212,138 @@ int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
     return 0;
 }
 
+// in-place sum over the ranks of `count` device doubles, ordered on the context's stream: the native
+// RCCL communicator when there is one (enqueued from here, no host callback), else the caller's hook
+int allreduce(omc_ctx* c, double* dptr, int count)
+{
+    if (c->comm) {
+        std::string err;
+        const int rc = omc::comm_allreduce_f64(c->comm, dptr, (size_t)count, 0, c->stream, &err);
+        if (rc) return fail(rc, err.c_str());
+        return 0;
+    }
+    if (c->hook) {
+        if (c->hook(c->hook_user, dptr, count)) return fail(998, "all-reduce hook failed");
+    }
+    return 0;
+}
+
+bool step_graph_enabled(const omc_ctx* c)
+{
+    if (c->step_graph >= 0) return c->step_graph != 0;
+    static const int env = [] {
+        const char* e = getenv("OMC_STEP_GRAPH");
+        return e ? atoi(e) : 1;
+    }();
+    return env != 0;
+}
+
+void drop_sweep_graph(omc_ctx* c)
+{
+    if (c->sweep_exec) (void)hipGraphExecDestroy(c->sweep_exec);
+    if (c->sweep_graph) (void)hipGraphDestroy(c->sweep_graph);
+    c->sweep_exec = nullptr;
+    c->sweep_graph = nullptr;
+    c->sg_M = -1;
+}
+
+// The per-step sweep as ONE graph launch.  Returns 0 when the sweep was enqueued, kNoGraph when the
+// caller should launch the kernels one by one (capture unavailable), else an error code.
+constexpr int kNoGraph = -12345;
+int enqueue_sweep_graph(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w, int semantics,
+                        bool fill_state)
+{
+    if (c->sg_failed) return kNoGraph;
+    const size_t nb = omc::lsm_sweep_args_bytes();
+    constexpr int kSlots = 32;
+    if (c->sweep_args.ensure(nb)) return kNoGraph;
+    if (!c->sweep_pin && hipHostMalloc((void**)&c->sweep_pin, nb * kSlots, hipHostMallocDefault) != hipSuccess) {
+        c->sweep_pin = nullptr;
+        c->sg_failed = 1;
+        (void)hipGetLastError();
+        return kNoGraph;
+    }
+    std::vector<char> img(nb);
+    omc::lsm_sweep_args_image(p, w, semantics, fill_state, img.data());
+    if (img != c->sweep_img) {
+        if (c->sweep_pin_slot == kSlots) {  // the ring wraps: earlier uploads must have been consumed
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->sweep_pin_slot = 0;
+        }
+        char* slot = c->sweep_pin + nb * (size_t)c->sweep_pin_slot++;
+        memcpy(slot, img.data(), nb);
+        HIP_TRY(hipMemcpyAsync(c->sweep_args.p, slot, nb, hipMemcpyHostToDevice, c->stream));
+        c->sweep_img.swap(img);
+    }
+    const int vec4 = ((p.M % 4) == 0 && (p.ld % 4) == 0 && ((uintptr_t)p.S % 16) == 0) ? 1 : 0;
+    if (!c->sweep_exec || c->sg_M != p.M || c->sg_N != p.N || c->sg_sem != semantics || c->sg_vec4 != vec4 ||
+        c->sg_ld != p.ld || c->sg_args != c->sweep_args.p) {
+        drop_sweep_graph(c);
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const hipError_t le = omc::lsm_sweep_indirect(c->stream, p, w, semantics, c->sweep_args.p);
+            const hipError_t ee = hipStreamEndCapture(c->stream, &c->sweep_graph);
+            ok = le == hipSuccess && ee == hipSuccess && c->sweep_graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&c->sweep_exec, c->sweep_graph, nullptr, nullptr, 0) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            drop_sweep_graph(c);
+            c->sg_failed = 1;
+            return kNoGraph;
+        }
+        c->sg_M = p.M; c->sg_N = p.N; c->sg_sem = semantics; c->sg_vec4 = vec4; c->sg_ld = p.ld;
+        c->sg_args = c->sweep_args.p;
+    }
+    HIP_TRY(hipGraphLaunch(c->sweep_exec, c->stream));
+    return 0;
+}
+
 // enqueue the whole backward induction on c->stream; sums land in w.result
 int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w, int semantics,
                 bool write_state)
 {
     hipStream_t st = c->stream;
+    int rc;
     if (semantics == OMC_SEM_TWO_PASS) {
         HIP_TRY(omc::lsm_pass1_moments(st, p, w));
-        if (c->hook) {
-            int rc = c->hook(c->hook_user, w.gmom, 8 * (p.N + 1));
-            if (rc) return fail(998, "all-reduce hook failed");
-        }
+        if (c->distributed() && (rc = allreduce(c, w.gmom, 8 * (p.N + 1)))) return rc;
         HIP_TRY(omc::lsm_solve_all(st, p, w));
         HIP_TRY(omc::lsm_pass2_apply(st, p, w, write_state));
     } else {
-        const bool ext = c->hook != nullptr;
-        const int nblk = omc::lsm_sweep_blocks(p.M);
-        for (int t = p.N; t >= 1; --t) {
-            HIP_TRY(omc::lsm_step(st, p, w, semantics, t, ext));
-            if (ext && t >= 2) {
-                HIP_TRY(omc::lsm_reduce_step_moments(st, w, t - 1, nblk));
-                int rc = c->hook(c->hook_user, w.gmom + (size_t)(t - 1) * 8, 8);
-                if (rc) return fail(998, "all-reduce hook failed");
-            }
+        const bool ext = c->distributed();
+        const bool flags = semantics == OMC_SEM_REFERENCE;
+        int graphed = kNoGraph;
+        if (!ext && step_graph_enabled(c)) {
+            graphed = enqueue_sweep_graph(c, p, w, semantics, write_state);
+            if (graphed != 0 && graphed != kNoGraph) return graphed;
         }
-        HIP_TRY(omc::lsm_final_reduce(st, p, w, semantics == OMC_SEM_TEXTBOOK ? 0 : 1));
+        if (graphed == kNoGraph) {
+            const int nblk = omc::lsm_sweep_blocks(p.M);
+            for (int t = p.N; t >= 1; --t) {
+                HIP_TRY(omc::lsm_step(st, p, w, semantics, t, ext));
+                if (ext && t >= 2) {
+                    HIP_TRY(omc::lsm_reduce_step_moments(st, w, t - 1, nblk));
+                    if ((rc = allreduce(c, w.gmom + (size_t)(t - 1) * 8, 8))) return rc;
+                }
+            }
+            HIP_TRY(omc::lsm_final_reduce(st, p, w, semantics == OMC_SEM_TEXTBOOK ? 0 : 1, flags, write_state));
+        }
     }
-    if (c->hook) {  // {sum, sumsq, n_exercised, n_zero, sum_nitm, ..} -> global sums
-        int rc = c->hook(c->hook_user, w.result, 8);
-        if (rc) return fail(998, "all-reduce hook failed");
-    }
+    // {sum, sumsq, n_exercised, n_zero, sum_nitm, ..} -> global sums.  Slot 4 is built from the moment
+    // table, which is ALREADY global on every rank: fill_result divides it by the world size again.
+    if (c->distributed() && (rc = allreduce(c, w.result, 8))) return rc;
     return 0;
 }
 
-void fill_result(omc_result* res, const double* h, int64_t M)
+void fill_result(omc_result* res, const double* h, int64_t M, int world = 1)
 {
     res->sum = h[0];
     res->sumsq = h[1];
     res->n_paths = M;
     res->n_exercised = (int64_t)llround(h[2]);
     res->n_zero = (int64_t)llround(h[3]);
-    res->sum_nitm = (int64_t)llround(h[4]);
+    res->sum_nitm = (int64_t)llround(h[4] / (double)world);
     res->price = h[0] / (double)M;
     const double var = h[1] / (double)M - res->price * res->price;
     res->std = var > 0 ? std::sqrt(var) : 0.0;
@@ -278,29 +397,35 @@ int omc_ctx_create(int device, void* hip_stream, omc_ctx** out)
     HIP_TRY(hipSetDevice(device));
     omc_ctx* c = new omc_ctx();
     c->device = device;
+    auto undo = [&](hipError_t e) {  // release what was created so far, report e
+        for (auto& ev : c->ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return e;
+    };
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
         c->own_stream = false;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        const hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
-            delete c;
-            HIP_TRY(e);
+            c->stream = nullptr;
+            HIP_TRY(undo(e));
         }
         c->own_stream = true;
     }
     for (auto& ev : c->ev) {
-        hipError_t e = hipEventCreate(&ev);
+        const hipError_t e = hipEventCreate(&ev);
         if (e != hipSuccess) {
-            delete c;
-            HIP_TRY(e);
+            ev = nullptr;
+            HIP_TRY(undo(e));
         }
     }
     if (hipHostMalloc((void**)&c->hres_pin, sizeof(double) * 8, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->hres_dev, c->hres_pin, 0) != hipSuccess) {
+        (void)hipGetLastError();
         if (c->hres_pin) (void)hipHostFree(c->hres_pin);
-    if (c->seq_pin) (void)hipHostFree(c->seq_pin);
-    if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
         c->hres_pin = c->hres_dev = nullptr;  // fall back to a device buffer + copy into the pageable member
     }
     *out = c;
@@ -312,10 +437,14 @@ int omc_ctx_destroy(omc_ctx* c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
-                      &c->result, &c->scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc, &c->mlp_part,
-                      &c->mlp_loss, &c->mlp_wt})
+    drop_sweep_graph(c);
+    if (c->comm) omc::comm_destroy(c->comm);
+    c->comm = nullptr;
+    for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
+                      &c->result, &c->scratch, &c->sweep_args, &c->bslab, &c->btable, &c->bres, &c->bdisc,
+                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt})
         b->release();
+    if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->hres_pin) (void)hipHostFree(c->hres_pin);
@@ -380,6 +509,7 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     if (!strcmp(key, "gbm_vec")) c->gbm_vec = (int)value;
     else if (!strcmp(key, "heston_vec")) c->heston_vec = (int)value;
     else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
+    else if (!strcmp(key, "step_graph")) c->step_graph = value < 0 ? -1 : (value ? 1 : 0);
     else return fail(-4, "unknown option key.");
     return 0;
 }
@@ -389,6 +519,70 @@ int omc_set_allreduce_hook(omc_ctx* c, omc_allreduce_fn fn, void* user)
     if (!c) return fail(-7, "null context.");
     c->hook = fn;
     c->hook_user = user;
+    return 0;
+}
+
+// ------------------------------------------------------------------ native RCCL communicator
+int omc_comm_unique_id(void* uid_out, size_t bytes)
+{
+    if (!uid_out || bytes < (size_t)omc::kCommUidBytes) return fail(-7, "unique-id buffer must hold 128 bytes.");
+    std::string err;
+    const int rc = omc::comm_unique_id(uid_out, &err);
+    if (rc) return fail(rc, err.c_str());
+    return 0;
+}
+
+int omc_comm_init(omc_ctx* c, int rank, int world, const void* uid, size_t bytes)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!uid || bytes < (size_t)omc::kCommUidBytes) return fail(-7, "unique id must be 128 bytes.");
+    if (world < 1 || rank < 0 || rank >= world) return fail(-4, "rank / world size out of range.");
+    if (c->comm) return fail(-4, "this context already has a communicator.");
+    std::string err;
+    omc::Comm* comm = nullptr;
+    rc = omc::comm_create(rank, world, uid, &comm, &err);
+    if (rc) return fail(rc, err.c_str());
+    c->comm = comm;
+    c->world = omc::comm_world(comm);
+    return 0;
+}
+
+int omc_comm_destroy(omc_ctx* c)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!c->comm) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    omc::comm_destroy(c->comm);
+    c->comm = nullptr;
+    c->world = 1;
+    return 0;
+}
+
+int omc_comm_info(omc_ctx* c, int* rank, int* world)
+{
+    if (!c) return fail(-7, "null context.");
+    if (rank) *rank = omc::comm_rank(c->comm);
+    if (world) *world = c->comm ? omc::comm_world(c->comm) : 0;
+    return 0;
+}
+
+int omc_comm_allreduce_f64(omc_ctx* c, double* host_inout, int count, int op)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!c->comm) return fail(-4, "no communicator on this context (omc_comm_init).");
+    if (!host_inout || count <= 0 || count > 4096) return fail(-7, "bad buffer (1..4096 doubles).");
+    if (op != 0 && op != 1) return fail(-4, "op must be 0 (sum) or 1 (max).");
+    if ((rc = c->scratch.ensure(sizeof(double) * 4096))) return rc;
+    double* d = (double*)c->scratch.p;
+    HIP_TRY(hipMemcpyAsync(d, host_inout, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    std::string err;
+    rc = omc::comm_allreduce_f64(c->comm, d, (size_t)count, op, c->stream, &err);
+    if (rc) return fail(rc, err.c_str());
+    HIP_TRY(hipMemcpyAsync(host_inout, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -517,7 +711,7 @@ int omc_lsm_poly(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     if ((rc = copy_outputs(c, w, n_paths, n_steps, betas_out, sx_out, tex_out))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     memset(res, 0, sizeof *res);
-    fill_result(res, c->hres, c->hook ? n_paths * c->world : n_paths);
+    fill_result(res, c->hres, c->distributed() ? n_paths * c->world : n_paths, c->distributed() ? c->world : 1);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     res->ms_lsm = ms;
@@ -546,6 +740,40 @@ int omc_lsm_apply_frozen(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths
     if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     memset(res, 0, sizeof *res);
+    fill_result(res, c->hres, n_paths);
+    return 0;
+}
+
+// The per-step sweep with EXTERNALLY supplied continuation values: cont is a device float32 matrix
+// [n_steps+1][ldc]; at step t an in-the-money path that may still exercise does so iff
+// payoff > cont[t][j] (strict).  Everything else -- sticky mask or textbook overwrite, discounting,
+// valuation time, the returned statistics -- is the code path of omc_lsm_poly's per-step flows.
+int omc_lsm_apply_values(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                         double r, double T, int is_put, int semantics, const float* cont, int64_t ldc,
+                         omc_result* res, float* sx_out, int32_t* tex_out)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_market(1.0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (semantics != OMC_SEM_REFERENCE && semantics != OMC_SEM_TEXTBOOK)
+        return fail(-4, "continuation values drive the per-step flows only (semantics 0 or 1).");
+    if (!cont || !res) return fail(-7, "null pointer.");
+    if (ldc < n_paths) return fail(-6, "ldc smaller than n_paths.");
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w))) return rc;
+    w.cont = cont;
+    w.ldc = ldc;
+    omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
+    for (int t = n_steps; t >= 1; --t) HIP_TRY(omc::lsm_step(c->stream, p, w, semantics, t, false));
+    HIP_TRY(omc::lsm_final_reduce(c->stream, p, w, semantics == OMC_SEM_TEXTBOOK ? 0 : 1,
+                                  semantics == OMC_SEM_REFERENCE, sx_out || tex_out));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    c->hres[4] = 0.0;  // no regression sets in this mode
     fill_result(res, c->hres, n_paths);
     return 0;
 }
@@ -635,7 +863,7 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     // Single GPU: the finalize kernel stores its 8 sums straight into host-mapped pinned memory (no copy
     // kernel, no extra dependent launch).  With an all-reduce hook the sums stay in device memory for
     // the collective and are copied afterwards.
-    const bool zero_copy = c->hres_dev && !c->hook;
+    const bool zero_copy = c->hres_dev && !c->distributed();
     double* result = nullptr;
     if ((rc = enqueue_pricing(c, p, S_keep, ld, zero_copy ? c->hres_dev : nullptr, true, &result))) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
@@ -644,7 +872,8 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
         HIP_TRY(hipMemcpyAsync(hres, result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
     if ((rc = wait_stream(c))) return rc;
     memset(res, 0, sizeof *res);
-    fill_result(res, hres, c->hook ? p->n_paths * c->world : p->n_paths);  // hook: sums are global
+    fill_result(res, hres, c->distributed() ? p->n_paths * c->world : p->n_paths,
+                c->distributed() ? c->world : 1);  // distributed: sums are global
     return read_kernel_times(c, p, res);
 }
 
@@ -677,10 +906,10 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
         // with an all-reduce hook the sums stay in device memory for the collective (which the hook
         // enqueues on the stream, no host wait) and are copied to the slot afterwards
         double* result = nullptr;
-        if ((rc = enqueue_pricing(c, &p[i], nullptr, 0, c->hook ? nullptr : c->seq_dev + 8 * (size_t)i, i == 0,
+        if ((rc = enqueue_pricing(c, &p[i], nullptr, 0, c->distributed() ? nullptr : c->seq_dev + 8 * (size_t)i, i == 0,
                                   &result)))
             return rc;
-        if (c->hook)
+        if (c->distributed())
             HIP_TRY(hipMemcpyAsync(c->seq_pin + 8 * (size_t)i, result, sizeof(double) * 8, hipMemcpyDeviceToHost,
                                    c->stream));
         if (i == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
@@ -696,7 +925,8 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     if ((rc = read_kernel_times(c, &p[0], &first))) return rc;
     for (int i = 0; i < n; ++i) {
         memset(&res[i], 0, sizeof res[i]);
-        fill_result(&res[i], c->seq_pin + 8 * (size_t)i, c->hook ? p[i].n_paths * c->world : p[i].n_paths);
+        fill_result(&res[i], c->seq_pin + 8 * (size_t)i, c->distributed() ? p[i].n_paths * c->world : p[i].n_paths,
+                    c->distributed() ? c->world : 1);
         res[i].ms_paths = first.ms_paths;
         res[i].ms_pass1 = first.ms_pass1;
         res[i].ms_pass2 = first.ms_pass2;
@@ -792,7 +1022,7 @@ static int check_batch(const omc_params* p, int n)
 static int generator_id(const omc_params* p)
 {
     if (p->model == OMC_MODEL_GBM) return p->antithetic ? 0 : 1;
-    return p->heston_scheme == 0 ? 2 : 3;
+    return 2 + p->heston_scheme;  // 2 reference clamp, 3 full truncation, 4 calibrator scheme
 }
 
 static int run_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res, bool american)
@@ -801,7 +1031,7 @@ static int run_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res, bo
     if ((rc = bind(c))) return rc;
     if ((rc = check_batch(p, n))) return rc;
     if (!res) return fail(-7, "null result pointer.");
-    if (c->hook) return fail(-4, "batched pricing is single-GPU (no all-reduce hook).");
+    if (c->distributed()) return fail(-4, "batched pricing is single-GPU (no all-reduce hook / communicator).");
     const bool two_pass = p[0].semantics == OMC_SEM_TWO_PASS;
     const size_t slab = omc::batch_slab_bytes(p, n, american, two_pass);
     const size_t nd = american ? omc::batch_discount_doubles(p, n) : 0;

@@ -26,7 +26,7 @@ size_t batch_discount_doubles(const BatchItem* items, int n);
 void batch_build(const BatchItem* items, int n, bool american, bool two_pass, char* slab,
                  double* results_dev, double* disc_dev, void* table_host, double* disc_host,
                  BatchExtents* ext);
-// gen: 0 GBM antithetic, 1 GBM plain, 2 Heston reference clamp, 3 Heston full truncation
+// gen: 0 GBM antithetic, 1 GBM plain, 2 Heston reference clamp, 3 Heston full truncation, 4 Heston calibrator scheme
 hipError_t batch_paths(hipStream_t st, const void* table_dev, int n, const BatchExtents& e, int gen);
 hipError_t batch_lsm(hipStream_t st, const void* table_dev, int n, const BatchExtents& e, int semantics);
 hipError_t batch_terminal(hipStream_t st, const void* table_dev, int n, const BatchExtents& e, int gen);

@@ -33,14 +33,15 @@ struct BatchProb {
 };
 
 // ------------------------------------------------------------------ batched entry points
-template <int VEC, int GEN>  // GEN 0 GBM antithetic, 1 GBM plain, 2 Heston clamp, 3 Heston full truncation
+template <int VEC, int GEN>  // GEN 0 GBM antithetic, 1 GBM plain, 2 Heston clamp, 3 full truncation, 4 calibrator
 __global__ __launch_bounds__(kBlock) void paths_batch_kernel(const BatchProb* __restrict__ pr)
 {
     const PathArgs g = pr[blockIdx.y].path;
     if constexpr (GEN == 0) gbm_paths_body<VEC, true>(g);
     else if constexpr (GEN == 1) gbm_paths_body<VEC, false>(g);
     else if constexpr (GEN == 2) heston_paths_body<VEC, 0>(g);
-    else heston_paths_body<VEC, 1>(g);
+    else if constexpr (GEN == 3) heston_paths_body<VEC, 1>(g);
+    else heston_paths_body<VEC, 2>(g);
 }
 
 template <int GEN>
@@ -50,15 +51,16 @@ __global__ __launch_bounds__(kBlock) void terminal_batch_kernel(const BatchProb*
     if constexpr (GEN == 0) terminal_body<0, true>(a);
     else if constexpr (GEN == 1) terminal_body<0, false>(a);
     else if constexpr (GEN == 2) terminal_body<1, true>(a);
-    else terminal_body<2, true>(a);
+    else if constexpr (GEN == 3) terminal_body<2, true>(a);
+    else terminal_body<3, true>(a);
 }
 
-template <int SEM, int VEC>
-__global__ __launch_bounds__(kStepBlock) void lsm_step_batch_kernel(const BatchProb* __restrict__ pr, int t)
+template <int SEM, int VEC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void lsm_step_batch_kernel(const BatchProb* __restrict__ pr, int t)
 {
     StepArgs a = pr[blockIdx.z].step;
     a.t = t;
-    lsm_step_body<SEM, VEC>(a);  // leaves at once when t > N or blockIdx.x >= nblk
+    lsm_step_body<SEM, VEC, BLOCK>(a);  // leaves at once when t > N or blockIdx.x >= nblk
 }
 
 template <int VEC>
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void lsm_finalize_batch_kernel(const BatchP
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {  // byte offsets of one problem's buffers inside the slab
-    size_t S, sx, tex, part, gmom, betas, part1, end;
+    size_t S, sx, tex, ex, part, gmom, betas, part1, end;
     int64_t ld, ntiles;
     int nblk_sweep, nblk_blocks, pstride;
 };
@@ -142,6 +144,7 @@ static Layout plan(const BatchItem& it, size_t base, bool american, bool two_pas
         L.S = take(sizeof(float) * (size_t)L.ld * (size_t)(N + 1));
         L.sx = take(sizeof(float) * (size_t)M);
         L.tex = take(sizeof(int32_t) * (size_t)M);
+        L.ex = take((size_t)M);
         L.gmom = take(sizeof(double) * 8 * (size_t)(N + 1));
         L.betas = take(sizeof(double) * 4 * (size_t)(N + 1));
         if (two_pass) L.part1 = take(sizeof(double) * 8 * (size_t)(N + 1) * (size_t)L.ntiles);
@@ -219,9 +222,10 @@ void batch_build(const BatchItem* items, int n, bool american, bool two_pass, ch
         dk += (size_t)N + 1;
         StepArgs& s = p.step;
         s.S = p.path.S; s.ld = L.ld; s.M = M; s.N = N; s.is_put = it.is_put; s.K = it.K; s.invK = 1.0 / it.K;
-        s.sx = (float*)(slab + L.sx); s.tex = (int32_t*)(slab + L.tex); s.D = D; s.part = part;
+        s.sx = (float*)(slab + L.sx); s.tex = (int32_t*)(slab + L.tex); s.ex = (uint8_t*)(slab + L.ex); s.D = D;
+        s.part = part;
         s.gmom = (double*)(slab + L.gmom); s.betas = (double*)(slab + L.betas);
-        s.t = 0; s.nblk = L.nblk_sweep; s.external = 0; s.pstride = L.pstride;
+        s.t = 0; s.nblk = L.nblk_sweep; s.external = 0; s.pstride = L.pstride; s.cont = nullptr; s.ldc = 0;
         Pass1Args& a1 = p.p1;
         a1.S = s.S; a1.ld = L.ld; a1.M = M; a1.N = N; a1.is_put = it.is_put; a1.K = it.K; a1.invK = s.invK;
         a1.D = D; a1.part1 = two_pass ? (double*)(slab + L.part1) : nullptr; a1.ntiles = L.ntiles; a1.tchunk = 16;
@@ -231,6 +235,7 @@ void batch_build(const BatchItem* items, int n, bool american, bool two_pass, ch
         a2.nblk = L.nblk_blocks; a2.pstride = L.pstride;
         FinalArgs& f = p.fin;
         f.sx = s.sx; f.tex = s.tex; f.M = M; f.N = N; f.is_put = it.is_put; f.tval = it.semantics == 1 ? 0 : 1;
+        f.ex = it.semantics == 0 ? s.ex : nullptr; f.SN = s.S + (int64_t)N * L.ld; f.fill_state = 0;
         f.K = it.K; f.D = D; f.part = part; f.nblk = L.nblk_blocks; f.pstride = L.pstride;
         p.fin_nblk = L.nblk_blocks;
         e.max_steps = std::max(e.max_steps, N);
@@ -249,9 +254,11 @@ hipError_t batch_paths(hipStream_t st, const void* table_dev, int n, const Batch
     const dim3 grid((unsigned)((e.path_blocks + vec - 1) / vec), (unsigned)n), block(kBlock);
 #define OMC_BP(V, G) hipLaunchKernelGGL((paths_batch_kernel<V, G>), grid, block, 0, st, pr)
     if (vec == 4) {
-        if (gen == 0) OMC_BP(4, 0); else if (gen == 1) OMC_BP(4, 1); else if (gen == 2) OMC_BP(4, 2); else OMC_BP(4, 3);
+        if (gen == 0) OMC_BP(4, 0); else if (gen == 1) OMC_BP(4, 1); else if (gen == 2) OMC_BP(4, 2);
+        else if (gen == 3) OMC_BP(4, 3); else OMC_BP(4, 4);
     } else {
-        if (gen == 0) OMC_BP(1, 0); else if (gen == 1) OMC_BP(1, 1); else if (gen == 2) OMC_BP(1, 2); else OMC_BP(1, 3);
+        if (gen == 0) OMC_BP(1, 0); else if (gen == 1) OMC_BP(1, 1); else if (gen == 2) OMC_BP(1, 2);
+        else if (gen == 3) OMC_BP(1, 3); else OMC_BP(1, 4);
     }
 #undef OMC_BP
     return hipGetLastError();
@@ -275,17 +282,22 @@ hipError_t batch_lsm(hipStream_t st, const void* table_dev, int n, const BatchEx
         if (e.vec4) hipLaunchKernelGGL((lsm_pass2_batch_kernel<4>), g2, dim3(kBlock), dyn, st, pr);
         else hipLaunchKernelGGL((lsm_pass2_batch_kernel<1>), g2, dim3(kBlock), dyn, st, pr);
     } else {
-        const dim3 gs((unsigned)e.sweep_blocks, 1, z), bs(kStepBlock);
+        const bool big = lsm_step_block_threads() == 1024;
+        const dim3 gs((unsigned)e.sweep_blocks, 1, z), bs(big ? 1024 : 512);
         const size_t dyn = semantics == 1 ? sizeof(double) * (size_t)(Nmax + 1) : 0;
+#define OMC_BSTEP(SEM, VEC)                                                                              \
+    do {                                                                                                 \
+        if (big) hipLaunchKernelGGL((lsm_step_batch_kernel<SEM, VEC, 1024>), gs, bs, dyn, st, pr, t);    \
+        else hipLaunchKernelGGL((lsm_step_batch_kernel<SEM, VEC, 512>), gs, bs, dyn, st, pr, t);         \
+    } while (0)
         for (int t = Nmax; t >= 1; --t) {
             if (semantics == 0) {
-                if (e.vec4) hipLaunchKernelGGL((lsm_step_batch_kernel<0, 4>), gs, bs, 0, st, pr, t);
-                else hipLaunchKernelGGL((lsm_step_batch_kernel<0, 1>), gs, bs, 0, st, pr, t);
+                if (e.vec4) OMC_BSTEP(0, 4); else OMC_BSTEP(0, 1);
             } else {
-                if (e.vec4) hipLaunchKernelGGL((lsm_step_batch_kernel<1, 4>), gs, bs, dyn, st, pr, t);
-                else hipLaunchKernelGGL((lsm_step_batch_kernel<1, 1>), gs, bs, dyn, st, pr, t);
+                if (e.vec4) OMC_BSTEP(1, 4); else OMC_BSTEP(1, 1);
             }
         }
+#undef OMC_BSTEP
         const dim3 gf((unsigned)e.block_blocks, 1, z);
         if (e.vec4) hipLaunchKernelGGL((lsm_final_batch_kernel<4>), gf, dim3(kBlock), 0, st, pr);
         else hipLaunchKernelGGL((lsm_final_batch_kernel<1>), gf, dim3(kBlock), 0, st, pr);
@@ -301,7 +313,8 @@ hipError_t batch_terminal(hipStream_t st, const void* table_dev, int n, const Ba
     if (gen == 0) hipLaunchKernelGGL((terminal_batch_kernel<0>), grid, dim3(kBlock), 0, st, pr);
     else if (gen == 1) hipLaunchKernelGGL((terminal_batch_kernel<1>), grid, dim3(kBlock), 0, st, pr);
     else if (gen == 2) hipLaunchKernelGGL((terminal_batch_kernel<2>), grid, dim3(kBlock), 0, st, pr);
-    else hipLaunchKernelGGL((terminal_batch_kernel<3>), grid, dim3(kBlock), 0, st, pr);
+    else if (gen == 3) hipLaunchKernelGGL((terminal_batch_kernel<3>), grid, dim3(kBlock), 0, st, pr);
+    else hipLaunchKernelGGL((terminal_batch_kernel<4>), grid, dim3(kBlock), 0, st, pr);
     hipLaunchKernelGGL(lsm_finalize_batch_kernel, dim3(1, 1, (unsigned)n), dim3(kBlock), 0, st, pr, 0);
     return hipGetLastError();
 }

@@ -118,30 +118,43 @@ __device__ __forceinline__ double wave_reduce8(const double (&acc)[kNQ], double*
 }
 
 // ------------------------------------------------------------------ 3x3 OLS solve
+// 1/a for a normal, positive a: v_rcp_f64 seed + two Newton steps (~1 ulp).  An IEEE division
+// expands to ~15 dependent instructions; the per-step kernel solves on its critical path.
+__device__ __forceinline__ double rcp_nr(double a)
+{
+    double x = __builtin_amdgcn_rcp(a);
+    x = fma(fma(-a, x, 1.0), x, x);
+    x = fma(fma(-a, x, 1.0), x, x);
+    return x;
+}
+
 // y ~ b0 + b1 u + b2 u^2 from m = {n, Su, Su2, Su3, Su4, Sy, Suy, Su2y}; centred LDL^T,
-// degree reduced to n-1 for n < 3 or when a pivot is not safely positive.
+// degree reduced to n-1 for n < 3 or when a pivot is not safely positive.  Three reciprocals
+// (1/n, 1/c11, 1/d2) instead of eight divisions.
 __device__ __forceinline__ void solve_poly2(const double (&m)[8], double (&beta)[3])
 {
     const double n = m[0];
     beta[0] = beta[1] = beta[2] = 0.0;
     if (n < 0.5) return;
-    const double mu = m[1] / n, my = m[5] / n;
+    const double rn = rcp_nr(n);
+    const double mu = m[1] * rn, my = m[5] * rn;
     const double c11 = m[2] - m[1] * mu;
     const double c1y = m[6] - m[1] * my;
     if (n < 1.5 || !(c11 > 1e-14 * fabs(m[2]) + 1e-300)) { beta[0] = my; return; }
-    const double mq = m[2] / n;
+    const double mq = m[2] * rn;
     const double c22 = m[4] - m[2] * mq;
     const double c12 = m[3] - m[1] * mq;
     const double c2y = m[7] - m[2] * my;
-    const double l21 = c12 / c11;
+    const double r11 = rcp_nr(c11);
+    const double l21 = c12 * r11;
     const double d2 = c22 - l21 * c12;
     if (n < 2.5 || !(d2 > 1e-12 * fabs(c22) + 1e-300)) {
-        beta[1] = c1y / c11;
+        beta[1] = c1y * r11;
         beta[0] = my - beta[1] * mu;
         return;
     }
-    const double b2 = (c2y - l21 * c1y) / d2;
-    const double b1 = (c1y - c12 * b2) / c11;
+    const double b2 = (c2y - l21 * c1y) * rcp_nr(d2);
+    const double b1 = (c1y - c12 * b2) * r11;
     beta[2] = b2;
     beta[1] = b1;
     beta[0] = my - b1 * mu - b2 * mq;

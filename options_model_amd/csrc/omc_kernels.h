@@ -54,6 +54,7 @@ struct LsmProblem {
 struct LsmWorkspace {
     float* sx;        // [M]   spot at the (current) exercise time of each path
     int32_t* tex;     // [M]   step index of that exercise (N = maturity / never exercised)
+    uint8_t* ex;      // [M]   per-step reference flow: sticky "has exercised" flag (sx / tex valid where set)
     double* D;        // [N+1] discount table exp(-r dt k)
     double* part;     // [2][8][kMaxLsmBlocks] per-block partial moments, ping-pong by step parity
     double* gmom;     // [N+1][8] reduced moments per step
@@ -61,6 +62,8 @@ struct LsmWorkspace {
     double* part1;    // two-pass: [N+1][8][ntiles] partial moments of pass 1
     int64_t part1_tiles;
     double* result;   // [8] sum, sumsq, n_exercised, n_zero, sum_nitm, -, -, -
+    const float* cont = nullptr;  // per-step sweeps, "values" mode: continuation values [N+1][ldc]
+    int64_t ldc = 0;
     // optional: events recorded right around the two big kernels of the two-pass flow
     hipEvent_t ev_p1_begin = nullptr, ev_p1_end = nullptr, ev_p2_begin = nullptr, ev_p2_end = nullptr;
 };
@@ -78,7 +81,15 @@ hipError_t lsm_step(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, 
 // partials of step t -> gmom[t]  (only needed between steps when moments leave the GPU)
 hipError_t lsm_reduce_step_moments(hipStream_t st, const LsmWorkspace& w, int t, int nblk);
 int lsm_step_blocks(int64_t M);   // grid of pass 2 / valuation sweeps (256-thread blocks)
-int lsm_sweep_blocks(int64_t M);  // grid of the per-step sweep (512-thread blocks)
+int lsm_sweep_blocks(int64_t M);  // grid of the per-step sweep
+int lsm_step_block_threads();     // its workgroup size (1024; OMC_STEP_BLOCK=512 for experiments)
+// The whole per-step sweep with its arguments in a device block (lsm_sweep_args_bytes, filled from
+// lsm_sweep_args_image): capturable into a HIP graph whose replays serve every pricing of the same
+// geometry (M, N, semantics, ld, alignment of S).
+size_t lsm_sweep_args_bytes();
+void lsm_sweep_args_image(const LsmProblem& p, const LsmWorkspace& w, int semantics, bool fill_state, void* out);
+hipError_t lsm_sweep_indirect(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
+                              const void* args_dev);
 
 // two-pass flow (semantics 2)
 hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);
@@ -87,8 +98,11 @@ hipError_t lsm_solve_all(hipStream_t st, const LsmProblem& p, const LsmWorkspace
 hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w,
                            bool write_state);
 
-// valuation of (sx,tex): sums into w.result ; tval = 1 (reference flows) or 0 (textbook)
-hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval);
+// valuation of (sx,tex): sums into w.result ; tval = 1 (reference flows) or 0 (textbook);
+// use_flags: state of the per-step reference sweep (w.ex: unexercised paths take (S_N, N)),
+// fill_state: also write that into sx / tex
+hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval,
+                            bool use_flags = false, bool fill_state = false);
 
 // ---- continuation-value network of the NN flow (omc_mlp.hip): 7 -> 64 -> 64 (-> 64) -> 1
 constexpr int kMlpPartialStride2 = 4800;                   // gradient partial per workgroup, 2 / 3 hidden layers

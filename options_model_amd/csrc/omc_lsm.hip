@@ -17,11 +17,25 @@
 // fixed-order reductions (bitwise reproducible), no atomics.
 #include "omc_lsm_dev.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace omc {
 
 // ------------------------------------------------------------------ __global__ entry points
-template <int SEM, int VEC>
-__global__ __launch_bounds__(kStepBlock) void lsm_step_kernel(StepArgs a) { lsm_step_body<SEM, VEC>(a); }
+template <int SEM, int VEC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void lsm_step_kernel(StepArgs a) { lsm_step_body<SEM, VEC, BLOCK>(a); }
+
+// the same with the argument block in device memory: the N launches of one sweep differ only in `t`,
+// so a captured HIP graph of them can be replayed for any pricing of the same geometry after
+// refreshing that block
+template <int SEM, int VEC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void lsm_step_ind_kernel(const StepArgs* __restrict__ ap, int t)
+{
+    StepArgs a = *ap;
+    a.t = t;
+    lsm_step_body<SEM, VEC, BLOCK>(a);
+}
 
 __global__ __launch_bounds__(kBlock) void lsm_reduce_step_kernel(const double* part, double* gmom, int t,
                                                                  int nblk, int pstride)
@@ -31,6 +45,10 @@ __global__ __launch_bounds__(kBlock) void lsm_reduce_step_kernel(const double* p
 
 template <int VEC, int TPW, int PUT>
 __global__ __launch_bounds__(kBlock) void lsm_pass1_kernel(Pass1Args a) { lsm_pass1_body<VEC, TPW, PUT>(a); }
+
+// measurement builds (OMC_PASS1_DIAG=1|2|3, wrong results by construction): which part of the kernel costs what
+template <int DIAG>
+__global__ __launch_bounds__(kBlock) void lsm_pass1_diag_kernel(Pass1Args a) { lsm_pass1_body<4, 4, 1, DIAG>(a); }
 
 __global__ __launch_bounds__(kBlock) void lsm_reduce_pass1_kernel(const double* part1, double* gmom,
                                                                   int64_t ntiles, int N)
@@ -49,10 +67,35 @@ __global__ __launch_bounds__(kBlock) void lsm_pass2_kernel(Pass2Args a) { lsm_pa
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void lsm_final_kernel(FinalArgs a) { lsm_final_body<VEC>(a); }
 
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void lsm_final_ind_kernel(const FinalArgs* __restrict__ ap)
+{
+    lsm_final_body<VEC>(*ap);
+}
+
 __global__ __launch_bounds__(kBlock) void lsm_finalize_kernel(const double* part, const double* gmom,
                                                               double* result, int nblk, int N, int pstride)
 {
     lsm_finalize_body(part, gmom, result, nblk, N, pstride);
+}
+
+struct FinalizeArgs {
+    const double* part;
+    const double* gmom;
+    double* result;
+    int nblk, N, pstride;
+};
+// device-resident argument block of a captured per-step sweep
+struct SweepArgs {
+    StepArgs step;
+    FinalArgs fin;
+    FinalizeArgs fz;
+};
+
+__global__ __launch_bounds__(kBlock) void lsm_finalize_ind_kernel(const FinalizeArgs* __restrict__ ap)
+{
+    const FinalizeArgs a = *ap;
+    lsm_finalize_body(a.part, a.gmom, a.result, a.nblk, a.N, a.pstride);
 }
 
 // ------------------------------------------------------------------ host launchers
@@ -69,9 +112,20 @@ int lsm_step_blocks(int64_t M)
     return (int)(b > kMaxLsmBlocks ? kMaxLsmBlocks : b);
 }
 
+int lsm_step_block_threads()
+{
+    // threads per workgroup of the per-step sweep: 1024 (one workgroup per CU, 256 partials) or 512
+    static const int v = [] {
+        const char* e = getenv("OMC_STEP_BLOCK");
+        const int x = e ? atoi(e) : 0;
+        return x == 512 ? 512 : 1024;
+    }();
+    return v;
+}
+
 int lsm_sweep_blocks(int64_t M)
 {
-    const int64_t per_block = (int64_t)kStepBlock * 4;
+    const int64_t per_block = (int64_t)lsm_step_block_threads() * 4;
     int64_t b = (M + per_block - 1) / per_block;
     if (b < 1) b = 1;
     return (int)(b > kStepMaxBlocks ? kStepMaxBlocks : b);
@@ -83,25 +137,91 @@ size_t lsm_part1_tiles(int64_t M)
     return (size_t)((M + kBlock - 1) / kBlock);
 }
 
+static void fill_step_args(StepArgs& a, const LsmProblem& p, const LsmWorkspace& w, int t, bool external_moments)
+{
+    a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
+    a.K = p.K; a.invK = 1.0 / p.K;
+    a.sx = w.sx; a.tex = w.tex; a.ex = w.ex; a.D = w.D; a.part = w.part; a.gmom = w.gmom; a.betas = w.betas;
+    a.t = t; a.nblk = lsm_sweep_blocks(p.M); a.external = external_moments ? 1 : 0;
+    a.pstride = kPStride;
+    a.cont = w.cont; a.ldc = w.ldc;
+}
+
+template <int SEM, int VEC, int BLOCK>
+static void launch_step(hipStream_t st, const StepArgs& a, const StepArgs* ind, int t, size_t dyn)
+{
+    const dim3 grid(a.nblk), block(BLOCK);
+    if (ind) hipLaunchKernelGGL((lsm_step_ind_kernel<SEM, VEC, BLOCK>), grid, block, dyn, st, ind, t);
+    else hipLaunchKernelGGL((lsm_step_kernel<SEM, VEC, BLOCK>), grid, block, dyn, st, a);
+}
+
+// `ind` != null: the kernel reads its arguments from that device block (see lsm_step_args)
+static hipError_t lsm_step_impl(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
+                                int t, bool external_moments, const StepArgs* ind)
+{
+    StepArgs a;
+    fill_step_args(a, p, w, t, external_moments);
+    const bool v4 = vec4_ok(p);
+    const size_t dyn = semantics == 1 ? sizeof(double) * (size_t)(p.N + 1) : 0;
+    const bool big = lsm_step_block_threads() == 1024;
+#define OMC_STEP(SEM, VEC)                                                       \
+    do {                                                                         \
+        if (big) launch_step<SEM, VEC, 1024>(st, a, ind, t, dyn);               \
+        else launch_step<SEM, VEC, 512>(st, a, ind, t, dyn);                    \
+    } while (0)
+    if (semantics == 0) {
+        if (v4) OMC_STEP(0, 4); else OMC_STEP(0, 1);
+    } else {
+        if (v4) OMC_STEP(1, 4); else OMC_STEP(1, 1);
+    }
+#undef OMC_STEP
+    return hipGetLastError();
+}
+
 hipError_t lsm_step(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
                     int t, bool external_moments)
 {
-    StepArgs a;
-    a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
-    a.K = p.K; a.invK = 1.0 / p.K;
-    a.sx = w.sx; a.tex = w.tex; a.D = w.D; a.part = w.part; a.gmom = w.gmom; a.betas = w.betas;
-    a.t = t; a.nblk = lsm_sweep_blocks(p.M); a.external = external_moments ? 1 : 0;
-    a.pstride = kPStride;
-    const dim3 grid(a.nblk), block(kStepBlock);
-    const bool v4 = vec4_ok(p);
-    const size_t dyn = semantics == 1 ? sizeof(double) * (size_t)(p.N + 1) : 0;
-    if (semantics == 0) {
-        if (v4) hipLaunchKernelGGL((lsm_step_kernel<0, 4>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((lsm_step_kernel<0, 1>), grid, block, 0, st, a);
-    } else {
-        if (v4) hipLaunchKernelGGL((lsm_step_kernel<1, 4>), grid, block, dyn, st, a);
-        else hipLaunchKernelGGL((lsm_step_kernel<1, 1>), grid, block, dyn, st, a);
+    return lsm_step_impl(st, p, w, semantics, t, external_moments, nullptr);
+}
+
+size_t lsm_sweep_args_bytes() { return sizeof(SweepArgs); }
+
+static void fill_final_args(FinalArgs& a, const LsmProblem& p, const LsmWorkspace& w, int tval, bool use_flags,
+                            bool fill_state)
+{
+    a.sx = w.sx; a.tex = w.tex; a.ex = use_flags ? w.ex : nullptr; a.SN = p.S + (int64_t)p.N * p.ld;
+    a.M = p.M; a.N = p.N; a.is_put = p.is_put; a.tval = tval; a.fill_state = fill_state ? 1 : 0;
+    a.K = p.K; a.D = w.D; a.part = w.part;
+    a.nblk = lsm_step_blocks(p.M); a.pstride = kPStride;
+}
+
+// host image of the device argument block the indirect kernels read
+void lsm_sweep_args_image(const LsmProblem& p, const LsmWorkspace& w, int semantics, bool fill_state, void* out)
+{
+    SweepArgs s;
+    memset(&s, 0, sizeof s);
+    fill_step_args(s.step, p, w, 0, false);
+    fill_final_args(s.fin, p, w, semantics == 1 ? 0 : 1, semantics == 0, fill_state);
+    s.fz.part = w.part; s.fz.gmom = w.gmom; s.fz.result = w.result;
+    s.fz.nblk = s.fin.nblk; s.fz.N = p.N; s.fz.pstride = kPStride;
+    memcpy(out, &s, sizeof s);
+}
+
+// the whole per-step sweep (N step launches + valuation + finalize) with device-resident arguments:
+// this is what gets captured into a HIP graph.  Launch geometry depends on (M, N, semantics, ld, S
+// alignment) only -- the graph's cache key.
+hipError_t lsm_sweep_indirect(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
+                              const void* args_dev)
+{
+    const SweepArgs* sa = (const SweepArgs*)args_dev;
+    for (int t = p.N; t >= 1; --t) {
+        hipError_t e = lsm_step_impl(st, p, w, semantics, t, false, &sa->step);
+        if (e != hipSuccess) return e;
     }
+    const int nblk = lsm_step_blocks(p.M);
+    if ((p.M % 4) == 0) hipLaunchKernelGGL((lsm_final_ind_kernel<4>), dim3(nblk), dim3(kBlock), 0, st, &sa->fin);
+    else hipLaunchKernelGGL((lsm_final_ind_kernel<1>), dim3(nblk), dim3(kBlock), 0, st, &sa->fin);
+    hipLaunchKernelGGL(lsm_finalize_ind_kernel, dim3(1), dim3(kBlock), 0, st, &sa->fz);
     return hipGetLastError();
 }
 
@@ -127,7 +247,17 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     a.ntiles = (p.M + per_wave - 1) / per_wave;
     a.tchunk = (tch_env >= 2 && tch_env <= 64) ? tch_env : 32;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
+    static const int diag_env = getenv("OMC_PASS1_DIAG") ? atoi(getenv("OMC_PASS1_DIAG")) : 0;
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
+    if (diag_env >= 1 && diag_env <= 3 && v4 && tpw == 4 && p.is_put) {
+        if (diag_env == 1) hipLaunchKernelGGL((lsm_pass1_diag_kernel<1>), grid, dim3(kBlock), 0, st, a);
+        else if (diag_env == 2) hipLaunchKernelGGL((lsm_pass1_diag_kernel<2>), grid, dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((lsm_pass1_diag_kernel<3>), grid, dim3(kBlock), 0, st, a);
+        if (w.ev_p1_end) (void)hipEventRecord(w.ev_p1_end, st);
+        hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1, 8), dim3(kBlock), 0, st, w.part1, w.gmom,
+                           a.ntiles, p.N);
+        return hipGetLastError();
+    }
     auto launch = [&](auto vec, auto tp) {
         constexpr int V = decltype(vec)::value, T = decltype(tp)::value;
         if (p.is_put) hipLaunchKernelGGL((lsm_pass1_kernel<V, T, 1>), grid, dim3(kBlock), 0, st, a);
@@ -185,13 +315,12 @@ hipError_t lsm_finalize(hipStream_t st, const double* part, const double* gmom, 
     return hipGetLastError();
 }
 
-hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval)
+hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval, bool use_flags,
+                            bool fill_state)
 {
     FinalArgs a;
-    a.sx = w.sx; a.tex = w.tex; a.M = p.M; a.N = p.N; a.is_put = p.is_put; a.tval = tval;
-    a.K = p.K; a.D = w.D; a.part = w.part;
-    const int nblk = lsm_step_blocks(p.M);
-    a.nblk = nblk; a.pstride = kPStride;
+    fill_final_args(a, p, w, tval, use_flags, fill_state);
+    const int nblk = a.nblk;
     if ((p.M % 4) == 0) hipLaunchKernelGGL((lsm_final_kernel<4>), dim3(nblk), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL((lsm_final_kernel<1>), dim3(nblk), dim3(kBlock), 0, st, a);
     hipLaunchKernelGGL(lsm_finalize_kernel, dim3(1), dim3(kBlock), 0, st, w.part, w.gmom, w.result,

@@ -59,8 +59,7 @@ __global__ __launch_bounds__(kBlock) void heston_from_normals_kernel(
     S[p + P] = sa;
     for (int t = 1; t <= n_steps; ++t) {
         const float z1 = Z1[(int64_t)(t - 1) * ldz + p], z2 = Z2[(int64_t)(t - 1) * ldz + p];
-        heston_step<SCHEME>(c, z1, z2, s, va);
-        heston_step<SCHEME>(c, -z1, -z2, sa, vb);
+        heston_pair_step<SCHEME>(c, z1, z2, s, va, sa, vb);
         S[(int64_t)t * ld + p] = s;
         S[(int64_t)t * ld + p + P] = sa;
     }
@@ -111,6 +110,7 @@ HestonC make_heston(double r, double T, int n_steps, double kappa, double theta,
     c.sqdt = (float)sqrt(dt);
     c.rdt = (float)(r * dt);
     c.xi_sqdt = (float)(xi * sqrt(dt));
+    c.l2e_sqdt = (float)(L2E * sqrt(dt));
     return c;
 }
 
@@ -236,8 +236,7 @@ __global__ __launch_bounds__(kBlock) void heston_terminal_store_kernel(float* __
     for (int t = 0; t < g.n_steps; ++t) {
         const int i = t & 1;
         if (i == 0) normals4(g.pair_offset + (uint64_t)p, (uint32_t)(t >> 1), g.stream, g.k0, g.k1, z);
-        heston_step<SCHEME>(g.hc, z[2 * i], z[2 * i + 1], s, va);
-        heston_step<SCHEME>(g.hc, -z[2 * i], -z[2 * i + 1], sa, vb);
+        heston_pair_step<SCHEME>(g.hc, z[2 * i], z[2 * i + 1], s, va, sa, vb);
     }
     ST[p] = s;
     ST[p + g.P] = sa;
@@ -316,8 +315,10 @@ hipError_t launch_terminal(hipStream_t st, double* part, int* nblk_out, int mode
         else hipLaunchKernelGGL((terminal_kernel<0, false>), grid, block, 0, st, a);
     } else if (scheme == 0) {
         hipLaunchKernelGGL((terminal_kernel<1, true>), grid, block, 0, st, a);
-    } else {
+    } else if (scheme == 1) {
         hipLaunchKernelGGL((terminal_kernel<2, true>), grid, block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL((terminal_kernel<3, true>), grid, block, 0, st, a);
     }
     return hipGetLastError();
 }

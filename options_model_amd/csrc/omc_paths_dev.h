@@ -25,7 +25,8 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
 // lays it out).  !ANTI: P independent paths, one column each.
 struct HestonC {
     float dtf, kdt, theta, xi, rho, rho2, rdt_l2, hdt_l2, l2e;
-    float sqdt, rdt, xi_sqdt;  // calibrator scheme: sqrt(dt), r*dt, xi*sqrt(dt)
+    float sqdt, rdt, xi_sqdt;  // sqrt(dt), r*dt, xi*sqrt(dt)
+    float l2e_sqdt;            // log2(e)*sqrt(dt)
 };
 
 // one argument block for both generators (Heston ignores a/b, GBM ignores v_init/hc)
@@ -82,30 +83,52 @@ __device__ __forceinline__ void gbm_paths_body(const PathArgs& g)
 }
 
 // ------------------------------------------------------------------ Heston
-// one Euler step; the operation order is part of the numerics contract that the
-// test-side CPU restatement follows as well
+// One Euler step of an ANTITHETIC PAIR (normals (z1, z2) and (-z1, -z2)); the operation order is part
+// of the numerics contract that the test-side CPU restatement follows as well.  What the
+// two partners share is computed once: w2 = rho z1 + rho2 z2, tw = xi sqrt(dt) w2, az = log2(e) sqrt(dt) z1
+// -- the partner's are their exact negations -- so a path costs max, sqrt, sub, 4 fma, exp2, mul (, max).
 template <int SCHEME>
-__device__ __forceinline__ void heston_step(const HestonC& c, float z1, float z2, float& s, float& v)
+__device__ __forceinline__ void heston_path_step(const HestonC& c, float tw, float az, float& s, float& v)
+{
+    const float vp = fmaxf(v, 0.0f);
+    const float sq = __builtin_amdgcn_sqrtf(vp);
+    const float base = SCHEME ? v : vp;
+    const float vn = __builtin_fmaf(sq, tw, __builtin_fmaf(c.kdt, c.theta - vp, base));
+    const float arg = __builtin_fmaf(sq, az, __builtin_fmaf(-c.hdt_l2, vp, c.rdt_l2));
+    s = s * fast_exp2(arg);
+    v = SCHEME ? vn : fmaxf(vn, 0.0f);
+}
+
+template <int SCHEME>
+__device__ __forceinline__ void heston_pair_step(const HestonC& c, float z1, float z2, float& s, float& v,
+                                                 float& sa, float& vb)
 {
     if constexpr (SCHEME == 2) {
         // The calibrator's own scheme (heston_calibration.py:242-255): variance floored at 1e-8
         // before use and at store, ARITHMETIC Euler for S (S may cross zero; so be it).
-        const float vp = fmaxf(v, 1e-8f);
-        const float sq = __builtin_amdgcn_sqrtf(vp);
         const float w2 = __builtin_fmaf(c.rho, z1, c.rho2 * z2);
-        const float vn = __builtin_fmaf(c.xi_sqdt * sq, w2, __builtin_fmaf(c.kdt, c.theta - vp, vp));
-        s = __builtin_fmaf(s, __builtin_fmaf(sq * c.sqdt, z1, c.rdt), s);
-        v = fmaxf(vn, 1e-8f);
+        {
+            const float vp = fmaxf(v, 1e-8f);
+            const float sq = __builtin_amdgcn_sqrtf(vp);
+            const float vn = __builtin_fmaf(c.xi_sqdt * sq, w2, __builtin_fmaf(c.kdt, c.theta - vp, vp));
+            s = __builtin_fmaf(s, __builtin_fmaf(sq * c.sqdt, z1, c.rdt), s);
+            v = fmaxf(vn, 1e-8f);
+        }
+        {
+            const float vp = fmaxf(vb, 1e-8f);
+            const float sq = __builtin_amdgcn_sqrtf(vp);
+            const float vn = __builtin_fmaf(c.xi_sqdt * sq, -w2, __builtin_fmaf(c.kdt, c.theta - vp, vp));
+            sa = __builtin_fmaf(sa, __builtin_fmaf(sq * c.sqdt, -z1, c.rdt), sa);
+            vb = fmaxf(vn, 1e-8f);
+        }
         return;
+    } else {
+        const float w2 = __builtin_fmaf(c.rho, z1, c.rho2 * z2);
+        const float tw = c.xi_sqdt * w2;
+        const float az = c.l2e_sqdt * z1;
+        heston_path_step<SCHEME>(c, tw, az, s, v);
+        heston_path_step<SCHEME>(c, -tw, -az, sa, vb);
     }
-    const float vp = fmaxf(v, 0.0f);
-    const float sq = __builtin_amdgcn_sqrtf(vp * c.dtf);
-    const float w2 = __builtin_fmaf(c.rho, z1, c.rho2 * z2);
-    const float base = SCHEME ? v : vp;
-    const float vn = __builtin_fmaf(c.xi * sq, w2, __builtin_fmaf(c.kdt, c.theta - vp, base));
-    const float arg = __builtin_fmaf(sq * c.l2e, z1, __builtin_fmaf(-c.hdt_l2, vp, c.rdt_l2));
-    s = s * fast_exp2(arg);
-    v = SCHEME ? vn : fmaxf(vn, 0.0f);
 }
 
 // One Philox block per pair per TWO steps: words (0,1) -> (z1,z2) of the odd step,
@@ -143,10 +166,8 @@ __device__ __forceinline__ void heston_paths_body(const PathArgs& g)
             if (++t > n_steps) break;
             row += ld;
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                heston_step<SCHEME>(c, z[v][2 * i], z[v][2 * i + 1], s[v], va[v]);
-                heston_step<SCHEME>(c, -z[v][2 * i], -z[v][2 * i + 1], sa[v], vb[v]);
-            }
+            for (int v = 0; v < VEC; ++v)
+                heston_pair_step<SCHEME>(c, z[v][2 * i], z[v][2 * i + 1], s[v], va[v], sa[v], vb[v]);
             store_vec<VEC>(row, s);
             store_vec<VEC>(row + P, sa);
         }
@@ -178,7 +199,7 @@ __device__ __forceinline__ void add_payoff(double (&acc)[8], float s, double K, 
     acc[3] += (p == 0.0) ? 1.0 : 0.0;
 }
 
-// MODEL 0 GBM (ANTI selectable), MODEL 1/2 Heston scheme 0/1 (always antithetic)
+// MODEL 0 GBM (ANTI selectable), MODEL 1/2/3 Heston scheme 0/1/2 (always antithetic)
 template <int MODEL, bool ANTI>
 __device__ __forceinline__ void terminal_body(const TermArgs& a)
 {
@@ -202,8 +223,7 @@ __device__ __forceinline__ void terminal_body(const TermArgs& a)
                 const int i = t & 1;
                 if (i == 0)
                     normals4(a.pair_offset + (uint64_t)p, (uint32_t)(t >> 1), a.stream, a.k0, a.k1, z);
-                heston_step<MODEL - 1>(a.hc, z[2 * i], z[2 * i + 1], s, va);
-                heston_step<MODEL - 1>(a.hc, -z[2 * i], -z[2 * i + 1], sa, vb);
+                heston_pair_step<MODEL - 1>(a.hc, z[2 * i], z[2 * i + 1], s, va, sa, vb);
             }
         }
         add_payoff(acc, s, a.K, a.is_put, a.df);

@@ -1,5 +1,6 @@
-"""Path sharding across the GPUs of one node: one process per GPU, torch.distributed
-(backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+"""Path sharding across the GPUs of one node: one process per GPU.  Two transports for the two
+tiny exchanges below: RcclPricer (RCCL called from inside libomc.so, no torch) and ShardedPricer
+(torch.distributed: backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests).
 
 The reference has no distributed code at all (its only parallelism is a ProcessPoolExecutor
 over S0 values, options_model_3.py:1053).  Paths are independent, so they shard by antithetic
@@ -14,6 +15,7 @@ the price -- does not depend on the number of shards.  Only two things cross GPU
 from __future__ import annotations
 
 import math
+import time
 
 
 def shard(n_paths_global: int, world: int, rank: int, antithetic: bool = True):
@@ -52,8 +54,109 @@ class _DevPtr:
                                          "version": 2}
 
 
-class ShardedPricer:
-    """One per rank.  Requires torch.distributed to be initialised (nccl) and a GPU."""
+class _ShardedBase:
+    """Shared by the two transports: shard the global problem, price the local shard through a
+    context whose library calls already return GLOBAL sums (hook or native communicator)."""
+
+    ctx = None
+    rank = 0
+    world = 1
+    _ffi = None
+
+    def _enter(self):  # context manager around library calls (torch transport: current stream)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def price_american(self, n_paths_global: int, **kw) -> dict:
+        """kw: arguments of _ffi.make_params except n_paths / pair_offset."""
+        anti = kw.get("antithetic", True)
+        n_local, off = shard(n_paths_global, self.world, self.rank, anti)
+        p = self._ffi.make_params(n_paths=n_local, pair_offset=off, **kw)
+        with self._enter():
+            res = self.ctx.price_american(p)
+        # with world > 1 the sums in `res` are global already
+        out = merge(res, lambda v: v)
+        out["local"] = res
+        return out
+
+    def price_american_seq(self, n_paths_global: int, streams, **kw) -> list:
+        """len(streams) pricings (one Philox stream id each) enqueued back to back, one wait at the end;
+        the all-reduces are stream-ordered, so no rank waits on the host in between."""
+        anti = kw.get("antithetic", True)
+        n_local, off = shard(n_paths_global, self.world, self.rank, anti)
+        ps = [self._ffi.make_params(n_paths=n_local, pair_offset=off, stream=int(s), **kw) for s in streams]
+        with self._enter():
+            res = self.ctx.price_american_seq(ps)
+        outs = []
+        for r in res:
+            out = merge(r, lambda v: v)
+            out["local"] = r
+            outs.append(out)
+        return outs
+
+    def close(self):
+        self.ctx.close()
+
+
+class RcclPricer(_ShardedBase):
+    """One per rank, NO torch: the library owns an RCCL communicator (omc_comm_init) and enqueues its
+    all-reduces itself.  The unique id travels from rank 0 through options_model_amd.rendezvous."""
+
+    transport = "rccl-native"
+
+    def __init__(self, local_rank: int, rank: int, world: int, tag: str | None = None, timeout_s: float = 120.0):
+        from . import _ffi, rendezvous
+
+        self._ffi = _ffi
+        self.rank, self.world = int(rank), int(world)
+        self.ctx = _ffi.Context(local_rank)
+        marker = b"OMC_RCCL_UNAVAILABLE"
+        failure = []
+
+        def make_uid():  # rank 0; a failure is published too, so that the other ranks do not wait for it
+            try:
+                return _ffi.comm_unique_id()
+            except Exception as e:
+                failure.append(e)
+                return marker.ljust(128, b"\0")
+
+        uid, path = rendezvous.exchange(self.rank, make_uid, 128, tag, timeout_s)
+        if uid.startswith(marker):
+            if path:
+                time.sleep(0.5)  # let the other ranks read the marker
+                rendezvous.retire(path)
+            self.ctx.close()
+            raise RuntimeError(f"RCCL unique id unavailable on rank 0: {failure[0] if failure else 'see rank 0'}")
+        try:
+            self.ctx.comm_init(self.rank, self.world, uid)  # collective
+        finally:
+            if path:
+                rendezvous.retire(path)
+        r, w = self.ctx.comm_info()
+        if (r, w) != (self.rank, self.world):
+            raise RuntimeError(f"RCCL communicator reports rank {r} of {w}, expected {self.rank} of {self.world}")
+
+    def comm_ranks(self) -> int:
+        return self.ctx.comm_info()[1]
+
+    def barrier(self):
+        self.ctx.comm_allreduce([0.0])
+
+    def allreduce_max(self, x: float) -> float:
+        return float(self.ctx.comm_allreduce([x], "max")[0])
+
+    def close(self):
+        try:
+            self.ctx.comm_destroy()
+        finally:
+            self.ctx.close()
+
+
+class ShardedPricer(_ShardedBase):
+    """One per rank over torch.distributed (nccl == RCCL, or gloo for CPU-side rehearsals): the library
+    calls back into Python for its all-reduces (omc_set_allreduce_hook)."""
+
+    transport = "torch.distributed"
 
     def __init__(self, local_rank: int, group=None, force_hook: bool = False):
         import torch
@@ -79,6 +182,9 @@ class ShardedPricer:
             self.ctx.set_allreduce_hook(self._allreduce_device)
             self.ctx.set_option("world_size", self.world)
 
+    def _enter(self):
+        return self.torch.cuda.stream(self.stream)  # the hook's all_reduce sees this stream as current
+
     def _allreduce_device(self, dptr: int, count: int):
         t = self._alias.get((dptr, count))
         if t is None:  # workspace pointers are stable across pricings of one size
@@ -86,32 +192,14 @@ class ShardedPricer:
             self._alias[(dptr, count)] = t
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
-    def price_american(self, n_paths_global: int, **kw) -> dict:
-        """kw: arguments of _ffi.make_params except n_paths / pair_offset."""
-        anti = kw.get("antithetic", True)
-        n_local, off = shard(n_paths_global, self.world, self.rank, anti)
-        p = self._ffi.make_params(n_paths=n_local, pair_offset=off, **kw)
-        with self.torch.cuda.stream(self.stream):  # the hook's all_reduce sees this stream as current
-            res = self.ctx.price_american(p)
-        # with world > 1 the sums in `res` are global already (see __init__)
-        out = merge(res, lambda v: v)
-        out["local"] = res
-        return out
+    def comm_ranks(self) -> int:
+        return self.dist.get_world_size(self.group)
 
-    def price_american_seq(self, n_paths_global: int, streams, **kw) -> list:
-        """len(streams) pricings (one Philox stream id each) enqueued back to back, one wait at the end;
-        the hook's all-reduces are stream-ordered, so no rank waits on the host in between."""
-        anti = kw.get("antithetic", True)
-        n_local, off = shard(n_paths_global, self.world, self.rank, anti)
-        ps = [self._ffi.make_params(n_paths=n_local, pair_offset=off, stream=int(s), **kw) for s in streams]
-        with self.torch.cuda.stream(self.stream):
-            res = self.ctx.price_american_seq(ps)
-        outs = []
-        for r in res:
-            out = merge(r, lambda v: v)
-            out["local"] = r
-            outs.append(out)
-        return outs
+    def barrier(self):
+        self.dist.barrier(self.group)
 
-    def close(self):
-        self.ctx.close()
+    def allreduce_max(self, x: float) -> float:
+        dev = self.device if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())

@@ -554,6 +554,6 @@ def price_american_option_nn(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", 
                        zero_prob=out.get("zero_prob", 0.0), n_paths=M,
                        n_exercised=out.get("n_exercised", 0), sum_nitm=out.get("R", 0), model=model_l,
                        semantics="two_pass", option_type=option_type,
-                       timings_ms={k: 1e3 * v for k, v in out.items() if k.startswith("seconds_")},
+                       timings_ms={k[len("seconds_"):]: 1e3 * v for k, v in out.items() if k.startswith("seconds_")},
                        info={k: out[k] for k in ("trainer", "pass2", "rows", "batch", "epochs_run", "optimizer_steps",
                                                  "best_loss", "graphed") if k in out})

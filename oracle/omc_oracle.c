@@ -152,7 +152,8 @@ void orc_gbm_paths_from_normals_f32(float *S, int64_t ld, int64_t n_paths, int n
 /* ---------------------------------------------------------------- Heston paths */
 typedef struct {
     float dtf, kdt, theta, xi, rho, rho2, rdt_l2, hdt_l2, l2e;
-    float sqdt, rdt, xi_sqdt; /* scheme 2 (calibrator): sqrt(dt), r*dt, xi*sqrt(dt) */
+    float sqdt, rdt, xi_sqdt; /* sqrt(dt), r*dt, xi*sqrt(dt) */
+    float l2e_sqdt;           /* log2(e)*sqrt(dt) */
 } heston_consts;
 
 static heston_consts heston_make(double r, double T, int n_steps, double kappa, double theta,
@@ -172,6 +173,7 @@ static heston_consts heston_make(double r, double T, int n_steps, double kappa, 
     c.sqdt = (float)sqrt(dt);
     c.rdt = (float)(r * dt);
     c.xi_sqdt = (float)(xi * sqrt(dt));
+    c.l2e_sqdt = (float)(L2E * sqrt(dt));
     return c;
 }
 
@@ -189,12 +191,17 @@ static inline void heston_step(const heston_consts *c, int scheme, float z1, flo
         *v = fmaxf(vn, 1e-8f);
         return;
     }
+    /* float32 operation order shared with the HIP kernels (heston_pair_step): the pair-level
+     * products tw = xi sqrt(dt) w2 and az = log2(e) sqrt(dt) z1 first (the antithetic partner's are
+     * their exact negations, which calling this with (-z1, -z2) reproduces bit for bit), then per path */
     float vp = fmaxf(*v, 0.0f);
-    float sq = sqrtf(vp * c->dtf);
+    float sq = sqrtf(vp);
     float w2 = fmaf(c->rho, z1, c->rho2 * z2);
+    float tw = c->xi_sqdt * w2;
+    float az = c->l2e_sqdt * z1;
     float base = scheme ? *v : vp;
-    float vn = fmaf(c->xi * sq, w2, fmaf(c->kdt, c->theta - vp, base));
-    float arg = fmaf(sq * c->l2e, z1, fmaf(-c->hdt_l2, vp, c->rdt_l2));
+    float vn = fmaf(sq, tw, fmaf(c->kdt, c->theta - vp, base));
+    float arg = fmaf(sq, az, fmaf(-c->hdt_l2, vp, c->rdt_l2));
     *s = *s * exp2f_ref(arg);
     *v = scheme ? vn : fmaxf(vn, 0.0f);
 }

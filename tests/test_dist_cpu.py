@@ -93,3 +93,78 @@ def test_merge_statistics():
     assert out["price"] == 2.5 and out["n_paths"] == 8 and out["n_exercised"] == 2
     assert out["std"] == pytest.approx(np.sqrt(60 / 8 - 2.5**2))
     assert out["zero_prob"] == 0.5 and out["sum_nitm"] == 14
+
+
+# ------------------------------------------------------------------ RCCL unique-id rendezvous (no torch)
+def _rdzv_worker(rank, tag, q):
+    from options_model_amd import rendezvous
+    payload, path = rendezvous.exchange(rank, lambda: bytes(range(128)), 128, tag, timeout_s=30.0)
+    q.put((rank, payload, path))
+
+
+def test_unique_id_rendezvous_two_processes(tmp_path, monkeypatch):
+    """Rank 0 publishes the 128-byte id, rank 1 (started FIRST, so it has to wait) receives exactly it;
+    the file goes away when rank 0 retires it.  This is the gloo-free exchange bench.py's native RCCL
+    transport uses (options_model_amd/rendezvous.py)."""
+    import multiprocessing as mp
+
+    from options_model_amd import rendezvous
+    monkeypatch.setenv("OMC_RDZV_DIR", str(tmp_path))
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    tag = f"t{os.getpid()}"
+    p1 = ctxm.Process(target=_rdzv_worker, args=(1, tag, q))
+    p1.start()
+    p0 = ctxm.Process(target=_rdzv_worker, args=(0, tag, q))
+    p0.start()
+    got = dict()
+    for _ in range(2):
+        r, payload, path = q.get(timeout=60)
+        got[r] = (payload, path)
+    p0.join(30)
+    p1.join(30)
+    assert got[0][0] == got[1][0] == bytes(range(128))
+    assert got[1][1] is None and os.path.exists(got[0][1])
+    rendezvous.retire(got[0][1])
+    assert not os.path.exists(got[0][1])
+    rendezvous.retire(got[0][1])  # idempotent
+
+
+def test_rendezvous_times_out_instead_of_hanging(tmp_path, monkeypatch):
+    from options_model_amd import rendezvous
+    monkeypatch.setenv("OMC_RDZV_DIR", str(tmp_path))
+    with pytest.raises(TimeoutError):
+        rendezvous.fetch(128, tag="nobody", timeout_s=0.2)
+    # a half-written file (wrong size) is not accepted either
+    open(os.path.join(str(tmp_path), "omc_rccl_uid_short"), "wb").write(b"x" * 10)
+    with pytest.raises(TimeoutError):
+        rendezvous.fetch(128, tag="short", timeout_s=0.2)
+
+
+# ------------------------------------------------------------------ bench.py --gpus N launcher
+def test_bench_launcher_starts_n_ranks_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 rank processes itself (round 1
+    ignored --gpus).  In this container there is no GPU, so both ranks must refuse to run -- and the
+    parent must report that with a non-zero exit code, not print a 1-rank line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box: no device for this check
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0
+    assert out.stdout.strip() == ""  # no JSON line from a failed job
+    assert "rank" in out.stderr and "stopping the other ranks" in out.stderr
+    assert out.stderr.count("needs a GPU") >= 1
+
+
+def test_bench_world_size_must_match_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                         capture_output=True, text=True, timeout=120, cwd=root)
+    assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr

@@ -89,6 +89,8 @@ def test_two_shard_emulation_equals_unsharded(tctx, ctx):
     assert merged["n_paths"] == M
     assert merged["price"] == pytest.approx(full["price"], rel=1e-12)
     assert merged["n_exercised"] == full["n_exercised"] and merged["n_zero"] == full["n_zero"]
+    # each emulated rank saw the GLOBAL moment table: its regression-set total is the unsharded one
+    assert a["sum_nitm"] == full["sum_nitm"] and b["sum_nitm"] == full["sum_nitm"]
 
 
 def test_world_size_normalisation_with_doubling_hook(tctx, ctx):
@@ -111,6 +113,9 @@ def test_world_size_normalisation_with_doubling_hook(tctx, ctx):
         c.set_allreduce_hook(None)
         c.set_option("world_size", 1)
         assert out["n_paths"] == 60000 and out["n_exercised"] == 2 * base["n_exercised"]
+        # the regression-set sizes come from the moment table, which is global on every rank BEFORE the
+        # result sums are all-reduced: they must come out once per rank, not world_size times each
+        assert out["sum_nitm"] == 2 * base["sum_nitm"]
         assert out["price"] == pytest.approx(base["price"], rel=1e-12)
         assert out["std"] == pytest.approx(base["std"], rel=1e-9)
 
@@ -172,3 +177,86 @@ def test_two_ranks_through_bench_equal_the_unsharded_price(ctx, tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "path-sharded x2"
     ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=200000, n_steps=50, seed=42, stream=1))
     assert d["price"] == pytest.approx(ref["price"], rel=1e-10)
+
+
+def _bench_json(cmd, root, timeout=420):
+    import json
+    import os
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # the contract: ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_its_own_ranks(ctx):
+    """`python bench.py --gpus 2` WITHOUT torchrun: bench.py itself starts two rank processes (before any
+    GPU call in the parent), they form a 2-rank group (gloo here, both on this one GPU) and the sharded
+    pricing equals the unsharded 2x-path problem."""
+    import os
+    import sys
+    from options_model_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                     "--paths-per-gpu", "100000", "--n-steps", "50", "--backend", "gloo", "--single-device",
+                     "--no-variants", "--no-cpu-baseline", "--no-sustained"], root)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["parallelism"] == "path-sharded x2"
+    ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=200000, n_steps=50, seed=42, stream=1))
+    assert d["price"] == pytest.approx(ref["price"], rel=1e-10)
+    assert d["price_check"]["rel_err"] < 1e-3 and d["price_check"]["same_stream"]
+    # the per-step flow went through the 2-rank exchange too
+    ref2 = ctx.price_american(_ffi.make_params(semantics="reference", n_paths=200000, n_steps=50, seed=42, stream=4))
+    assert d["roofline_per_step"]["price"] == pytest.approx(ref2["price"], rel=1e-10)
+
+
+def test_bench_gpus_mismatch_fails_loudly():
+    """--gpus must equal the launcher's world size: a silent single-rank run is what round 1 did."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=120, cwd=root)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_native_rccl_communicator_world_size_one(ctx):
+    """omc_comm_init / ncclAllReduce from inside libomc.so (no torch.distributed): with one rank every
+    all-reduce is the identity, so each flow must reproduce the plain pricing -- through the external-
+    moments code path and real RCCL calls on the library's own stream and buffers."""
+    from options_model_amd import _ffi
+    from options_model_amd import dist as omc_dist
+    sp = omc_dist.RcclPricer(0, 0, 1, tag=f"pytest_{__import__('os').getpid()}")
+    try:
+        assert sp.ctx.comm_info() == (0, 1) and sp.comm_ranks() == 1
+        assert sp.allreduce_max(3.5) == 3.5
+        sp.barrier()
+        for sem in ("two_pass", "reference", "textbook"):
+            out = sp.price_american(20_000, semantics=sem, n_steps=12, seed=4)
+            base = ctx.price_american(_ffi.make_params(semantics=sem, n_paths=20_000, n_steps=12, seed=4))
+            assert out["price"] == pytest.approx(base["price"], rel=1e-12)
+            assert (out["n_exercised"], out["n_zero"], out["sum_nitm"]) == (
+                base["n_exercised"], base["n_zero"], base["sum_nitm"])
+        outs = sp.price_american_seq(20_000, [1, 2, 3], semantics="two_pass", n_steps=12, seed=4)
+        for s, o in zip((1, 2, 3), outs):
+            base = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=20_000, n_steps=12, seed=4,
+                                                       stream=s))
+            assert o["price"] == pytest.approx(base["price"], rel=1e-12)
+    finally:
+        sp.close()
+
+
+def test_bench_force_dist_uses_native_rccl():
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                     "--paths-per-gpu", "100000", "--n-steps", "50", "--force-dist", "--no-variants",
+                     "--no-cpu-baseline", "--no-sustained"], root)
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["comm"].startswith("rccl-native")
+    assert d["price_check"]["rel_err"] < 1e-3

@@ -1,0 +1,79 @@
+#!/bin/bash
+# Round-2 GPU steps, one per gpurun call (a call is capped at 20 minutes):
+#   bash tools/gpu_r02.sh tests TAG      GPU parity tests + smoke
+#   bash tools/gpu_r02.sh sweep TAG      instruction-rate microbenchmarks + kernel experiment sweeps
+#   bash tools/gpu_r02.sh bench TAG      bench.py default line + rocprofv3 kernel traces (+ per-config lines)
+#   bash tools/gpu_r02.sh pmc TAG        PMC passes (HBM traffic, SQ counters)
+# A step killed by its timeout stops the chain (no further GPU work after a hang).
+set -u
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+WHAT=${1:-tests}
+TAG=${2:-r02}
+R="$GRAFT_REPO_ROOT"
+ok() { [ "$1" -ne 124 ] && [ "$1" -ne 137 ]; }
+
+case "$WHAT" in
+tests)
+  timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/gpu_tests_$TAG.log 2>&1; rc=$?
+  echo "pytest exit=$rc" | tee -a gpurun_out/gpu_tests_$TAG.log
+  tail -15 gpurun_out/gpu_tests_$TAG.log
+  ok $rc || exit 1
+  [ $rc -eq 0 ] || exit $rc
+  timeout -k 10 300 python __graft_entry__.py --smoke > gpurun_out/smoke_$TAG.log 2>&1; rc=$?
+  echo "smoke exit=$rc"; tail -6 gpurun_out/smoke_$TAG.log
+  ;;
+sweep)
+  timeout -k 10 200 tools/_ubench > gpurun_out/ubench_$TAG.txt 2>&1; rc=$?
+  echo "ubench exit=$rc"; cat gpurun_out/ubench_$TAG.txt
+  ok $rc || exit 1
+  for W in ${3:-step pass1 heston}; do
+    timeout -k 10 400 python tools/r02_sweep.py $W > gpurun_out/sweep_${W}_$TAG.jsonl 2> gpurun_out/sweep_${W}_$TAG.err; rc=$?
+    echo "sweep $W exit=$rc"
+    python - "$R/gpurun_out/sweep_${W}_$TAG.jsonl" <<'PY'
+import json, sys
+for ln in open(sys.argv[1]):
+    d = json.loads(ln)
+    if "error" in d:
+        print("ERR", d["spec"], d["error"][-300:]); continue
+    s = d["spec"]
+    print(f"{s['sem']:9s} {s.get('model','gbm'):6s} M={s['M']:>8d} opt={s.get('options',{})} env={d['env']} wall={d['ms_wall']:.3f} "
+          f"paths={d['ms_paths']:.3f} lsm={d['ms_lsm_avg']:.3f} p1={d['ms_pass1']:.3f} p2={d['ms_pass2']:.3f} price={d['price']:.6f}")
+PY
+    ok $rc || exit 1
+  done
+  ;;
+bench)
+  timeout -k 10 500 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; rc=$?
+  echo "bench exit=$rc"; cat gpurun_out/bench_$TAG.json; tail -3 gpurun_out/bench_$TAG.err
+  ok $rc || exit 1
+  cd /tmp && export TMPDIR=/tmp
+  for SEM in two_pass reference; do
+    OUT="$R/gpurun_out/prof_${TAG}_$SEM"
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- \
+        python "$R/bench.py" --steps 10 --warmup 2 --semantics $SEM --no-cpu-baseline --no-variants --no-sustained \
+        > "$R/gpurun_out/bench_prof_${TAG}_$SEM.json" 2> "$R/gpurun_out/prof_${TAG}_$SEM.err"; rc=$?
+    echo "rocprof $SEM exit=$rc"
+    ok $rc || exit 1
+    find "$OUT" -name "*kernel_stats.csv" | head -1 | xargs -r head -12
+  done
+  OUT="$R/gpurun_out/prof_${TAG}_c4"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- \
+      python "$R/bench.py" --config c4 --steps 5 --warmup 1 --no-cpu-baseline --no-variants --no-sustained \
+      > "$R/gpurun_out/bench_prof_${TAG}_c4.json" 2> "$R/gpurun_out/prof_${TAG}_c4.err"; rc=$?
+  echo "rocprof c4 exit=$rc"
+  find "$OUT" -name "*kernel_stats.csv" | head -1 | xargs -r head -8
+  ;;
+pmc)
+  cd /tmp && export TMPDIR=/tmp
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    OUT="$R/gpurun_out/pmc_${TAG}_$CTR"
+    timeout -k 10 300 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$OUT" -- \
+        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-sustained \
+        > /dev/null 2> "$R/gpurun_out/pmc_${TAG}_$CTR.err"; rc=$?
+    echo "pmc $CTR exit=$rc"
+    ok $rc || exit 1
+  done
+  python "$R/tools/summarize_pmc.py" "$R/gpurun_out" "$TAG" | tee "$R/gpurun_out/pmc_summary_$TAG.txt"
+  ;;
+esac

@@ -9,10 +9,24 @@
 
 constexpr int ITER = 4096;
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int MODE>
-__global__ __launch_bounds__(256) void rate_kernel(float* out, float seed)
+__global__ __launch_bounds__(256) void rate_kernel(float* out, float seed, unsigned long long* stamps)
 {
     const int tid = blockIdx.x * 256 + threadIdx.x;
+    // in-kernel clock: shader cycles (s_memtime) against the 100 MHz reference (s_memrealtime)
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    struct Stamp {
+        unsigned long long c0, r0, *dst;
+        bool on;
+        __device__ ~Stamp()
+        {
+            if (!on) return;
+            dst[0] = __builtin_amdgcn_s_memtime() - c0;
+            dst[1] = __builtin_amdgcn_s_memrealtime() - r0;
+        }
+    } stamp{c0, r0, stamps + 2 * blockIdx.x, threadIdx.x == 0};
     if constexpr (MODE == 0) {  // v_fma_f32
         float a[8];
         for (int i = 0; i < 8; ++i) a[i] = seed + i + tid;
@@ -88,6 +102,41 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed)
             }
         for (int i = 0; i < 8; ++i) acc += a[i];
         out[tid] = (float)acc;
+    } else if constexpr (MODE == 7) {  // v_pk_fma_f32: two float32 FMAs per lane and instruction
+        f2 a[8];
+        for (int i = 0; i < 8; ++i) a[i] = f2{seed + i + tid, seed - i};
+        const f2 m{1.000001f, 0.999999f}, c{0.5f, 0.25f};
+        for (int it = 0; it < ITER; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(a[i], m, c);
+        float s = 0;
+        for (int i = 0; i < 8; ++i) s += a[i].x + a[i].y;
+        out[tid] = s;
+    } else if constexpr (MODE == 8) {  // v_cndmask_b32 pair (64-bit select) + v_cmp
+        double a[8];
+        for (int i = 0; i < 8; ++i) a[i] = seed + i + tid;
+        for (int it = 0; it < ITER; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a[i] = (a[i] > 3.0) ? a[i] * 0.5 : 7.0;
+            }
+        double s = 0;
+        for (int i = 0; i < 8; ++i) s += a[i];
+        out[tid] = (float)s;
+    } else if constexpr (MODE == 9) {  // v_sqrt_f32 / v_log_f32 / v_sin_f32 / v_cos_f32 mix (Box-Muller's four)
+        float a[8];
+        for (int i = 0; i < 8; ++i) a[i] = 0.3f + 1e-3f * i;
+        for (int it = 0; it < ITER; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; i += 4) {
+                a[i] = __builtin_amdgcn_sqrtf(a[i]) + 0.1f;
+                a[i + 1] = __builtin_amdgcn_logf(a[i + 1]) + 2.0f;
+                a[i + 2] = __builtin_amdgcn_sinf(a[i + 2]) + 0.5f;
+                a[i + 3] = __builtin_amdgcn_cosf(a[i + 3]) + 0.5f;
+            }
+        float s = 0;
+        for (int i = 0; i < 8; ++i) s += a[i];
+        out[tid] = s;
     }
 }
 
@@ -95,22 +144,32 @@ template <int MODE>
 static void run(const char* name, double ops_per_iter)
 {
     float* out;
+    unsigned long long* stamps;
     hipMalloc(&out, sizeof(float) * 256 * 2048);
+    hipMalloc(&stamps, sizeof(unsigned long long) * 2 * 2048);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(2048), dim3(256), 0, 0, out, 1.0f);
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(2048), dim3(256), 0, 0, out, 1.0f, stamps);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(2048), dim3(256), 0, 0, out, 1.0f);
+    for (int rep = 0; rep < 20; ++rep)  // ~100 ms of back-to-back launches: the clock has settled
+        hipLaunchKernelGGL(rate_kernel<MODE>, dim3(2048), dim3(256), 0, 0, out, 1.0f, stamps);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
+    ms /= 20.0f;
+    static unsigned long long h[2 * 2048];
+    hipMemcpy(h, stamps, sizeof h, hipMemcpyDeviceToHost);
+    double ghz = 0;
+    for (int b = 0; b < 2048; ++b) ghz += (double)h[2 * b] / (double)h[2 * b + 1] * 0.1;
+    ghz /= 2048;
     // 2048 blocks x 4 waves = 8192 waves over 1024 SIMDs = 8 waves per SIMD
     const double wave_instr_per_simd = 8.0 * ITER * ops_per_iter;
-    printf("%-28s %8.3f ms   %6.2f ns per wave-instruction per SIMD  (= %.1f cycles at 2.4 GHz)\n", name,
-           ms, ms * 1e6 / wave_instr_per_simd, ms * 1e6 / wave_instr_per_simd * 2.4);
+    printf("%-28s %8.3f ms   %6.2f ns per wave-instruction per SIMD  (= %.1f cycles at the in-kernel clock of %.2f GHz)\n",
+           name, ms, ms * 1e6 / wave_instr_per_simd, ms * 1e6 / wave_instr_per_simd * ghz, ghz);
     hipFree(out);
+    hipFree(stamps);
 }
 
 int main()
@@ -122,5 +181,8 @@ int main()
     run<4>("v_mul_hi_u32+v_mul_lo_u32", 16);
     run<5>("v_exp_f32 (+mul)", 8);
     run<6>("v_cvt_f64_f32+cvt_f32_f64", 16);
+    run<7>("v_pk_fma_f32", 8);
+    run<8>("f64 cmp+mul+2 cndmask", 32);
+    run<9>("sqrt/log/sin/cos f32 (+add)", 16);
     return 0;
 }
