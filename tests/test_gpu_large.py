@@ -101,7 +101,7 @@ def test_config4_size_heston_put_real_decisions_and_idempotence(ctx):
     properties: (1) every flow exercises a large share of paths and prices above the European value on
     the same paths; (2) idempotence: replaying the two-pass fits through omc_lsm_apply_frozen returns the
     identical state and sums; (3) the per-step flow through the captured graph and kernel by kernel
-    agree bit for bit; (4) two 2M-path shards with exchanged moments equal the 4M run."""
+    agree bit for bit; (4) the adapted (textbook) rule prices below the reference's look-ahead flows."""
     from options_model_amd import _ffi
     M, N = 4_000_000, 252
     S = ctx.heston_paths(M, N, 100.0, 0.05, 1.0, seed=77, stream=3, scheme=1, **HP)
