@@ -3,6 +3,14 @@
 
 Same per-step sticky flow as v1; Heston paths are antithetic here (v2's simulator is not,
 options_model_2.py:150-170) -- a variance reduction, not a change of distribution.
+
+Regressor: the reference fits a fresh ContNet(1 -> nn_hidden -> nn_hidden -> 1) per time step with
+nn_epochs full-batch Adam steps from a random initialisation (options_model_2.py:291-301) -- a barely
+trained network whose output the price inherits.  Here every step solves OLS on [1, u, u^2] instead
+(BASELINE.json's "polynomial LSM"; the reference accepts lsm_poly_degree and ignores it, :178-179), so
+nn_hidden / nn_epochs / nn_lr are accepted for signature compatibility and have NO effect: this is
+logged once per process, and stated in INTEGRATION.md.  The reference's mask / discount / strict-'>' /
+statistics logic is pinned to recorded runs of this very class (tests/golden/per_step_ref.npz).
 """
 from __future__ import annotations
 
@@ -14,6 +22,9 @@ from .. import _ffi
 from ..api import heston_defaults
 
 
+_told = False
+
+
 class OptionPricer:
     def __init__(self, K: float, r: float, sigma: Optional[float], option_type: str = "call",
                  lsm_poly_degree: int = 2, seed: int = 42, use_heston: bool = False,
@@ -23,7 +34,14 @@ class OptionPricer:
         self.lsm_poly_degree, self.seed = lsm_poly_degree, seed
         self.use_heston, self.heston_params = use_heston, heston_params
         self.nn_hidden, self.nn_epochs, self.nn_lr, self.verbose = nn_hidden, nn_epochs, nn_lr, verbose
+        self.regressor = "poly"
         self.last_result: Optional[dict] = None
+        global _told
+        if not _told:
+            _told = True
+            logging.getLogger(__name__).info(
+                "options_model_amd.compat.options_model_2: the per-step ContNet regressor is replaced by OLS on "
+                "[1,u,u^2]; nn_hidden / nn_epochs / nn_lr have no effect")
 
     def price_american_option(self, S0: float, T: float, num_simulations: int = 10000,
                               num_time_steps: int = 50, plot_paths: bool = False) -> float:

@@ -13,8 +13,9 @@ What differs, by construction (DESIGN.md "Parity"):
   * normals come from Philox4x32-10 keyed by the child seed RNGManager hands out, not from
     numpy's PCG64 -- the master-seed draw sequence (two draws per LSM pricing, one per
     500-path European chunk) is kept so curves consume seeds exactly as the reference does;
-  * the continuation-value regressor is OLS on [1,u,u^2] per time step (regressor="poly");
-    regressor="nn" trains the reference's SingleLSMNet on the GPU (nn_regressor.py);
+  * the continuation-value regressor is the reference's: ONE SingleLSMNet trained on the pass-1 rows
+    (regressor="nn", the default; nn_regressor.py + the MFMA kernels of csrc/omc_mlp.hip);
+    regressor="poly" (OLS on [1,u,u^2] per time step, same control flow) is the explicit fast option;
   * iv_model: pass an `options_model_amd.local_vol.IVModel` (same constructor contract as the
     reference's); paths are then simulated on the GPU through the IV network (local_vol.py).
 """
@@ -22,6 +23,8 @@ from __future__ import annotations
 
 import logging
 import math
+import os
+import warnings
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -115,8 +118,23 @@ class AdvancedOptionPricer:
                  european_approximation: bool = False, use_control_variate: bool = True,
                  # -- extensions (keyword-only in spirit; the GPU file adds nn_layers/nn_dropout
                  #    the same way, option_model_3_gpu.py:557-561)
-                 nn_layers: int = 3, nn_dropout: float = 0.10, regressor: str = "poly",
+                 nn_layers: int = 3, nn_dropout: float = 0.10, regressor: Optional[str] = None,
                  semantics: str = "two_pass", device: int = 0):
+        """Called with the reference's own arguments only, this prices the way the reference does:
+        ONE SingleLSMNet(7, nn_hidden, nn_layers) with dropout, trained on the pass-1 rows and applied
+        in the sticky pass 2 (options_model_3.py:482-651) -- regressor "nn", the default -- on the GPU
+        (hand-written MFMA trainer / pass-2 kernels for 64|128 units x 2|3 layers).  regressor="poly"
+        is the explicit fast option: OLS on [1,u,u^2] per time step in the same two-pass control flow
+        (the reference accepts lsm_poly_degree and never uses it).  The environment
+        variable OMC_REGRESSOR=poly|nn changes the default for callers that cannot pass the argument
+        (e.g. the Streamlit UI going through compute_curve_worker_enhanced)."""
+        if regressor is None:
+            regressor = os.environ.get("OMC_REGRESSOR", "nn").lower()
+        if regressor not in ("poly", "nn"):
+            raise ValueError("regressor must be 'poly' or 'nn'.")
+        if regressor == "poly" and (nn_hidden, nn_epochs, nn_lr, nn_layers, nn_dropout) != (128, 25, 1e-3, 3, 0.10):
+            warnings.warn("AdvancedOptionPricer(regressor='poly') ignores nn_hidden / nn_epochs / nn_lr / nn_layers / "
+                          "nn_dropout: the polynomial regressor has no network", stacklevel=2)
         self.K, self.r, self.sigma, self.option_type = K, r, sigma, option_type
         self.rng_manager = rng_manager or RNGManager()
         self.use_heston, self.heston_params = use_heston, heston_params

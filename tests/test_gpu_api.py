@@ -67,7 +67,7 @@ def test_advanced_pricer_consumes_master_seeds_like_reference(golden):
     from options_model_amd import AdvancedOptionPricer, RNGManager
     seeds = golden["scalars"]["rng_manager_42_child_seeds"]
     pricer = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put",
-                                  rng_manager=RNGManager(42), use_control_variate=False)
+                                  rng_manager=RNGManager(42), use_control_variate=False, regressor="poly")
     price = pricer.price_american_option(100.0, 1.0, 10000, 50)
     assert isinstance(price, float)
     # two master draws per LSM pricing (options_model_3.py:454-455): the next one is #3
@@ -80,9 +80,9 @@ def test_advanced_pricer_default_adds_bs_minus_european(golden):
     """default return = LSM + (Black-Scholes - independent European MC), SURVEY F10."""
     from options_model_amd import AdvancedOptionPricer, RNGManager
     seeds = golden["scalars"]["rng_manager_42_child_seeds"]
-    p_cv = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(42))
+    p_cv = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(42), regressor="poly")
     total = p_cv.price_american_option(100.0, 1.0, 2000, 20)
-    p_a = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(42), use_control_variate=False)
+    p_a = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(42), use_control_variate=False, regressor="poly")
     lsm = p_a.price_american_option(100.0, 1.0, 2000, 20)
     eur = p_a.price_european_streaming(100.0, 1.0, 2000, 20)  # continues the same master stream
     bs = rf.black_scholes_price(100, 100, 1, 0.05, 0.2, "put")
@@ -96,7 +96,7 @@ def test_advanced_pricer_default_adds_bs_minus_european(golden):
 def test_advanced_pricer_heston_and_errors():
     from options_model_amd import AdvancedOptionPricer, RNGManager
     p = AdvancedOptionPricer(100, 0.05, 0.2, "call", RNGManager(1), use_heston=True, heston_params=HP,
-                             use_control_variate=False)
+                             use_control_variate=False, regressor="poly")
     v = p.price_american_option(100.0, 1.0, 20000, 50)
     assert 9.0 < v < 13.0 and p.last_result["n_paths"] == 20000
     with pytest.raises(ValueError, match="S0, K, T must be positive"):
@@ -108,14 +108,36 @@ def test_advanced_pricer_heston_and_errors():
     assert abs(e.price_american_option(100.0, 1.0, 400_000, 10) - rf.black_scholes_price(100, 100, 1, .05, .2, "put")) < 0.05
 
 
-def test_curve_worker_records_and_never_raises():
+def test_curve_worker_records_and_never_raises(monkeypatch):
     from options_model_amd.pricer import compute_curve_worker_enhanced
+    monkeypatch.setenv("OMC_REGRESSOR", "poly")  # the worker has no regressor argument (reference signature)
     recs = compute_curve_worker_enhanced(100.0, 100.0, 0.05, 0.2, "put", 2025, 2, 6, 4000, False, False, None)
     assert len(recs) == 6
     assert set(recs[0]) == {"S0", "Days to Expiry", "Option Value"}
     assert [r["Days to Expiry"] for r in recs] == [3.0, 2.5, 2.0, 1.5, 1.0, 0.5]
     assert all(r["Option Value"] > 0 for r in recs)
     assert compute_curve_worker_enhanced(-5.0, 100.0, 0.05, 0.2, "put", 1, 2, 2, 100, False, False, None) == []
+
+
+def test_advanced_pricer_defaults_to_the_reference_regressor(golden):
+    """Constructed with the reference's own arguments only, the pricer does what the reference does:
+    one SingleLSMNet(7, 128, 3), dropout 0.1 (left on at inference), trained on the pass-1 rows --
+    and config 1 lands inside the band the reference itself spans across seeds
+    (tests/golden/scalars.json: 6.81 for RNGManager(42), 6.96-7.29 for seeds 1-3), far from what the
+    polynomial regressor returns (7.5).  The network trains in this library's kernels."""
+    from options_model_amd import AdvancedOptionPricer, RNGManager
+    p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(42),
+                             use_control_variate=False)
+    assert (p.regressor, p.nn_hidden, p.nn_layers, p.nn_dropout, p.nn_epochs) == ("nn", 128, 3, 0.10, 25)
+    price = p.price_american_option(100.0, 1.0, 10000, 50)
+    sc = golden["scalars"]
+    refs = [sc["end_to_end_10k_x_50_seed42"]["gbm_put_cv_off"]] + list(sc["reference_nn_seed_band"].values())
+    assert min(refs) - 0.3 < price < max(refs) + 0.3, (price, refs)
+    assert p.last_result["trainer"] == "hip" and p.last_result["R"] > 200_000
+    with pytest.warns(UserWarning, match="ignores nn_hidden"):
+        AdvancedOptionPricer(100, 0.05, 0.2, "put", regressor="poly", nn_hidden=64)
+    with pytest.raises(ValueError, match="regressor"):
+        AdvancedOptionPricer(100, 0.05, 0.2, "put", regressor="forest")
 
 
 # ---------------------------------------------------------------- v1 / v2 surfaces

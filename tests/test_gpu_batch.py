@@ -77,8 +77,8 @@ def test_v3_curve_batched_equals_point_by_point(ctx):
     calls, including the master-seed consumption and the default control-variate wrapper."""
     from options_model_amd import AdvancedOptionPricer, RNGManager
     for cv in (False, True):
-        a = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(2025), use_control_variate=cv)
-        b = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(2025), use_control_variate=cv)
+        a = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(2025), use_control_variate=cv, regressor="poly")
+        b = AdvancedOptionPricer(100, 0.05, 0.2, "put", RNGManager(2025), use_control_variate=cv, regressor="poly")
         curve = a.compute_curve_for_S0(95.0, 2, 30, 4000, False)
         ref = []
         for i in range(30, 0, -1):

