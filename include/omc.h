@@ -90,6 +90,11 @@ int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
  * the all-reduce hook, see below), "step_graph" (1 / 0: replay the per-step sweep as one captured HIP
  * graph or launch its kernels one by one; -1 = default, on) */
 int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
+/* measurement aid: with option "step_stamps" = 1 the per-step reference sweep runs a build of its kernel
+ * that records eight 100 MHz time stamps per launch and workgroup (entry, partials in, fit solved,
+ * barrier passed, rows in, paths done, block sums done, exit); this copies them out, laid out
+ * [n_steps + 1][256][8] uint64 with launch index n_steps - t.  Not part of the pricing path. */
+int omc_debug_read(omc_ctx* ctx, void* host, size_t bytes);
 
 /* ---- path generation ------------------------------------------------------------------- */
 /* replaces the inline GBM block options_model_3.py:473-480 (== Options_model.py:79-88,

@@ -73,7 +73,8 @@ struct omc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf S, sx, tex, ex, D, part, gmom, betas, part1, result, scratch, sweep_args;
+    DevBuf S, sx, tex, ex, D, part, gmom, betas, part1, result, scratch, sweep_args, dbg;
+    int step_stamps = 0;  // measurement mode: the per-step kernels time-stamp themselves into `dbg`
     DevBuf bslab, btable, bres, bdisc;  // batched path: problem slab, table, results, discounts
     DevBuf mlp_part, mlp_loss, mlp_wt;  // NN training: gradient partials, epoch loss, transposed connections
     std::vector<char> h_table;
@@ -186,6 +187,10 @@ int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
     w->sx = (float*)c->sx.p;
     w->tex = (int32_t*)c->tex.p;
     w->ex = (uint8_t*)c->ex.p;
+    if (c->step_stamps) {
+        if ((rc = c->dbg.ensure(sizeof(unsigned long long) * 8 * 256 * (size_t)(N + 1)))) return rc;
+        w->dbg = (unsigned long long*)c->dbg.p;
+    }
     w->D = (double*)c->D.p;
     w->part = (double*)c->part.p;
     w->gmom = (double*)c->gmom.p;
@@ -314,7 +319,7 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
         const bool ext = c->distributed();
         const bool flags = semantics == OMC_SEM_REFERENCE;
         int graphed = kNoGraph;
-        if (!ext && step_graph_enabled(c)) {
+        if (!ext && step_graph_enabled(c) && !c->step_stamps) {
             graphed = enqueue_sweep_graph(c, p, w, semantics, write_state);
             if (graphed != 0 && graphed != kNoGraph) return graphed;
         }
@@ -441,7 +446,7 @@ int omc_ctx_destroy(omc_ctx* c)
     if (c->comm) omc::comm_destroy(c->comm);
     c->comm = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
-                      &c->result, &c->scratch, &c->sweep_args, &c->bslab, &c->btable, &c->bres, &c->bdisc,
+                      &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->bslab, &c->btable, &c->bres, &c->bdisc,
                       &c->mlp_part, &c->mlp_loss, &c->mlp_wt})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
@@ -510,6 +515,7 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     else if (!strcmp(key, "heston_vec")) c->heston_vec = (int)value;
     else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
     else if (!strcmp(key, "step_graph")) c->step_graph = value < 0 ? -1 : (value ? 1 : 0);
+    else if (!strcmp(key, "step_stamps")) c->step_stamps = value ? 1 : 0;
     else return fail(-4, "unknown option key.");
     return 0;
 }
@@ -519,6 +525,17 @@ int omc_set_allreduce_hook(omc_ctx* c, omc_allreduce_fn fn, void* user)
     if (!c) return fail(-7, "null context.");
     c->hook = fn;
     c->hook_user = user;
+    return 0;
+}
+
+// measurement aid: the time stamps the per-step kernels wrote ("step_stamps" option), [n_steps+1][256][8]
+int omc_debug_read(omc_ctx* c, void* host, size_t bytes)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!host || !c->dbg.p || bytes > c->dbg.cap) return fail(-7, "no debug buffer of that size.");
+    HIP_TRY(hipMemcpyAsync(host, c->dbg.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

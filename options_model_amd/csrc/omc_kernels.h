@@ -64,6 +64,7 @@ struct LsmWorkspace {
     double* result;   // [8] sum, sumsq, n_exercised, n_zero, sum_nitm, -, -, -
     const float* cont = nullptr;  // per-step sweeps, "values" mode: continuation values [N+1][ldc]
     int64_t ldc = 0;
+    unsigned long long* dbg = nullptr;  // measurement builds: in-kernel time stamps [N+1][nblk][8]
     // optional: events recorded right around the two big kernels of the two-pass flow
     hipEvent_t ev_p1_begin = nullptr, ev_p1_end = nullptr, ev_p2_begin = nullptr, ev_p2_end = nullptr;
 };

@@ -77,6 +77,8 @@ struct StepArgs {
     // (float32, as the reference's networks return it) instead of the fitted polynomial
     const float* cont;
     int64_t ldc;
+    // diagnostic builds only (STAMP): 8 s_memrealtime stamps (100 MHz) per launch and workgroup
+    unsigned long long* dbg;
 };
 
 // One launch per time step t = N .. 1 (the launch boundary is the grid-wide barrier the
@@ -100,10 +102,21 @@ struct StepArgs {
 constexpr int kStepMaxBlocks = 256;
 constexpr int kStepPL = kStepMaxBlocks / 64;
 
-template <int SEM, int VEC, int BLOCK>
+template <int SEM, int VEC, int BLOCK, bool STAMP = false, bool PRO_FIRST = true>
 __device__ __forceinline__ void lsm_step_body(StepArgs a)
 {
     constexpr int WAVES = BLOCK / 64;
+    // STAMP: where a launch spends its time, seen from wave 0 of every workgroup (the wave on the
+    // critical path: it owns the prologue).  Values leave through a.dbg only.
+    unsigned long long stamp[8];
+    auto mark = [&](int k) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            stamp[k] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    mark(0);
     __shared__ double wl[WAVES * kWaveRedDoubles];
     __shared__ double sh_w[WAVES * 8];
     __shared__ double sh_beta[4];
@@ -120,10 +133,14 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
         for (int k = tid; k <= N; k += BLOCK) sh_D[k] = a.D[k];
     }
 
-    // ---- prologue loads (wave 0): the partial moments of step t, issued FIRST so that their
-    // counted wait (vmcnt) does not sit behind this wave's own row loads
+    // ---- prologue loads (wave 0): the partial moments of step t.  Measured with the STAMP build at
+    // C2: issued together with the row loads of all 4096 waves they come back after ~2.3 us (they queue
+    // behind the 13 MB burst), and the reduce + solve (0.5 us) only starts then.  So the workgroup holds
+    // its row loads back until wave 0 has its partials (PRO_FIRST: one extra barrier, ~0.5 us after
+    // entry); reduce + solve then run under the row loads' latency.
     const bool pro = do_apply && wave == 0 && !values;
     double pv[kStepPL][8];
+    double pacc[8];
     if (pro && !a.external) {
         const double* pp = a.part + (size_t)(t & 1) * 8 * a.pstride;
 #pragma unroll
@@ -137,6 +154,17 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
                 pv[i][q] = ok ? v : 0.0;
             }
         }
+        if constexpr (PRO_FIRST) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                pacc[q] = pv[0][q];
+#pragma unroll
+                for (int i = 1; i < kStepPL; ++i) pacc[q] += pv[i][q];
+            }
+        }
+    }
+    if constexpr (PRO_FIRST) {
+        if (do_apply && !values && !a.external) __syncthreads();  // wave 0 arrives once its partials are in
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -179,9 +207,17 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
                 double acc[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    acc[q] = pv[0][q];
+                    if constexpr (PRO_FIRST) {
+                        acc[q] = pacc[q];
+                    } else {
+                        acc[q] = pv[0][q];
 #pragma unroll
-                    for (int i = 1; i < kStepPL; ++i) acc[q] += pv[i][q];
+                        for (int i = 1; i < kStepPL; ++i) acc[q] += pv[i][q];
+                    }
+                }
+                if constexpr (STAMP) {
+                    if (!PRO_FIRST) asm volatile("s_waitcnt vmcnt(4)");  // the partials are in (4 row loads behind them)
+                    mark(1);
                 }
                 const double s = wave_reduce8(acc, wl);  // total of quantity lane >> 3 in every lane
 #pragma unroll
@@ -189,6 +225,7 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
             }
             double beta[3];
             solve_poly2(m, beta);  // every lane, same result
+            mark(2);
             if (lane == 0) {
                 sh_beta[0] = beta[0]; sh_beta[1] = beta[1]; sh_beta[2] = beta[2]; sh_beta[3] = m[0];
                 if (blockIdx.x == 0) {
@@ -205,6 +242,11 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
         b0 = sh_beta[0]; b1 = sh_beta[1]; b2 = sh_beta[2]; nfit = sh_beta[3];
     } else if (SEM == 1 && do_mom) {
         __syncthreads();
+    }
+    mark(3);
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)");  // this wave's first rows / state are in
+        mark(4);
     }
 
     double acc[8];
@@ -295,17 +337,28 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
         j += stride;
         if (j < a.M) load_chunk(j);
     }
+    mark(5);
     if (do_mom) {
         // a wave none of whose lanes added anything contributes exact zeros: skip its transpose
         double s = 0.0;
         if (__builtin_amdgcn_ballot_w64(added) != 0) s = wave_reduce8(acc, wl + wave * kWaveRedDoubles);
         if ((lane & 7) == 0) sh_w[wave * 8 + (lane >> 3)] = s;
         __syncthreads();
+        mark(6);
         if (tid < 8) {
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) tot += sh_w[w * 8 + tid];
             a.part[(size_t)((t - 1) & 1) * 8 * a.pstride + (size_t)tid * a.pstride + blockIdx.x] = tot;
+        }
+    }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)");
+        mark(7);
+        if (tid == 0 && a.dbg) {
+            unsigned long long* d = a.dbg + ((size_t)(N - t) * a.nblk + blockIdx.x) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = stamp[k];
         }
     }
 }
