@@ -27,8 +27,7 @@ template <int SEM, int VEC, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void lsm_step_kernel(StepArgs a) { lsm_step_body<SEM, VEC, BLOCK>(a); }
 
 // measurement build (omc_set_option "step_stamps"): same kernel with in-kernel time stamps
-template <bool PRO_FIRST>
-__global__ __launch_bounds__(1024) void lsm_step_stamp_kernel(StepArgs a) { lsm_step_body<0, 4, 1024, true, PRO_FIRST>(a); }
+__global__ __launch_bounds__(1024) void lsm_step_stamp_kernel(StepArgs a) { lsm_step_body<0, 4, 1024, true>(a); }
 
 // the same with the argument block in device memory: the N launches of one sweep differ only in `t`,
 // so a captured HIP graph of them can be replayed for any pricing of the same geometry after
@@ -170,9 +169,7 @@ static hipError_t lsm_step_impl(hipStream_t st, const LsmProblem& p, const LsmWo
     const size_t dyn = semantics == 1 ? sizeof(double) * (size_t)(p.N + 1) : 0;
     const bool big = lsm_step_block_threads() == 1024;
     if (w.dbg && !ind && semantics == 0 && v4 && big) {
-        static const bool late = getenv("OMC_STEP_PRO_LATE") != nullptr;  // the round-2a ordering, for comparison
-        if (late) hipLaunchKernelGGL(lsm_step_stamp_kernel<false>, dim3(a.nblk), dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL(lsm_step_stamp_kernel<true>, dim3(a.nblk), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(lsm_step_stamp_kernel, dim3(a.nblk), dim3(1024), 0, st, a);
         return hipGetLastError();
     }
 #define OMC_STEP(SEM, VEC)                                                       \

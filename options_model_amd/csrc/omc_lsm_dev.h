@@ -102,7 +102,7 @@ struct StepArgs {
 constexpr int kStepMaxBlocks = 256;
 constexpr int kStepPL = kStepMaxBlocks / 64;
 
-template <int SEM, int VEC, int BLOCK, bool STAMP = false, bool PRO_FIRST = true>
+template <int SEM, int VEC, int BLOCK, bool STAMP = false>
 __device__ __forceinline__ void lsm_step_body(StepArgs a)
 {
     constexpr int WAVES = BLOCK / 64;
@@ -133,14 +133,13 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
         for (int k = tid; k <= N; k += BLOCK) sh_D[k] = a.D[k];
     }
 
-    // ---- prologue loads (wave 0): the partial moments of step t.  Measured with the STAMP build at
-    // C2: issued together with the row loads of all 4096 waves they come back after ~2.3 us (they queue
-    // behind the 13 MB burst), and the reduce + solve (0.5 us) only starts then.  So the workgroup holds
-    // its row loads back until wave 0 has its partials (PRO_FIRST: one extra barrier, ~0.5 us after
-    // entry); reduce + solve then run under the row loads' latency.
+    // ---- prologue loads (wave 0): the partial moments of step t, issued FIRST so that their
+    // counted wait (vmcnt) does not sit behind this wave's own row loads.  (Measured with the STAMP
+    // build at C2, DESIGN.md section 8: the first bytes of ANY load come back 1.6-2.3 us after kernel
+    // entry; holding the row loads back until the partials are in, or de-correlating the order in which
+    // workgroups walk the partial rows, changed nothing measurable in the production build.)
     const bool pro = do_apply && wave == 0 && !values;
     double pv[kStepPL][8];
-    double pacc[8];
     if (pro && !a.external) {
         const double* pp = a.part + (size_t)(t & 1) * 8 * a.pstride;
 #pragma unroll
@@ -154,17 +153,6 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
                 pv[i][q] = ok ? v : 0.0;
             }
         }
-        if constexpr (PRO_FIRST) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                pacc[q] = pv[0][q];
-#pragma unroll
-                for (int i = 1; i < kStepPL; ++i) pacc[q] += pv[i][q];
-            }
-        }
-    }
-    if constexpr (PRO_FIRST) {
-        if (do_apply && !values && !a.external) __syncthreads();  // wave 0 arrives once its partials are in
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -207,16 +195,12 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
                 double acc[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    if constexpr (PRO_FIRST) {
-                        acc[q] = pacc[q];
-                    } else {
-                        acc[q] = pv[0][q];
+                    acc[q] = pv[0][q];
 #pragma unroll
-                        for (int i = 1; i < kStepPL; ++i) acc[q] += pv[i][q];
-                    }
+                    for (int i = 1; i < kStepPL; ++i) acc[q] += pv[i][q];
                 }
                 if constexpr (STAMP) {
-                    if (!PRO_FIRST) asm volatile("s_waitcnt vmcnt(4)");  // the partials are in (4 row loads behind them)
+                    asm volatile("s_waitcnt vmcnt(4)");  // the partials are in (4 row loads behind them)
                     mark(1);
                 }
                 const double s = wave_reduce8(acc, wl);  // total of quantity lane >> 3 in every lane
