@@ -167,8 +167,10 @@ def launch_ranks(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed pricings first (the GPU's clocks take ~10-20 ms of work to come up: "
+                         "profiles/r02f shows the same kernel 1.46 -> 0.93 ms over its first 13 launches)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
                     help="c2: GBM put 1M paths/GPU (default); c3: 8M paths/GPU (64M over 8); c4: Heston call 4M")
     ap.add_argument("--paths-per-gpu", type=int, default=None, help="override the config's paths per GPU")
@@ -207,6 +209,10 @@ def main():
     N = a.n_steps
     is_put = model == "gbm"
     backend = a.backend or ("gloo" if a.single_device and world > 1 else "rccl")
+
+    # the CPU oracle's OpenMP runtime reads OMP_NUM_THREADS when the library is first loaded (price_check
+    # comes before cpu_baseline): pin it to the container's CPU quota now, not to the 256 visible threads
+    os.environ.setdefault("OMP_NUM_THREADS", str(cpu_threads()))
 
     from options_model_amd import _ffi
 

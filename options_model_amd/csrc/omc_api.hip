@@ -106,6 +106,12 @@ struct omc_ctx {
     char* sweep_pin = nullptr;     // pinned upload ring
     int sweep_pin_slot = 0;
     int step_graph = -1;           // -1: environment default (on), 0 off, 1 on
+    // persistent per-step sweep (one launch for the whole backward induction): -1 default (on), 0 off, 1 on
+    int step_persistent = -1;
+    int persist_failed = 0;        // a bounded spin gave up once on this context: stay with launches
+    int persist_used = 0;          // the pricing(s) enqueued since the last wait went through it
+    int device_cus = 0;
+    DevBuf persist_scratch;
     bool distributed() const { return comm != nullptr || hook != nullptr; }
 };
 
@@ -233,6 +239,17 @@ int allreduce(omc_ctx* c, double* dptr, int count)
     return 0;
 }
 
+bool step_persistent_enabled(const omc_ctx* c)
+{
+    if (c->persist_failed) return false;
+    if (c->step_persistent >= 0) return c->step_persistent != 0;
+    static const int env = [] {
+        const char* e = getenv("OMC_STEP_PERSISTENT");
+        return e ? atoi(e) : 1;
+    }();
+    return env != 0;
+}
+
 bool step_graph_enabled(const omc_ctx* c)
 {
     if (c->step_graph >= 0) return c->step_graph != 0;
@@ -318,6 +335,14 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
     } else {
         const bool ext = c->distributed();
         const bool flags = semantics == OMC_SEM_REFERENCE;
+        if (!ext && flags && !c->step_stamps && !w.cont && step_persistent_enabled(c) &&
+            omc::lsm_persist_supported(p, c->device_cus)) {
+            if ((rc = c->persist_scratch.ensure(omc::lsm_persist_scratch_bytes()))) return rc;
+            static const double spin_s = getenv("OMC_PERSIST_SPIN_SECONDS") ? atof(getenv("OMC_PERSIST_SPIN_SECONDS")) : 0.25;
+            HIP_TRY(omc::lsm_sweep_persistent(st, p, w, c->persist_scratch.p, write_state, spin_s));
+            c->persist_used = 1;
+            return 0;
+        }
         int graphed = kNoGraph;
         if (!ext && step_graph_enabled(c) && !c->step_stamps) {
             graphed = enqueue_sweep_graph(c, p, w, semantics, write_state);
@@ -339,6 +364,15 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
     // table, which is ALREADY global on every rank: fill_result divides it by the world size again.
     if (c->distributed() && (rc = allreduce(c, w.result, 8))) return rc;
     return 0;
+}
+
+// The persistent sweep's bounded spins gave up (result slot 7 carries its error word): remember it on the
+// context -- the caller re-enqueues the pricing, which then takes the launch-per-step sweep.
+bool persistent_gave_up(omc_ctx* c, const double* h)
+{
+    if (!c->persist_used || h[7] == 0.0) return false;
+    c->persist_failed = 1;
+    return true;
 }
 
 void fill_result(omc_result* res, const double* h, int64_t M, int world = 1)
@@ -433,6 +467,7 @@ int omc_ctx_create(int device, void* hip_stream, omc_ctx** out)
         if (c->hres_pin) (void)hipHostFree(c->hres_pin);
         c->hres_pin = c->hres_dev = nullptr;  // fall back to a device buffer + copy into the pageable member
     }
+    (void)hipDeviceGetAttribute(&c->device_cus, hipDeviceAttributeMultiprocessorCount, device);
     *out = c;
     return 0;
 }
@@ -446,7 +481,7 @@ int omc_ctx_destroy(omc_ctx* c)
     if (c->comm) omc::comm_destroy(c->comm);
     c->comm = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
-                      &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->bslab, &c->btable, &c->bres, &c->bdisc,
+                      &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->persist_scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc,
                       &c->mlp_part, &c->mlp_loss, &c->mlp_wt})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
@@ -516,6 +551,10 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
     else if (!strcmp(key, "step_graph")) c->step_graph = value < 0 ? -1 : (value ? 1 : 0);
     else if (!strcmp(key, "step_stamps")) c->step_stamps = value ? 1 : 0;
+    else if (!strcmp(key, "step_persistent")) {
+        c->step_persistent = value < 0 ? -1 : (value ? 1 : 0);
+        if (value > 0) c->persist_failed = 0;  // explicit request: try again
+    }
     else return fail(-4, "unknown option key.");
     return 0;
 }
@@ -721,12 +760,17 @@ int omc_lsm_poly(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     omc::LsmWorkspace w;
     if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, semantics == OMC_SEM_TWO_PASS, betas_out != nullptr, &w))) return rc;
     omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if ((rc = enqueue_lsm(c, p, w, semantics, sx_out || tex_out))) return rc;
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-    if ((rc = copy_outputs(c, w, n_paths, n_steps, betas_out, sx_out, tex_out))) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int attempt = 0;; ++attempt) {
+        c->persist_used = 0;
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        if ((rc = enqueue_lsm(c, p, w, semantics, sx_out || tex_out))) return rc;
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = copy_outputs(c, w, n_paths, n_steps, betas_out, sx_out, tex_out))) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (attempt == 0 && persistent_gave_up(c, c->hres)) continue;
+        break;
+    }
     memset(res, 0, sizeof *res);
     fill_result(res, c->hres, c->distributed() ? n_paths * c->world : n_paths, c->distributed() ? c->world : 1);
     float ms = 0;
@@ -881,13 +925,18 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     // kernel, no extra dependent launch).  With an all-reduce hook the sums stay in device memory for
     // the collective and are copied afterwards.
     const bool zero_copy = c->hres_dev && !c->distributed();
-    double* result = nullptr;
-    if ((rc = enqueue_pricing(c, p, S_keep, ld, zero_copy ? c->hres_dev : nullptr, true, &result))) return rc;
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     double* hres = c->hres_pin ? c->hres_pin : c->hres;
-    if (!zero_copy)
-        HIP_TRY(hipMemcpyAsync(hres, result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-    if ((rc = wait_stream(c))) return rc;
+    for (int attempt = 0;; ++attempt) {
+        c->persist_used = 0;
+        double* result = nullptr;
+        if ((rc = enqueue_pricing(c, p, S_keep, ld, zero_copy ? c->hres_dev : nullptr, true, &result))) return rc;
+        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        if (!zero_copy)
+            HIP_TRY(hipMemcpyAsync(hres, result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = wait_stream(c))) return rc;
+        if (attempt == 0 && persistent_gave_up(c, hres)) continue;
+        break;
+    }
     memset(res, 0, sizeof *res);
     fill_result(res, hres, c->distributed() ? p->n_paths * c->world : p->n_paths,
                 c->distributed() ? c->world : 1);  // distributed: sums are global
@@ -919,22 +968,28 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
         c->seq_cap = n;
     }
     hipEvent_t ev_end = c->ev[2];
-    for (int i = 0; i < n; ++i) {
-        // with an all-reduce hook the sums stay in device memory for the collective (which the hook
-        // enqueues on the stream, no host wait) and are copied to the slot afterwards
-        double* result = nullptr;
-        if ((rc = enqueue_pricing(c, &p[i], nullptr, 0, c->distributed() ? nullptr : c->seq_dev + 8 * (size_t)i, i == 0,
-                                  &result)))
-            return rc;
-        if (c->distributed())
-            HIP_TRY(hipMemcpyAsync(c->seq_pin + 8 * (size_t)i, result, sizeof(double) * 8, hipMemcpyDeviceToHost,
-                                   c->stream));
-        if (i == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    }
     if (!c->ev_seq) HIP_TRY(hipEventCreate(&c->ev_seq));
     ev_end = c->ev_seq;
-    HIP_TRY(hipEventRecord(ev_end, c->stream));
-    if ((rc = wait_stream(c))) return rc;
+    for (int attempt = 0;; ++attempt) {
+        c->persist_used = 0;
+        for (int i = 0; i < n; ++i) {
+            // with an all-reduce hook the sums stay in device memory for the collective (which the hook
+            // enqueues on the stream, no host wait) and are copied to the slot afterwards
+            double* result = nullptr;
+            if ((rc = enqueue_pricing(c, &p[i], nullptr, 0, c->distributed() ? nullptr : c->seq_dev + 8 * (size_t)i,
+                                      i == 0, &result)))
+                return rc;
+            if (c->distributed())
+                HIP_TRY(hipMemcpyAsync(c->seq_pin + 8 * (size_t)i, result, sizeof(double) * 8, hipMemcpyDeviceToHost,
+                                       c->stream));
+            if (i == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        }
+        HIP_TRY(hipEventRecord(ev_end, c->stream));
+        if ((rc = wait_stream(c))) return rc;
+        bool redo = false;
+        for (int i = 0; i < n && attempt == 0; ++i) redo = redo || persistent_gave_up(c, c->seq_pin + 8 * (size_t)i);
+        if (!redo) break;
+    }
     float ms_all = 0;
     HIP_TRY(hipEventElapsedTime(&ms_all, c->ev[0], ev_end));
     omc_result first;

@@ -92,6 +92,15 @@ void lsm_sweep_args_image(const LsmProblem& p, const LsmWorkspace& w, int semant
 hipError_t lsm_sweep_indirect(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
                               const void* args_dev);
 
+// The per-step REFERENCE sweep as one persistent launch (omc_lsm_persist.hip): state on chip, the per-step
+// grid-wide dependency as an in-launch all-gather.  `scratch`: lsm_persist_scratch_bytes() of device memory.
+// result[7] != 0 afterwards: a bounded spin gave up (workgroups not co-resident) -- results invalid, rerun
+// with the launch-per-step sweep.
+size_t lsm_persist_scratch_bytes();
+bool lsm_persist_supported(const LsmProblem& p, int device_cus);
+hipError_t lsm_sweep_persistent(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, void* scratch,
+                                bool write_state, double spin_seconds);
+
 // two-pass flow (semantics 2)
 hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);
 hipError_t lsm_solve_all(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);
