@@ -24,6 +24,14 @@
 // raises a global error word that every other spin polls, all workgroups leave, and the host falls back to
 // the launch-per-step sweep -- the kernel cannot hang.
 //
+// OUTCOME (MI355X, profiles/r02_persist_stamps.txt): OFF by default.  The exchange of one epoch -- partials
+// published, workgroup 0 sweeps them, solves, publishes the fit, everyone picks it up -- takes 6.4 us at the
+// median workgroup (two write-through-store -> remote sc1-load hops at ~3 us each under 255 polling waves)
+// against 1.3 us of launch gap + ~2.3 us of cold-start latency for the launch-per-step kernel: 8.5 vs
+// 6.2 us per step at 1M paths, 24 vs 21 us at 8M.  An all-gather (every workgroup sweeps all partials) was
+// worse still (18 us per step: 1024 polling waves starve the writers).  Kept as an opt-in
+// (omc_set_option "step_persistent") and under test; the launch-per-step sweep stays the product path.
+//
 // Results: the same regression sets, fits and decisions as the launch-per-step sweep (the partial sums of
 // a workgroup cover the same paths and are combined over workgroups in the same order); only the order of
 // additions INSIDE a wave differs (xor-shuffle tree here, LDS transpose there), i.e. moment sums agree to
@@ -47,14 +55,18 @@ struct PersistArgs {
     double* gmom;
     double* betas;
     double* part;             // [8][pstride]: final sums of every workgroup (rows 0..3) for lsm_finalize
-    unsigned long long* gran; // [2][nblk][16] granules
+    unsigned long long* gran; // [2][nblk][16] granules: every workgroup's partial moments
+    unsigned long long* bgran; // [2][16] granules: the fit of the epoch, published by workgroup 0 (8 used per parity)
     unsigned int* err;        // raised by a spin that gave up
     int nblk, pstride, nchunk, write_state;
     unsigned long long spin_ticks;
+    unsigned long long* dbg;  // measurement aid (omc_set_option "step_stamps"): [N+1][nblk][8] time stamps
 };
 
 constexpr int kPersistBlock = 1024;
 constexpr int kPersistWaves = kPersistBlock / 64;
+constexpr int kPollWaves = kStepMaxBlocks / 64;  // waves 0..3 sweep the granules of 64 workgroups each
+constexpr int kPublishWave = kPersistWaves - 1;  // the last wave publishes
 
 // all 8 accumulators over the wave by an xor-shuffle tree; every lane ends with every total
 __device__ __forceinline__ void wave_allreduce8(double (&acc)[8])
@@ -69,8 +81,10 @@ __device__ __forceinline__ void wave_allreduce8(double (&acc)[8])
 template <int NCH>
 __global__ __launch_bounds__(kPersistBlock) void lsm_sweep_persist_kernel(PersistArgs a)
 {
+    constexpr bool kPatch = NCH <= 2;  // room for the per-wave LDS transpose patches next to S_N?
     __shared__ float sh_sn[NCH * kPersistBlock * 4];  // terminal spots of this workgroup's paths
     __shared__ double sh_all[kStepMaxBlocks * 8];     // gathered partial moments of one epoch
+    __shared__ double wl[kPatch ? kPersistWaves * kWaveRedDoubles : 8];
     __shared__ double sh_w[kPersistWaves * 8];
     __shared__ double sh_beta[4];
     __shared__ int sh_fail;
@@ -81,8 +95,18 @@ __global__ __launch_bounds__(kPersistBlock) void lsm_sweep_persist_kernel(Persis
     const int64_t cstride = (int64_t)G * kPersistBlock * 4;
     const int64_t j0 = ((int64_t)blockIdx.x * kPersistBlock + tid) * 4;
     gu64* const gran = (gu64*)a.gran;
+    gu64* const bgran = (gu64*)a.bgran;
     gu32* const err = (gu32*)a.err;
+    const bool leader = blockIdx.x == 0;
     if (tid == 0) sh_fail = 0;
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto mark = [&](int k) {
+        if (a.dbg) {
+            __builtin_amdgcn_sched_barrier(0);
+            stamp[k] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 
     float st[NCH][4], sm[NCH][4];
     bool valid[NCH];
@@ -131,63 +155,143 @@ __global__ __launch_bounds__(kPersistBlock) void lsm_sweep_persist_kernel(Persis
                 }
             }
         }
-        if (__builtin_amdgcn_ballot_w64(added) != 0) {
-            wave_allreduce8(acc);
+        mark(6);
+        if constexpr (kPatch) {
+            double s = 0.0;
+            if (__builtin_amdgcn_ballot_w64(added) != 0) s = wave_reduce8(acc, wl + wave * kWaveRedDoubles);
+            if ((lane & 7) == 0) sh_w[wave * 8 + (lane >> 3)] = s;
         } else {
+            if (__builtin_amdgcn_ballot_w64(added) != 0) {
+                wave_allreduce8(acc);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-        }
-        if (lane == 0) {
+                for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+            }
+            if (lane == 0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sh_w[wave * 8 + q] = acc[q];
+                for (int q = 0; q < 8; ++q) sh_w[wave * 8 + q] = acc[q];
+            }
         }
         __syncthreads();
-        if (tid < 8) {
+        // Published by a wave that does NOT poll: on gfx9 a wave's loads and stores share one in-order
+        // counter, so a poller that had just stored would sit behind its own write-through stores
+        // (measured: ~5 us each) on its next counted wait.
+        if (wave == kPublishWave && lane < 8) {
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < kPersistWaves; ++w) tot += sh_w[w * 8 + tid];
+            for (int w = 0; w < kPersistWaves; ++w) tot += sh_w[w * 8 + lane];
             const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
-            gu64* g = gran + ((size_t)(epoch & 1u) * G + blockIdx.x) * 16 + 2 * tid;
+            gu64* g = gran + ((size_t)(epoch & 1u) * G + blockIdx.x) * 16 + 2 * lane;
             const unsigned long long tag = (unsigned long long)epoch << 32;
             __hip_atomic_store(g, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g + 1, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 
-    // all workgroups' partials of `epoch` -> sh_all; false: a spin gave up somewhere (leave the kernel)
-    auto gather = [&](unsigned epoch) -> bool {
-        if (wave < kStepMaxBlocks / 64) {
-            const int b = wave * 64 + lane;
-            const bool mine = b < G;
-            const gu64* g = gran + ((size_t)(epoch & 1u) * G + (mine ? b : 0)) * 16;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            unsigned long long x[16];
-            bool failed = false;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok &= (unsigned)(x[k] >> 32) == epoch;
-                }
-                if (__builtin_amdgcn_ballot_w64(!(ok || !mine)) == 0) break;
-                const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks;
-                if (e != 0u || late) {
-                    if (late && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    failed = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+    // One bounded poll loop for both roles.  `ready(x)` says whether this lane's granules carry `epoch`.
+    // Returns false when a spin gave up somewhere (this one by time, or another one through `err`).
+    auto spin_until = [&](auto&& load_and_check, bool participate) -> bool {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned polls = 1;; ++polls) {
+            const bool ok = load_and_check();
+            if (__builtin_amdgcn_ballot_w64(participate && !ok) == 0) {
+                if (wave == 0) stamp[2] = polls;
+                return true;
             }
-            if (failed) {
-                sh_fail = 1;
-            } else if (mine) {
+            const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > a.spin_ticks;
+            if (e != 0u || late) {
+                if (late && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    };
+
+    // The exchange of one epoch, two hops: every workgroup has published its 8 partial moments; workgroup 0
+    // sweeps them all (256 lines per pass, ONE reader: no poller storm on the lines the writers are trying to
+    // reach), combines them in a fixed order, solves, and publishes the fit (b0, b1, b2, n) as 8 granules in
+    // one line; every other workgroup polls that one line with one wave.  Leaves the fit in sh_beta; false:
+    // leave the kernel.
+    auto exchange = [&](unsigned epoch, int t) -> bool {
+        if (leader) {
+            if (wave < kPollWaves) {
+                const int b = wave * 64 + lane;
+                const bool mine = b < G;
+                const gu64* g = gran + ((size_t)(epoch & 1u) * G + (mine ? b : 0)) * 16;
+                unsigned long long x[16];
+                const bool fine = spin_until([&]() {
+                    bool ok = true;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned long long bits = (x[2 * q] << 32) | (x[2 * q + 1] & 0xffffffffull);
-                    sh_all[b * 8 + q] = __longlong_as_double((long long)bits);
+                    for (int k = 0; k < 16; ++k) {
+                        x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= (unsigned)(x[k] >> 32) == epoch;
+                    }
+                    return ok;
+                }, mine);
+                if (!fine) {
+                    sh_fail = 1;
+                } else if (mine) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned long long bits = (x[2 * q] << 32) | (x[2 * q + 1] & 0xffffffffull);
+                        sh_all[b * 8 + q] = __longlong_as_double((long long)bits);
+                    }
                 }
+            }
+            __syncthreads();
+            if (sh_fail) return false;
+            if (wave >= 8) {  // wave 8 + q totals quantity q over the workgroups
+                const int q = wave - 8;
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < kStepMaxBlocks / 64; ++i) {
+                    const int b = lane + 64 * i;
+                    s += b < G ? sh_all[b * 8 + q] : 0.0;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0) sh_w[q] = s;
+            }
+            __syncthreads();
+            if (wave == kPublishWave) {
+                double m[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[q] = sh_w[q];
+                double beta[3];
+                solve_poly2(m, beta);
+                const double f4[4] = {beta[0], beta[1], beta[2], m[0]};
+                if (lane < 8) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(f4[lane >> 1]);
+                    const unsigned long long word = (lane & 1) ? (bits & 0xffffffffull) : (bits >> 32);
+                    __hip_atomic_store(bgran + (size_t)(epoch & 1u) * 16 + lane, ((unsigned long long)epoch << 32) | word,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane == 0) {
+                    sh_beta[0] = f4[0]; sh_beta[1] = f4[1]; sh_beta[2] = f4[2]; sh_beta[3] = f4[3];
+                    double* bo = a.betas + (size_t)t * 4;
+                    bo[0] = f4[0]; bo[1] = f4[1]; bo[2] = f4[2]; bo[3] = f4[3];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a.gmom[(size_t)t * 8 + q] = m[q];
+                }
+            }
+            __syncthreads();
+            return true;
+        }
+        if (wave == 0) {
+            const bool mine = lane < 8;
+            unsigned long long x = 0;
+            const gu64* g = bgran + (size_t)(epoch & 1u) * 16 + (mine ? lane : 0);
+            const bool fine = spin_until([&]() {
+                x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return (unsigned)(x >> 32) == epoch;
+            }, mine);
+            if (!fine) {
+                sh_fail = 1;
+            } else {
+                const unsigned lo = (unsigned)__shfl(x, lane | 1), hi = (unsigned)__shfl(x, lane & ~1);
+                if (mine && (lane & 1) == 0)
+                    sh_beta[lane >> 1] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
             }
         }
         __syncthreads();
@@ -198,41 +302,21 @@ __global__ __launch_bounds__(kPersistBlock) void lsm_sweep_persist_kernel(Persis
     if (N >= 2) moments_and_publish(N - 1, ++epoch);  // what launch t = N of the per-step sweep does
 
     for (int t = N - 1; t >= 1; --t) {
-        // S_t moves into place; S_{t-1} starts its journey now and is needed only after the exchange
+        // S_t moves into place
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int v = 0; v < 4; ++v) st[c][v] = sm[c][v];
-        if (t >= 2) load_row(sm, t - 1);
-
-        if (!gather(epoch)) return;  // uniform: every thread saw the same sh_fail after the barrier
-        if (wave == 0) {
-            // workgroups combined in the launch-per-step kernel's order: lane sums b = lane + 64 i, then lanes
-            double m[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                double s = 0.0;
-#pragma unroll
-                for (int i = 0; i < kStepMaxBlocks / 64; ++i) {
-                    const int b = lane + 64 * i;
-                    s += b < G ? sh_all[b * 8 + q] : 0.0;
-                }
-                m[q] = s;
-            }
-            wave_allreduce8(m);
-            double beta[3];
-            solve_poly2(m, beta);
-            if (lane == 0) {
-                sh_beta[0] = beta[0]; sh_beta[1] = beta[1]; sh_beta[2] = beta[2]; sh_beta[3] = m[0];
-                if (blockIdx.x == 0) {
-                    double* bo = a.betas + (size_t)t * 4;
-                    bo[0] = beta[0]; bo[1] = beta[1]; bo[2] = beta[2]; bo[3] = m[0];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) a.gmom[(size_t)t * 8 + q] = m[q];
-                }
-            }
-        }
-        __syncthreads();
+        // S_{t-1} starts its journey now and is needed only after the exchange and the apply phase; the
+        // polling waves start theirs after the gather (their granule loads would otherwise wait behind it)
+        const bool poller = leader ? wave < kPollWaves : wave == 0;
+        if (t >= 2 && !poller) load_row(sm, t - 1);
+        mark(0);
+        if (!exchange(epoch, t)) return;  // uniform: every thread saw the same sh_fail after a barrier
+        if (t >= 2 && poller) load_row(sm, t - 1);
+        mark(1);
+        mark(3);
+        mark(4);
         const double b0 = sh_beta[0], b1 = sh_beta[1], b2 = sh_beta[2];
         if (sh_beta[3] > 0.5) {
             const double Dt = a.D[t - 1];
@@ -260,7 +344,14 @@ __global__ __launch_bounds__(kPersistBlock) void lsm_sweep_persist_kernel(Persis
                 }
             }
         }
+        mark(5);
         if (t >= 2) moments_and_publish(t - 1, ++epoch);
+        mark(7);
+        if (a.dbg && tid == 0) {
+            unsigned long long* d = a.dbg + ((size_t)(N - t) * G + blockIdx.x) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = stamp[k];
+        }
     }
 
     // paths that never exercised keep their terminal payoff, valued at t = dt
@@ -330,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void lsm_persist_finalize_kernel(const doub
     if (threadIdx.x == 0) result[7] = (double)*err;
 }
 
-size_t lsm_persist_scratch_bytes() { return sizeof(unsigned long long) * 2 * kStepMaxBlocks * 16 + 256; }
+size_t lsm_persist_scratch_bytes() { return sizeof(unsigned long long) * (2 * kStepMaxBlocks * 16 + 2 * 16) + 256; }
 
 int lsm_persist_max_chunks() { return 8; }
 
@@ -351,13 +442,15 @@ hipError_t lsm_sweep_persistent(hipStream_t st, const LsmProblem& p, const LsmWo
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put; a.K = p.K; a.invK = 1.0 / p.K;
     a.sx = w.sx; a.tex = w.tex; a.ex = w.ex; a.D = w.D; a.gmom = w.gmom; a.betas = w.betas; a.part = w.part;
     a.gran = (unsigned long long*)scratch;
-    a.err = (unsigned int*)((char*)scratch + sizeof(unsigned long long) * 2 * kStepMaxBlocks * 16);
+    a.bgran = a.gran + 2 * kStepMaxBlocks * 16;
+    a.err = (unsigned int*)(a.bgran + 2 * 16);
     a.nblk = lsm_sweep_blocks(p.M);
     a.pstride = kMaxLsmBlocks;
     const int64_t per_sweep = (int64_t)a.nblk * kPersistBlock * 4;
     a.nchunk = (int)((p.M + per_sweep - 1) / per_sweep);
     a.write_state = write_state ? 1 : 0;
     a.spin_ticks = (unsigned long long)(spin_seconds * 1e8);
+    a.dbg = w.dbg;
     hipError_t e = hipMemsetAsync(scratch, 0, lsm_persist_scratch_bytes(), st);  // tags and error word: every launch
     if (e != hipSuccess) return e;
     const dim3 grid(a.nblk), block(kPersistBlock);
