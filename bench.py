@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="warm-up + timed region only (for rocprofv3 --pmc passes: every dispatch of a kernel is then "
+                         "the same workload): no per-step extra, sustained loop, price check, variants, CPU baseline")
     ap.add_argument("--group", type=int, default=10,
                     help="pricings enqueued per omc_price_american_seq call (one host wait per group)")
     ap.add_argument("--sync-every-step", action="store_true",
@@ -191,6 +194,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="go through the communicator even with one rank (rehearsal of the N>1 path)")
     a = ap.parse_args()
+    if a.only_timed:
+        a.no_cpu_baseline = a.no_variants = a.no_sustained = True
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
@@ -376,7 +381,7 @@ def main():
             for k in kernels:
                 stem = k["kernel"].replace("gbm_", "").replace("heston_", "")
                 for name, v in pk.items():
-                    if stem in name and same:
+                    if stem in name.replace("_ind_", "_") and same:
                         k["traffic"] = v["read_bytes"] + v["write_bytes"]
                         k["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
                                               f"{pj.get('round', 'r01')}; not measured in this run)"
@@ -391,7 +396,9 @@ def main():
 
     # ---- the per-timestep kernel north_star specifies, as a first-class number: the reference per-step
     # flow on the same workload, HIP-event time of its N launches (boundaries included) / N
-    if a.semantics != "reference":
+    if a.only_timed:
+        line["roofline_per_step"] = kernels[1] if a.semantics == "reference" else None
+    elif a.semantics != "reference":
         price_group([900, 901], "reference")  # warm (graph capture, workspaces)
         barrier(); ctx.sync()
         t1 = time.perf_counter()
@@ -431,7 +438,7 @@ def main():
                              "vs_timed_region": (world * M * N * n / dt) / line["value"]}
 
     # ---- parity in the bench line: GPU vs the CPU oracle on the SAME Philox (seed, stream), bounded slice
-    if rank == 0:
+    if rank == 0 and not a.only_timed:
         Mc = min(M, 200_000) // 4 * 4
         try:
             g = _ffi.Context(local_rank) if dist_mode else ctx  # unsharded, no communicator

@@ -66,14 +66,53 @@ bench)
   ;;
 pmc)
   cd /tmp && export TMPDIR=/tmp
+  # HBM traffic: separate passes per counter (TCC slots); every dispatch in a pass is the timed workload
+  for SEM in two_pass reference; do
+    for CTR in FETCH_SIZE WRITE_SIZE; do
+      OUT="$R/gpurun_out/pmc_${TAG}${SEM}_$CTR"
+      timeout -k 10 300 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$OUT" -- \
+          python "$R/bench.py" --steps 3 --warmup 1 --semantics $SEM --only-timed \
+          > /dev/null 2> "$OUT.err"; rc=$?
+      echo "pmc $SEM $CTR exit=$rc"
+      ok $rc || exit 1
+    done
+    python "$R/tools/summarize_pmc.py" "$R/gpurun_out" "${TAG}${SEM}" c2 1000000 "$TAG" | tee "$R/gpurun_out/pmc_summary_${TAG}${SEM}.txt"
+  done
   for CTR in FETCH_SIZE WRITE_SIZE; do
-    OUT="$R/gpurun_out/pmc_${TAG}_$CTR"
+    OUT="$R/gpurun_out/pmc_${TAG}c4_$CTR"
     timeout -k 10 300 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$OUT" -- \
-        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-sustained \
-        > /dev/null 2> "$R/gpurun_out/pmc_${TAG}_$CTR.err"; rc=$?
-    echo "pmc $CTR exit=$rc"
+        python "$R/bench.py" --config c4 --steps 3 --warmup 1 --only-timed > /dev/null 2> "$OUT.err"; rc=$?
+    echo "pmc c4 $CTR exit=$rc"
     ok $rc || exit 1
   done
-  python "$R/tools/summarize_pmc.py" "$R/gpurun_out" "$TAG" | tee "$R/gpurun_out/pmc_summary_$TAG.txt"
+  python "$R/tools/summarize_pmc.py" "$R/gpurun_out" "${TAG}c4" c4 4000000 "$TAG" | tee "$R/gpurun_out/pmc_summary_${TAG}c4.txt"
+  # where do the wave-cycles go (SQ counters), C2 two_pass and C4 (Heston generator)
+  for CFG in c2 c4; do
+    OUT="$R/gpurun_out/pmc_sq_${TAG}$CFG"
+    timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
+        --kernel-trace --output-format csv -d "$OUT" -- python "$R/bench.py" --config $CFG --steps 5 --warmup 10 --only-timed \
+        > /dev/null 2> "$OUT.err"; rc=$?
+    echo "pmc sq $CFG exit=$rc"
+    ok $rc || exit 1
+    python - "$OUT" <<'PY' | tee "$R/gpurun_out/pmc_sq_summary_${TAG}$CFG.txt"
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+for k, d in acc.items():
+    if "omc::" not in k: continue
+    print(k)
+    for c, (s, n) in sorted(d.items()):
+        print(f"   {c:24s} {s / n:16.0f}   ({n} dispatches)")
+PY
+  done
+  ;;
+persist)
+  timeout -k 10 120 python tools/persist_stamps.py 1000000 > gpurun_out/persist_stamps_$TAG.txt 2>&1
+  timeout -k 10 120 python tools/persist_stamps.py 8000000 >> gpurun_out/persist_stamps_$TAG.txt 2>&1
+  timeout -k 10 120 python tools/step_stamps.py 1000000 > gpurun_out/step_stamps_$TAG.txt 2>&1
+  cat gpurun_out/persist_stamps_$TAG.txt gpurun_out/step_stamps_$TAG.txt
   ;;
 esac

@@ -6,7 +6,7 @@ FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half 
 of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane
 streaming stores.  Counters are collected in separate passes (TCC slots).
 
-usage: summarize_pmc.py <gpurun_out dir> <tag>   -> prints a table and writes
+usage: summarize_pmc.py <gpurun_out dir> <tag> [config paths_per_gpu round]  -> prints a table and writes
        <dir>/pmc_traffic_<tag>.json (copy to profiles/pmc_traffic.json to have bench.py report it)
 """
 import csv
@@ -37,6 +37,8 @@ def main():
     names = sorted(set(fetch) | set(write))
     out = {"units": "bytes per dispatch; read = 2 x FETCH_SIZE x 1024 (gfx950 correction), "
                     "write = WRITE_SIZE x 1024", "kernels": {}}
+    if len(sys.argv) > 5:
+        out.update(config=sys.argv[3], paths_per_gpu=int(sys.argv[4]), round=sys.argv[5])
     print(f"{'kernel':58s} {'calls':>6s} {'read MB':>10s} {'write MB':>10s}")
     for n in names:
         f, nf = fetch.get(n, (0.0, 0))
@@ -54,6 +56,7 @@ def main():
     out["lsm_two_pass_bytes_per_pricing"] = tot(["lsm_pass1_kernel", "lsm_reduce_pass1_kernel",
                                                  "lsm_solve_all_kernel", "lsm_pass2_kernel",
                                                  "lsm_finalize_kernel"]) or None
+    out["lsm_step_kernel_bytes_per_launch"] = tot(["lsm_step_ind_kernel", "lsm_step_kernel"]) or None
     json.dump(out, open(os.path.join(base, f"pmc_traffic_{tag}.json"), "w"), indent=1)
     print(json.dumps({a: b for a, b in out.items() if a != "kernels"}, indent=1))
 
