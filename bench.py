@@ -372,7 +372,7 @@ def main():
         kernels.append(rf("lsm_step_kernel", step_bytes_per_path(a.semantics) * M, ms_lsm / N, launches=N))
     # HBM bytes per launch are PMC counters: they exist only in a rocprofv3 --pmc pass (two separate
     # passes, FETCH_SIZE doubled per the gfx950 note), so an ordinary run quotes the committed summary
-    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    prof = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.config}.json")
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof))
@@ -383,8 +383,8 @@ def main():
                 for name, v in pk.items():
                     if stem in name.replace("_ind_", "_") and same:
                         k["traffic"] = v["read_bytes"] + v["write_bytes"]
-                        k["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
-                                              f"{pj.get('round', 'r01')}; not measured in this run)"
+                        k["traffic_source"] = f"profiles/pmc_traffic_{a.config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
+                                              f"passes, {pj.get('round', 'r01')}; not measured in this run)"
         except Exception:
             pass
     dominant = max(kernels, key=lambda k: k["ms_per_launch"] * k["launches_per_pricing"])
