@@ -87,16 +87,25 @@ __device__ __forceinline__ void gbm_paths_body(const PathArgs& g)
 // of the numerics contract that the test-side CPU restatement follows as well.  What the
 // two partners share is computed once: w2 = rho z1 + rho2 z2, tw = xi sqrt(dt) w2, az = log2(e) sqrt(dt) z1
 // -- the partner's are their exact negations -- so a path costs max, sqrt, sub, 4 fma, exp2, mul (, max).
+// max(x, lo) as ONE v_max_f32: fmaxf() costs two instructions here (hipcc first quiets a possible
+// signalling NaN with v_max x, x, x; it also folds v_med3(x, lo, inf) back into that pair)
+__device__ __forceinline__ float floor_at(float x, float lo)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo));
+    return r;
+}
+
 template <int SCHEME>
 __device__ __forceinline__ void heston_path_step(const HestonC& c, float tw, float az, float& s, float& v)
 {
-    const float vp = fmaxf(v, 0.0f);
+    const float vp = floor_at(v, 0.0f);
     const float sq = __builtin_amdgcn_sqrtf(vp);
     const float base = SCHEME ? v : vp;
     const float vn = __builtin_fmaf(sq, tw, __builtin_fmaf(c.kdt, c.theta - vp, base));
     const float arg = __builtin_fmaf(sq, az, __builtin_fmaf(-c.hdt_l2, vp, c.rdt_l2));
     s = s * fast_exp2(arg);
-    v = SCHEME ? vn : fmaxf(vn, 0.0f);
+    v = SCHEME ? vn : floor_at(vn, 0.0f);
 }
 
 template <int SCHEME>
@@ -108,18 +117,18 @@ __device__ __forceinline__ void heston_pair_step(const HestonC& c, float z1, flo
         // before use and at store, ARITHMETIC Euler for S (S may cross zero; so be it).
         const float w2 = __builtin_fmaf(c.rho, z1, c.rho2 * z2);
         {
-            const float vp = fmaxf(v, 1e-8f);
+            const float vp = floor_at(v, 1e-8f);
             const float sq = __builtin_amdgcn_sqrtf(vp);
             const float vn = __builtin_fmaf(c.xi_sqdt * sq, w2, __builtin_fmaf(c.kdt, c.theta - vp, vp));
             s = __builtin_fmaf(s, __builtin_fmaf(sq * c.sqdt, z1, c.rdt), s);
-            v = fmaxf(vn, 1e-8f);
+            v = floor_at(vn, 1e-8f);
         }
         {
-            const float vp = fmaxf(vb, 1e-8f);
+            const float vp = floor_at(vb, 1e-8f);
             const float sq = __builtin_amdgcn_sqrtf(vp);
             const float vn = __builtin_fmaf(c.xi_sqdt * sq, -w2, __builtin_fmaf(c.kdt, c.theta - vp, vp));
             sa = __builtin_fmaf(sa, __builtin_fmaf(sq * c.sqdt, -z1, c.rdt), sa);
-            vb = fmaxf(vn, 1e-8f);
+            vb = floor_at(vn, 1e-8f);
         }
         return;
     } else {
