@@ -940,6 +940,275 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
     }
 }
 
+// ------------------------------------------------------------------ tile-per-workgroup trainer
+// Small minibatches -- the reference's own batch of 256 rows is 8 tiles -- leave the tile-per-wave kernel
+// with 8 waves on the whole chip, each running ~390 float32 MFMAs of 64 cycles in sequence (65 us per
+// step at 3 x 128).  Here one 32-row tile is a WORKGROUP of W = H / 32 waves, one per SIMD: wave w owns
+// units 32w .. 32w + 31 of every hidden layer, so each wave issues a quarter of the MFMAs and the four
+// SIMDs of the CU work on the tile together.  A layer's activations (and, going back, dZ) are exchanged
+// through LDS in the swizzled [unit][32 rows] layout of the other trainers: the forward / dH products
+// read them as B operands one value per lane ([unit][row c]: a permutation of a row, conflict-free),
+// the weight-gradient products as 16-byte row quads.  Weights come from global memory / L2 (canonical
+// layout for W^T dZ, the transposed copy for the forward products: both coalesced over the 32 units a
+// wave owns), one group of 16 k-steps ahead of the MFMAs that use them.  Every gradient entry is written
+// exactly once per tile (no accumulation across launches): ntiles <= kMlpMaxGroups workgroups, one
+// partial each, summed by the Adam kernel in index order -- bitwise reproducible like the others.
+struct MlpQuadArgs {
+    const float* data;
+    const float* params;  // canonical layout, mlp_params_of(H, L)
+    const float* wt;      // (L-1) x [H][H]: connection j transposed, wt_j[k][i] = W_j[i][k]
+    float* partial;       // [ntiles][pstride]
+    int64_t row0, nrows;
+    Shuffle shuf;
+    int ntiles, pstride;
+    float two_over_b, inv_keep;
+    uint32_t keep16, step, k0, k1;
+};
+
+// ReLU + inverted dropout on ONE 32-unit tile's pre-activations (16 per lane), in place; same bit budget as
+// relu_dropout (16 bits per unit from a multiply-with-carry stream seeded by one Philox block)
+__device__ __forceinline__ void relu_dropout_1(v16f& z, uint32_t row, uint32_t step, uint32_t tag, uint32_t keep16,
+                                               float inv_keep, uint32_t k0, uint32_t k1)
+{
+    if (keep16 >= 65536u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = fmaxf(z[r], 0.0f);
+        return;
+    }
+    const U4 o = philox4x32_10(row, step, tag, 0x4d4c5134u, k0, k1);
+    uint64_t st = ((uint64_t)(o.x ^ o.z) << 32) | ((o.y ^ o.w) | 1u);
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+        st = (uint64_t)4294957665u * (uint32_t)st + (st >> 32);
+        const uint32_t w = (uint32_t)st;
+        const float v0 = z[e], v1 = z[e + 1];
+        z[e] = (v0 > 0.0f && (w & 0xffffu) < keep16) ? v0 * inv_keep : 0.0f;
+        z[e + 1] = (v1 > 0.0f && (w >> 16) < keep16) ? v1 * inv_keep : 0.0f;
+    }
+}
+
+template <int H, int L>
+__global__ __launch_bounds__(H * 2) void mlp_train_quad_kernel(MlpQuadArgs a)
+{
+    constexpr int W = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H;
+    __shared__ float sAct[L][H * 32];  // H_j, swizzled [unit][32 rows]
+    __shared__ float sDz[H * 32];      // dZ_j of the layer being back-propagated
+    __shared__ float sX[8 * 32];       // inputs [in][row] (row 7 = the bias column of ones)
+    __shared__ float sO[W * 32];       // per-wave partial outputs
+    __shared__ float sD[32];           // d(loss)/d(out) per row
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    auto rho = [&](int r) { return (r >> 2) * 8 + 4 * h + (r & 3); };  // tile row of accumulator register r
+    const int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    float* out = a.partial + (size_t)tile * a.pstride;
+    const float* Wo = a.params + H * 8 + (L - 1) * CONN;
+    const int64_t row = (int64_t)tile * 32 + c;
+    const bool live = row < a.nrows;
+    float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live) x = reinterpret_cast<const float4*>(a.data + shuffle_index(a.shuf, (uint64_t)(a.row0 + row)) * 8)[h];
+    float y = x.w;
+    if (h == 1) x.w = 1.0f;
+    y = __shfl(y, c + 32, 64);
+    if (w == 0) {
+        sX[(4 * h + 0) * 32 + c] = x.x;
+        sX[(4 * h + 1) * 32 + c] = x.y;
+        sX[(4 * h + 2) * 32 + c] = x.z;
+        sX[(4 * h + 3) * 32 + c] = x.w;
+    }
+
+    // ---- layer 0: own 32 units x 8 inputs
+    v16f hreg[L];
+    {
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float4 wv = *reinterpret_cast<const float4*>(a.params + (32 * w + c) * 8 + 4 * h);
+        acc = mfma(wv.x, x.x, acc);
+        acc = mfma(wv.y, x.y, acc);
+        acc = mfma(wv.z, x.z, acc);
+        acc = mfma(wv.w, x.w, acc);
+        relu_dropout_1(acc, (uint32_t)row, a.step, 0x100u + 0x10u * (uint32_t)w + (uint32_t)h, a.keep16, a.inv_keep, a.k0,
+                       a.k1);
+        hreg[0] = acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sAct[0][st_idx(32 * w + rho(r), c)] = acc[r];
+    }
+    __syncthreads();
+
+    // 16 k-steps of one 32-unit block kt: A from global memory (row of `Wsrc` = k unit, 32 own units contiguous),
+    // B from the swizzled LDS image `Bsrc`; the next block's weights are requested before this block's MFMAs
+    auto product = [&](const float* Wsrc, const float* Bsrc, v16f acc) {
+        float wa[2][16];
+        auto fetch = [&](int kt, float (&dst)[16]) {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) dst[s2] = Wsrc[(size_t)(32 * kt + rho(s2)) * H + 32 * w + c];
+        };
+        fetch(0, wa[0]);
+#pragma unroll
+        for (int kt = 0; kt < W; ++kt) {
+            if (kt + 1 < W) fetch(kt + 1, wa[(kt + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            float b[16];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) b[s2] = Bsrc[st_idx(32 * kt + rho(s2), c)];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) acc = mfma(wa[kt & 1][s2], b[s2], acc);
+        }
+        return acc;
+    };
+
+    // ---- layers 1 .. L-1
+#pragma unroll
+    for (int j = 1; j < L; ++j) {
+        const float* bj = a.params + H * 8 + (size_t)(j - 1) * CONN + H * H;
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bj[32 * w + rho(r)];
+        acc = product(a.wt + (size_t)(j - 1) * H * H, sAct[j - 1], acc);
+        relu_dropout_1(acc, (uint32_t)row, a.step, 0x100u * (uint32_t)(j + 1) + 0x10u * (uint32_t)w + (uint32_t)h, a.keep16,
+                       a.inv_keep, a.k0, a.k1);
+        hreg[j] = acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sAct[j][st_idx(32 * w + rho(r), c)] = acc[r];
+        __syncthreads();
+    }
+
+    // ---- output, loss, d(loss)/d(out): every wave ends with the same numbers
+    float wo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wo[r] = Wo[32 * w + rho(r)];
+    {
+        float o = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o = __builtin_fmaf(wo[r], hreg[L - 1][r], o);
+        o += __shfl_xor(o, 32, 64);
+        if (h == 0) sO[w * 32 + c] = o;
+    }
+    __syncthreads();
+    float o = Wo[H];
+#pragma unroll
+    for (int ww = 0; ww < W; ++ww) o += sO[ww * 32 + c];
+    const float diff = live ? o - y : 0.0f;
+    const float dout = diff * a.two_over_b;
+    if (w == 0 && h == 0) sD[c] = dout;
+    v16f dz;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dz[r] = hreg[L - 1][r] > 0.0f ? wo[r] * dout * a.inv_keep : 0.0f;
+    __syncthreads();
+
+    // swizzled 16-byte read of rows 16h + 4q .. + 3 of `unit`
+    auto quad = [&](const float* base, int unit, int q) {
+        return *reinterpret_cast<const float4*>(base + unit * 32 + ((16 * h + 4 * q) ^ (((unit >> 1) & 7) << 2)));
+    };
+
+    // output-weight gradient of the own units: sum over rows of dout * H_{L-1}
+    {
+        float gws = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 e = quad(sAct[L - 1], 32 * w + c, q);
+            const float4 d = *reinterpret_cast<const float4*>(sD + 16 * h + 4 * q);
+            gws = __builtin_fmaf(e.x, d.x, gws);
+            gws = __builtin_fmaf(e.y, d.y, gws);
+            gws = __builtin_fmaf(e.z, d.z, gws);
+            gws = __builtin_fmaf(e.w, d.w, gws);
+        }
+        gws += __shfl_xor(gws, 32, 64);
+        if (h == 0) out[H * 8 + (L - 1) * CONN + 32 * w + c] = gws;
+    }
+
+#pragma unroll
+    for (int j = L - 1; j >= 1; --j) {
+        const float* Wj = a.params + H * 8 + (size_t)(j - 1) * CONN;
+        float* gWj = out + H * 8 + (size_t)(j - 1) * CONN;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sDz[st_idx(32 * w + rho(r), c)] = dz[r];
+        __syncthreads();
+        // ---- gW_j rows = own units, all H columns: contraction over the 32 batch rows
+        {
+            v16f acc[W];
+#pragma unroll
+            for (int nt = 0; nt < W; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+            float gbs = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 ea = quad(sDz, 32 * w + c, q);
+                const float av[4] = {ea.x, ea.y, ea.z, ea.w};
+                float bv[W][4];
+#pragma unroll
+                for (int nt = 0; nt < W; ++nt) {
+                    const float4 eb = quad(sAct[j - 1], 32 * nt + c, q);
+                    bv[nt][0] = eb.x; bv[nt][1] = eb.y; bv[nt][2] = eb.z; bv[nt][3] = eb.w;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    gbs += av[jj];
+#pragma unroll
+                    for (int nt = 0; nt < W; ++nt) acc[nt] = mfma(av[jj], bv[nt][jj], acc[nt]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < W; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gWj[(size_t)(32 * w + rho(r)) * H + 32 * nt + c] = acc[nt][r];
+            gbs += __shfl_xor(gbs, 32, 64);
+            if (h == 0) gWj[H * H + 32 * w + c] = gbs;
+        }
+        // ---- dH_{j-1} of the own units = W_j^T dZ_j, then through the ReLU / dropout mask of H_{j-1}
+        {
+            v16f d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+            d = product(Wj, sDz, d);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[r] = hreg[j - 1][r] > 0.0f ? d[r] * a.inv_keep : 0.0f;
+        }
+        __syncthreads();  // every wave is done with sDz
+    }
+
+    // ---- gW1 (own units x 8 inputs, bias in column 7): 16 rows per half-wave on the vector unit
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sDz[st_idx(32 * w + rho(r), c)] = dz[r];
+    __syncthreads();
+    {
+        float g[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 e = quad(sDz, 32 * w + c, q);
+            const float ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (int in = 0; in < 8; ++in) {
+                const float4 xv = *reinterpret_cast<const float4*>(sX + in * 32 + 16 * h + 4 * q);
+                g[in] = __builtin_fmaf(ev[0], xv.x, g[in]);
+                g[in] = __builtin_fmaf(ev[1], xv.y, g[in]);
+                g[in] = __builtin_fmaf(ev[2], xv.z, g[in]);
+                g[in] = __builtin_fmaf(ev[3], xv.w, g[in]);
+            }
+        }
+#pragma unroll
+        for (int in = 0; in < 8; ++in) g[in] += __shfl_xor(g[in], 32, 64);
+        if (h == 0) {
+            float4* po = reinterpret_cast<float4*>(out + (32 * w + c) * 8);
+            po[0] = make_float4(g[0], g[1], g[2], g[3]);
+            po[1] = make_float4(g[4], g[5], g[6], g[7]);
+        }
+    }
+    if (w == 0) {
+        float gbo = h == 0 ? dout : 0.0f, loss = h == 0 ? diff * diff : 0.0f;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            gbo += __shfl_xor(gbo, m, 64);
+            loss += __shfl_xor(loss, m, 64);
+        }
+        if (lane == 0) {
+            out[NP - 1] = gbo;
+            out[NP] = loss;
+        }
+    }
+}
+
 // wt_j[k][i] = W_j[i][k] for the L-1 connections (start of an epoch; Adam keeps it current)
 __global__ __launch_bounds__(256) void mlp_transpose_kernel(const float* params, float* wt, int H, int L)
 {
@@ -1229,12 +1498,15 @@ __global__ __launch_bounds__(256) void mlp_shuffle_kernel(Shuffle s, int64_t* ou
 // Which kernel trains (hidden, layers) at this minibatch size: 1 = workgroup kernel (64 units,
 // weights in LDS; large batches), 2 = tile-per-wave kernel (64 units at small batches, 128 units at
 // any batch), 0 = neither.
+// 1: workgroup kernel (64 units, large batches); 2: tile-per-wave kernel; 3: tile-per-workgroup kernel
+// (minibatches of at most kMlpMaxGroups tiles: the reference's batch of 256 rows is 8)
 int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
 {
     if (layers != 2 && layers != 3) return 0;
     const int64_t tiles = (batch + 31) / 32;
-    if (hidden == 64) return tiles <= 32 ? 2 : 1;
-    if (hidden == 128) return 2;
+    static const int quad = getenv("OMC_MLP_QUAD") ? atoi(getenv("OMC_MLP_QUAD")) : 1;
+    if (hidden == 64) return tiles <= 32 ? (quad ? 3 : 2) : 1;
+    if (hidden == 128) return (quad && tiles <= kMlpMaxGroups) ? 3 : 2;
     return 0;
 }
 
@@ -1248,7 +1520,7 @@ size_t mlp_partial_bytes(int hidden, int layers, int64_t batch)
 {
     const int choice = mlp_train_kernel_choice(hidden, layers, batch);
     if (choice == 1) return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride3;
-    if (choice == 2) {
+    if (choice == 2 || choice == 3) {
         const int64_t tiles = (batch + 31) / 32, cap = tile_waves_max(hidden);
         return sizeof(float) * (size_t)(tiles < cap ? tiles : cap) * tile_pstride(hidden, layers);
     }
@@ -1383,6 +1655,56 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
     return hipGetLastError();
 }
 
+// minibatches of at most kMlpMaxGroups tiles: one workgroup per tile (mlp_train_quad_kernel)
+template <int H, int L>
+static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
+{
+    hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
+    const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
+    int64_t step = t.first_step;
+    for (int64_t o = 0; o < t.nrows; o += t.batch) {
+        const int64_t nb = (t.nrows - o < t.batch) ? t.nrows - o : t.batch;
+        ++step;
+        MlpQuadArgs a;
+        a.data = t.data;
+        a.params = t.params;
+        a.wt = t.wt;
+        a.partial = t.partial;
+        a.row0 = o;
+        a.nrows = nb;
+        a.shuf = sh;
+        a.ntiles = (int)((nb + 31) / 32);
+        a.pstride = tile_pstride(H, L);
+        a.two_over_b = (float)(2.0 / (double)nb);
+        a.keep16 = t.dropout > 0.0 ? (uint32_t)llround((1.0 - t.dropout) * 65536.0) : 65536u;
+        a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
+        a.step = (uint32_t)step;
+        a.k0 = (uint32_t)t.seed;
+        a.k1 = (uint32_t)(t.seed >> 32);
+        hipLaunchKernelGGL((mlp_train_quad_kernel<H, L>), dim3(a.ntiles), dim3(H * 2), 0, st, a);
+        MlpAdamArgs b;
+        b.params = t.params;
+        b.m = t.adam_m;
+        b.v = t.adam_v;
+        b.partial = t.partial;
+        b.loss_acc = t.loss_acc;
+        b.nparts = a.ntiles;
+        b.nparams = mlp_params_of(H, L);
+        b.stride = a.pstride;
+        b.wt = t.wt; b.H = H; b.L = L;
+        b.inv_b = (float)(1.0 / (double)nb);
+        const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
+        b.lr_t = (float)(t.lr / bc1);
+        b.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        b.beta1 = (float)t.beta1;
+        b.beta2 = (float)t.beta2;
+        b.eps = (float)t.eps;
+        b.wd = (float)t.weight_decay;
+        hipLaunchKernelGGL(mlp_adam_kernel, dim3((mlp_params_of(H, L) + 16) / 16), dim3(256), 0, st, b);
+    }
+    return hipGetLastError();
+}
+
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
 {
     const int choice = mlp_train_kernel_choice(t.hidden, t.layers, t.batch);
@@ -1390,6 +1712,10 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
     if (choice == 2) {
         if (t.hidden == 64) return t.layers == 2 ? tile_steps<64, 2>(st, t) : tile_steps<64, 3>(st, t);
         return t.layers == 2 ? tile_steps<128, 2>(st, t) : tile_steps<128, 3>(st, t);
+    }
+    if (choice == 3) {
+        if (t.hidden == 64) return t.layers == 2 ? quad_steps<64, 2>(st, t) : quad_steps<64, 3>(st, t);
+        return t.layers == 2 ? quad_steps<128, 2>(st, t) : quad_steps<128, 3>(st, t);
     }
     return hipErrorInvalidValue;
 }
