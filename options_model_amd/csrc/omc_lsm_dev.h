@@ -480,22 +480,37 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         int cnt = 0;
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
+            // the VEC paths of a tile advance together, stage by stage: VEC independent dependency chains
+            // (convert -> u -> select -> u^2 -> sums) instead of one, and consecutive accumulations go to
+            // different accumulators -- the float64 pipe is 4 cycles deep per issue and a lone chain stalls it
+            // Masking by multiplication: m = 1.0 in the money, 0.0 otherwise.  u*m and p*m are exact, so the
+            // sums are those of the selected values bit for bit (a -0.0 added to a sum changes nothing), and
+            // one 32-bit select + one multiply replace the four selects of (u, p) -- on this chip a
+            // v_cndmask with an SGPR-pair mask costs as much as a float64 multiply (profiles/r02c_ubench.txt).
+            // p needs no masking of its own except in its plain sum: u*m already zeroes u p and u^2 p.
+            double u[VEC], m[VEC], u2[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) u[v] = fma((double)buf[k][v], invK, -1.0);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const float sf = buf[k][v];
                 const bool itm = IS_PUT ? sf < thrk[k] : sf > thrk[k];
                 cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(itm));
-                const double u0 = fma((double)sf, invK, -1.0);
-                const double u = itm ? u0 : 0.0;
-                const double p = itm ? pN[k][v] : 0.0;
-                const double u2 = u * u;
-                acc[1] += u;
-                acc[2] += u2;
-                acc[3] = fma(u2, u, acc[3]);
-                acc[4] = fma(u2, u2, acc[4]);
-                acc[5] += p;
-                acc[6] = fma(u, p, acc[6]);
-                acc[7] = fma(u2, p, acc[7]);
+                m[v] = itm ? 1.0 : 0.0;
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) u[v] *= m[v];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) u2[v] = u[v] * u[v];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                acc[1] += u[v];
+                acc[2] += u2[v];
+                acc[3] = fma(u2[v], u[v], acc[3]);
+                acc[4] = fma(u2[v], u2[v], acc[4]);
+                acc[5] = fma(pN[k][v], m[v], acc[5]);
+                acc[6] = fma(u[v], pN[k][v], acc[6]);
+                acc[7] = fma(u2[v], pN[k][v], acc[7]);
             }
         }
         const double d = shD[wave][t - t0];
