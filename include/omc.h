@@ -88,7 +88,8 @@ int omc_memcpy_h2d(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
 int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* knobs: "gbm_vec" / "heston_vec" (pairs per thread: 1,2,4; 0 = auto), "world_size" (ranks behind
  * the all-reduce hook, see below), "step_graph" (1 / 0: replay the per-step sweep as one captured HIP
- * graph or launch its kernels one by one; -1 = default, on), "step_persistent" (1: run the per-step
+ * graph or launch its kernels one by one; -1 = default, off: same speed at 1M x 252, and a capture per new
+ * geometry costs milliseconds), "step_persistent" (1: run the per-step
  * reference sweep as ONE persistent launch with an in-launch exchange of the partial moments --
  * csrc/omc_lsm_persist.hip; bounded spins, falls back to launches if its workgroups cannot all be
  * resident; default 0: measured slower than one launch per step on MI355X) */
