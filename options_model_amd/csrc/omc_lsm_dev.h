@@ -411,7 +411,11 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     const int64_t tg = (int64_t)blockIdx.x * (kBlock / 64) + wave;
     if (tg >= a.ntiles) return;  // whole wave leaves; no workgroup barrier below
     const int64_t base = tg * (64 * VEC * TPW) + (int64_t)lane * VEC;
-    const int t0 = 1 + blockIdx.y * a.tchunk;
+    // Time chunks are visited LATEST FIRST (workgroups are dispatched in blockIdx order): the generator
+    // has just written the whole matrix row by row for all paths at once, so what can still be in the 256 MB
+    // Infinity Cache when this kernel starts are the last ~60 rows (measured effect: small, 0.198 -> 0.190 ms
+    // for the load stream alone).  Which chunk a workgroup takes changes no sum: partials are per (step, tile).
+    const int t0 = 1 + ((int)gridDim.y - 1 - (int)blockIdx.y) * a.tchunk;
     const int t1 = min(t0 + a.tchunk, a.N);
     if (t0 >= t1) return;
     const double K = a.K, invK = a.invK;

@@ -17,39 +17,55 @@ import tempfile
 import time
 
 
-def _path(tag: str | None = None) -> str:
-    base = os.environ.get("OMC_RDZV_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+def _dirs() -> list:
+    """Where the file may live, in order of preference; rank 0 takes the first one it can write to and
+    the other ranks look in all of them."""
+    out = []
+    for d in (os.environ.get("OMC_RDZV_DIR"), "/dev/shm", tempfile.gettempdir()):
+        if d and os.path.isdir(d) and d not in out:
+            out.append(d)
+    return out
+
+
+def _name(tag: str | None = None) -> str:
     if tag is None:
         tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-    return os.path.join(base, f"omc_rccl_uid_{tag}")
+    return f"omc_rccl_uid_{tag}"
 
 
 def publish(payload: bytes, tag: str | None = None) -> str:
     """Rank 0: make `payload` visible to the other ranks.  Returns the path (pass it to retire())."""
-    path = _path(tag)
-    tmp = f"{path}.{os.getpid()}.tmp"
-    with open(tmp, "wb") as f:
-        f.write(payload)
-        f.flush()
-        os.fsync(f.fileno())
-    os.replace(tmp, path)  # atomic: a reader sees the whole payload or no file
-    return path
+    last = None
+    for d in _dirs():
+        path = os.path.join(d, _name(tag))
+        tmp = f"{path}.{os.getpid()}.tmp"
+        try:
+            with open(tmp, "wb") as f:
+                f.write(payload)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, path)  # atomic: a reader sees the whole payload or no file
+            return path
+        except OSError as e:  # read-only or full: try the next directory
+            last = e
+    raise OSError(f"no writable rendezvous directory among {_dirs()}: {last}")
 
 
 def fetch(nbytes: int, tag: str | None = None, timeout_s: float = 120.0) -> bytes:
     """Ranks > 0: wait for rank 0's payload.  Raises TimeoutError -- never hangs the job."""
-    path = _path(tag)
+    paths = [os.path.join(d, _name(tag)) for d in _dirs()]
     t0 = time.monotonic()
     while True:
-        try:
-            with open(path, "rb") as f:
-                data = f.read()
-            if len(data) == nbytes:
-                return data
-        except FileNotFoundError:
-            pass
+        for path in paths:
+            try:
+                with open(path, "rb") as f:
+                    data = f.read()
+                if len(data) == nbytes:
+                    return data
+            except OSError:
+                pass
         if time.monotonic() - t0 > timeout_s:
-            raise TimeoutError(f"rank 0 never published {path} within {timeout_s:.0f} s")
+            raise TimeoutError(f"rank 0 never published {paths[0]} within {timeout_s:.0f} s")
         time.sleep(0.005)
 
 
