@@ -393,6 +393,12 @@ def main():
     line["roofline_kernels"] = kernels
     line["roofline_lsm_total"] = {"bytes_per_pricing": b_lsm, "ms_per_pricing": ms_lsm,
                                   "achieved": b_lsm / (ms_lsm * 1e-3) / 1e9 if ms_lsm > 0 else 0.0, "unit": "GB/s"}
+    # the whole pricing against the HBM roofline: the per-kernel split above is skewed by the Infinity Cache
+    # (the generator "finishes" with up to 256 MB of its rows still dirty on chip; their write-back lands in
+    # the kernel that runs next -- DESIGN.md section 8.3), the total is not
+    whole = (b_gen + b_lsm) / (1e-3 * 1e3 * elapsed / a.steps) / 1e9
+    line["roofline_whole_pricing"] = {"bound": "hbm", "bytes_per_pricing": b_gen + b_lsm, "achieved": whole,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": whole / HBM_PEAK_GBS}
 
     # ---- the per-timestep kernel north_star specifies, as a first-class number: the reference per-step
     # flow on the same workload, HIP-event time of its N launches (boundaries included) / N
