@@ -135,7 +135,7 @@ def launch_ranks(n: int) -> int:
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMC_BENCH_RANK_PROCESS="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
@@ -396,7 +396,7 @@ def main():
     # the whole pricing against the HBM roofline: the per-kernel split above is skewed by the Infinity Cache
     # (the generator "finishes" with up to 256 MB of its rows still dirty on chip; their write-back lands in
     # the kernel that runs next -- DESIGN.md section 8.3), the total is not
-    whole = (b_gen + b_lsm) / (1e-3 * 1e3 * elapsed / a.steps) / 1e9
+    whole = (b_gen + b_lsm) / (elapsed / a.steps) / 1e9
     line["roofline_whole_pricing"] = {"bound": "hbm", "bytes_per_pricing": b_gen + b_lsm, "achieved": whole,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": whole / HBM_PEAK_GBS}
 
