@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OMC_ABI_VERSION 3
+#define OMC_ABI_VERSION 4
 
 typedef struct omc_ctx omc_ctx;
 
@@ -154,6 +154,29 @@ int omc_lsm_apply_values(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_pat
                          double K, double r, double T, int is_put, int semantics, const float* cont,
                          int64_t ldc, omc_result* res, float* sx_out, int32_t* tex_out);
 
+/* The regressor the reference's v1 / v2 pricers run: a FRESH ContNet(1 -> nn_hidden -> nn_hidden -> 1) at
+ * every time step (Options_model.py:14-25,112-151; options_model_2.py:283-312, whose constructor arguments
+ * nn_hidden / nn_epochs / nn_lr these are): input = the step's regression set (in the money, not yet
+ * exercised) standardised by its own mean / population std (std 0: centred only), target = the set's
+ * cash-flows valued at the step (not normalised), nn_epochs full-batch Adam(lr = nn_lr) steps on the mean
+ * squared error, exercise where payoff > net(input) (strict), sticky mask, cash-flows valued at t = 1.
+ * Initialisation is torch's nn.Linear default (uniform +-1/sqrt(fan_in), weights and biases) drawn from
+ * Philox keyed by (nn_seed, t): the reference's v1 never seeds torch and its v2 seeds it once per pricing, so
+ * individual nets cannot be matched, only the distribution of prices.  nn_hidden 1 .. 128; one GPU (-10 on a
+ * context with a communicator or hook).  res->sum_nitm = training rows summed over steps.
+ * omc_lsm_contnet works on a device path matrix [n_steps+1][ld]; omc_price_american_contnet generates the
+ * paths of `p` first (p->semantics must be OMC_SEM_REFERENCE). */
+int omc_lsm_contnet(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r,
+                    double T, int is_put, int nn_hidden, int nn_epochs, double nn_lr, uint64_t nn_seed,
+                    omc_result* res, float* sx_out, int32_t* tex_out);
+int omc_price_american_contnet(omc_ctx* ctx, const omc_params* p, int nn_hidden, int nn_epochs, double nn_lr,
+                               uint64_t nn_seed, omc_result* res);
+/* the initial parameters of step t's net (host float32 [n], n = 8H + H*H + 2H + 1 with H = nn_hidden rounded
+ * up to 32 / 64 / 128): layer 0 as [unit][8] = {weight, 0 x 6, bias}, layer 1 as [out][in] then its biases,
+ * the output weights, the output bias; entries of units >= nn_hidden are zero.  For tests and for seeding a
+ * torch ContNet with the same start. */
+int omc_contnet_init_params(omc_ctx* ctx, int nn_hidden, int t, uint64_t nn_seed, float* params_out, int n);
+
 /* multi-GPU: paths shard by antithetic pair, only regression moments and the final sums
  * cross GPUs.  `hook(user, dptr, count)` must all-reduce (sum) `count` DEVICE doubles in place,
  * ordered on the context's stream (RCCL via torch.distributed on the host side).  It is called
@@ -254,7 +277,8 @@ int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
 int omc_nn_feature_stats(omc_ctx* ctx, const double* x, const int32_t* t, const double* y,
                          int64_t n_rows, double T, double dt, double* out16);
 /* 1 if omc_mlp_train_epoch covers this network shape at this minibatch size: hidden 64 or 128 (the
- * reference's default width) with 2 or 3 hidden layers, any batch. */
+ * reference's default width) with 2 or 3 hidden layers, any batch; also 32 units x 2 layers (the width
+ * the per-step ContNet flow trains at, omc_lsm_contnet). */
 int omc_mlp_train_supported(int hidden, int layers, int64_t batch);
 int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t batch, int hidden,
                         int layers, float* params, float* adam_m, float* adam_v, int64_t* step,

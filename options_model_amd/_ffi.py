@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
 MODELS = {"gbm": 0, "heston": 1}
@@ -72,6 +72,9 @@ SIGNATURES = {
     "omc_lsm_poly": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, C.POINTER(Result), _P, _P, _P]),
     "omc_lsm_apply_frozen": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _P, C.POINTER(Result), _P, _P]),
     "omc_lsm_apply_values": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _P, _I64, C.POINTER(Result), _P, _P]),
+    "omc_lsm_contnet": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _I, _D, _U64, C.POINTER(Result), _P, _P]),
+    "omc_price_american_contnet": (C.c_int, [_P, C.POINTER(Params), _I, _I, _D, _U64, C.POINTER(Result)]),
+    "omc_contnet_init_params": (C.c_int, [_P, _I, _I, _U64, _P, _I]),
     "omc_set_allreduce_hook": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "omc_comm_unique_id": (C.c_int, [_P, _SZ]),
     "omc_comm_init": (C.c_int, [_P, _I, _I, _P, _SZ]),
@@ -381,6 +384,42 @@ class Context:
         d = res.as_dict()
         d.update(sx=sx, tex=tex)
         return d
+
+    def lsm_contnet(self, S, K, r, T, is_put, nn_hidden=32, nn_epochs=10, nn_lr=1e-3, nn_seed=0, want_state=True):
+        """The reference's v1 / v2 per-step flow (fresh ContNet per step) on a device path matrix."""
+        N, M = S.shape[0] - 1, S.shape[1]
+        res = Result()
+        sx = np.zeros(M, np.float32) if want_state else None
+        tex = np.zeros(M, np.int32) if want_state else None
+        _check(self.lib, self.lib.omc_lsm_contnet(self.handle, S.ptr, M, M, N, K, r, T, int(is_put), int(nn_hidden),
+                                                   int(nn_epochs), float(nn_lr), int(nn_seed) & (2**64 - 1),
+                                                   C.byref(res), sx.ctypes.data if want_state else None,
+                                                   tex.ctypes.data if want_state else None))
+        d = res.as_dict()
+        d.update(sx=sx, tex=tex)
+        return d
+
+    def contnet_init_params(self, nn_hidden, t, nn_seed=0):
+        """Initial parameters of step t's net as a dict of torch-shaped arrays (w0 [h,1], b0, w1 [h,h], b1, w2 [1,h], b2)."""
+        H = 32 if nn_hidden <= 32 else 64 if nn_hidden <= 64 else 128
+        n = 8 * H + H * H + 2 * H + 1
+        flat = np.zeros(n, np.float32)
+        _check(self.lib, self.lib.omc_contnet_init_params(self.handle, int(nn_hidden), int(t),
+                                                           int(nn_seed) & (2**64 - 1), flat.ctypes.data, n))
+        h = int(nn_hidden)
+        l0 = flat[:8 * H].reshape(H, 8)
+        w1 = flat[8 * H:8 * H + H * H].reshape(H, H)
+        b1 = flat[8 * H + H * H:8 * H + H * H + H]
+        wo = flat[8 * H + H * H + H:8 * H + H * H + 2 * H]
+        return dict(w0=l0[:h, :1].copy(), b0=l0[:h, 7].copy(), w1=w1[:h, :h].copy(), b1=b1[:h].copy(),
+                    w2=wo[:h].reshape(1, h).copy(), b2=flat[-1:].copy(), flat=flat)
+
+    def price_american_contnet(self, params: Params, nn_hidden=32, nn_epochs=10, nn_lr=1e-3, nn_seed=0):
+        res = Result()
+        _check(self.lib, self.lib.omc_price_american_contnet(self.handle, C.byref(params), int(nn_hidden),
+                                                              int(nn_epochs), float(nn_lr),
+                                                              int(nn_seed) & (2**64 - 1), C.byref(res)))
+        return res.as_dict()
 
     # -- native RCCL communicator (no torch): see include/omc.h
     def comm_init(self, rank: int, world: int, uid: bytes):

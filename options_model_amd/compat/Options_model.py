@@ -1,19 +1,25 @@
 """v1 functional surface (reference Options_model.py:44-157, :190-211) on the GPU hot path.
 
 Flow kept: per-time-step regress-and-decide with the sticky `exercised` mask, valued at t=dt
-(Options_model.py:108-157); the per-step ContNet is replaced by OLS on [1,u,u^2].  As in the
-reference every pricing reseeds with `seed`, so all points of a curve share their normals
-(common random numbers across maturities, Options_model.py:74,197).
+(Options_model.py:108-157).  Regressor: by default the reference's own -- a fresh ContNet(1-32-32-1) per
+step, 10 full-batch Adam steps at lr 1e-3 (Options_model.py:14-25,127-139) -- as HIP kernels;
+`regressor="poly"` (keyword, or OMC_REGRESSOR=poly in the environment) solves OLS on [1,u,u^2] per step
+instead.  The reference never seeds torch here, so its nets differ from run to run; ours are keyed by
+`seed` (same arguments, same price).  As in the reference every pricing reseeds with `seed`, so all
+points of a curve share their normals (common random numbers across maturities, Options_model.py:74,197).
 """
 from __future__ import annotations
 
 import math
 
 from .. import _ffi
+from ._regressor import resolve
+
+NN_HIDDEN, NN_EPOCHS, NN_LR = 32, 10, 1e-3  # Options_model.py:15,129,132
 
 
 def price_american_option(S0, K, T, r, sigma, num_simulations=10000, num_time_steps=50,
-                          option_type="call", lsm_poly_degree=2, plot_paths=False, seed=42):
+                          option_type="call", lsm_poly_degree=2, plot_paths=False, seed=42, *, regressor=None):
     """-> (mean, std, probability the option ends worthless)"""
     if S0 <= 0 or K <= 0 or T <= 0 or sigma <= 0:
         raise ValueError("S0, K, T, and sigma must be positive.")
@@ -31,14 +37,19 @@ def price_american_option(S0, K, T, r, sigma, num_simulations=10000, num_time_st
     p = _ffi.make_params(model="gbm", is_put=(option_type == "put"), semantics="reference",
                          n_paths=M, n_steps=int(num_time_steps), S0=S0, K=K, r=r, sigma=sigma, T=T,
                          seed=int(seed), stream=0)
-    out = _ffi.default_context().price_american(p)
+    if resolve(regressor) == "nn":
+        out = _ffi.default_context().price_american_contnet(p, NN_HIDDEN, NN_EPOCHS, NN_LR, int(seed))
+    else:
+        out = _ffi.default_context().price_american(p)
     return out["price"], out["std"], out["zero_prob"]
 
 
 def compute_curve_for_S0(S0, K, r, sigma, num_simulations, intervals_per_day, total_points,
-                         option_type, lsm_poly_degree, plot_paths, seed):
-    """Options_model.py:190-211.  All points share `seed` (the reference reseeds per pricing),
-    are independent, and therefore run as one batched set of launches."""
+                         option_type, lsm_poly_degree, plot_paths, seed, *, regressor=None):
+    """Options_model.py:190-211.  All points share `seed` (the reference reseeds per pricing) and are
+    independent: with the polynomial regressor they run as one batched set of launches, with the per-step
+    network one pricing after the other."""
+    regressor = resolve(regressor)
     points = []
     for i in range(total_points, 0, -1):
         d = i / intervals_per_day
@@ -62,6 +73,10 @@ def compute_curve_for_S0(S0, K, r, sigma, num_simulations, intervals_per_day, to
     params = [_ffi.make_params(model="gbm", is_put=(option_type == "put"), semantics="reference",
                                n_paths=M, n_steps=steps, S0=S0, K=K, r=r, sigma=sigma, T=T,
                                seed=int(seed), stream=0) for _, T, steps in points]
-    outs = _ffi.default_context().price_american_batch(params)
+    ctx = _ffi.default_context()
+    if regressor == "nn":
+        outs = [ctx.price_american_contnet(q, NN_HIDDEN, NN_EPOCHS, NN_LR, int(seed)) for q in params]
+    else:
+        outs = ctx.price_american_batch(params)
     return [{"S0": S0, "Days to Expiry": d, "Option Value": o["price"], "Std Dev": o["std"],
              "Zero Prob": o["zero_prob"]} for (d, _, _), o in zip(points, outs)]

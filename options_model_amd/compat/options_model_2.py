@@ -4,13 +4,15 @@
 Same per-step sticky flow as v1; Heston paths are antithetic here (v2's simulator is not,
 options_model_2.py:150-170) -- a variance reduction, not a change of distribution.
 
-Regressor: the reference fits a fresh ContNet(1 -> nn_hidden -> nn_hidden -> 1) per time step with
-nn_epochs full-batch Adam steps from a random initialisation (options_model_2.py:291-301) -- a barely
-trained network whose output the price inherits.  Here every step solves OLS on [1, u, u^2] instead
-(BASELINE.json's "polynomial LSM"; the reference accepts lsm_poly_degree and ignores it, :178-179), so
-nn_hidden / nn_epochs / nn_lr are accepted for signature compatibility and have NO effect: this is
-logged once per process, and stated in INTEGRATION.md.  The reference's mask / discount / strict-'>' /
-statistics logic is pinned to recorded runs of this very class (tests/golden/per_step_ref.npz).
+Regressor: by default the reference's own -- a fresh ContNet(1 -> nn_hidden -> nn_hidden -> 1) per time
+step, nn_epochs full-batch Adam(lr = nn_lr) steps from torch's default initialisation
+(options_model_2.py:291-301) -- as HIP kernels (omc_contnet.hip); nn_hidden / nn_epochs / nn_lr are
+honoured.  The reference seeds torch once per pricing with `seed` (:241); our nets are keyed by the same
+`seed` (a different stream, the same distribution): same arguments, same price.  `regressor="poly"`
+(keyword, or OMC_REGRESSOR=poly in the environment) solves OLS on [1, u, u^2] per step instead
+(BASELINE.json's "polynomial LSM"; the reference accepts lsm_poly_degree and ignores it, :178-179) and
+then ignores the nn_* arguments.  The reference's mask / discount / strict-'>' / statistics logic is
+pinned to recorded runs of this very class (tests/golden/per_step_ref.npz).
 """
 from __future__ import annotations
 
@@ -20,28 +22,21 @@ from typing import Any, Dict, List, Optional
 
 from .. import _ffi
 from ..api import heston_defaults
-
-
-_told = False
+from ._regressor import resolve
 
 
 class OptionPricer:
     def __init__(self, K: float, r: float, sigma: Optional[float], option_type: str = "call",
                  lsm_poly_degree: int = 2, seed: int = 42, use_heston: bool = False,
                  heston_params: Optional[Dict[str, Any]] = None, nn_hidden: int = 32,
-                 nn_epochs: int = 10, nn_lr: float = 1e-3, verbose: bool = False):
+                 nn_epochs: int = 10, nn_lr: float = 1e-3, verbose: bool = False, *,
+                 regressor: Optional[str] = None):
         self.K, self.r, self.sigma, self.option_type = K, r, sigma, option_type
         self.lsm_poly_degree, self.seed = lsm_poly_degree, seed
         self.use_heston, self.heston_params = use_heston, heston_params
         self.nn_hidden, self.nn_epochs, self.nn_lr, self.verbose = nn_hidden, nn_epochs, nn_lr, verbose
-        self.regressor = "poly"
+        self.regressor = resolve(regressor)
         self.last_result: Optional[dict] = None
-        global _told
-        if not _told:
-            _told = True
-            logging.getLogger(__name__).info(
-                "options_model_amd.compat.options_model_2: the per-step ContNet regressor is replaced by OLS on "
-                "[1,u,u^2]; nn_hidden / nn_epochs / nn_lr have no effect")
 
     def price_american_option(self, S0: float, T: float, num_simulations: int = 10000,
                               num_time_steps: int = 50, plot_paths: bool = False) -> float:
@@ -58,7 +53,7 @@ class OptionPricer:
         M = int(num_simulations) // 2 * 2
         if M == 0:
             raise ValueError("num_simulations and num_time_steps must be positive integers.")
-        out = _ffi.default_context().price_american(self._params(S0, T, M, num_time_steps))
+        out = self._price(self._params(S0, T, M, num_time_steps))
         self.last_result = out
         if self.verbose:
             logging.info(f"Probability option expires worthless: {out['zero_prob']:.2%}")
@@ -66,6 +61,15 @@ class OptionPricer:
                          f"(S0={S0}, K={self.K}, T={T}, r={self.r}, sigma={self.sigma}, "
                          f"simulations={num_simulations}, steps={num_time_steps}, heston={self.use_heston})")
         return out["price"]
+
+    def _price(self, params):
+        ctx = _ffi.default_context()
+        if self.regressor == "nn":
+            if not (1 <= int(self.nn_hidden) <= 128):
+                raise ValueError("nn_hidden must be in 1 .. 128.")
+            return ctx.price_american_contnet(params, int(self.nn_hidden), int(self.nn_epochs), float(self.nn_lr),
+                                              int(self.seed))
+        return ctx.price_american(params)
 
     def _params(self, S0, T, M, steps):
         if self.use_heston and self.heston_params is not None:
@@ -78,8 +82,8 @@ class OptionPricer:
 
     def compute_curve_for_S0(self, S0: float, intervals_per_day: int, total_points: int,
                              num_simulations: int, plot_paths: bool) -> List[Dict[str, Any]]:
-        """options_model_2.py:336-355: independent points, every one reseeded with self.seed ->
-        one batched set of launches instead of a loop of pricings."""
+        """options_model_2.py:336-355: independent points, every one reseeded with self.seed -> with the
+        polynomial regressor one batched set of launches instead of a loop of pricings."""
         points = []
         for i in range(total_points, 0, -1):
             d = i / intervals_per_day
@@ -99,7 +103,11 @@ class OptionPricer:
         M = int(num_simulations) // 2 * 2
         if M == 0:
             raise ValueError("num_simulations and num_time_steps must be positive integers.")
-        outs = _ffi.default_context().price_american_batch([self._params(S0, T, M, st) for _, T, st in points])
+        params = [self._params(S0, T, M, st) for _, T, st in points]
+        if self.regressor == "nn":
+            outs = [self._price(q) for q in params]
+        else:
+            outs = _ffi.default_context().price_american_batch(params)
         self.last_result = outs[-1]
         return [{"S0": S0, "Days to Expiry": d, "Option Value": o["price"]} for (d, _, _), o in zip(points, outs)]
 

@@ -77,6 +77,7 @@ struct omc_ctx {
     int step_stamps = 0;  // measurement mode: the per-step kernels time-stamp themselves into `dbg`
     DevBuf bslab, btable, bres, bdisc;  // batched path: problem slab, table, results, discounts
     DevBuf mlp_part, mlp_loss, mlp_wt;  // NN training: gradient partials, epoch loss, transposed connections
+    DevBuf cn_scratch, cn_data, cn_net, cn_cont;  // per-step ContNet flow: set bookkeeping, rows, net + Adam state, values
     std::vector<char> h_table;
     std::vector<double> h_disc, h_bres;
     std::vector<double> hD;
@@ -488,7 +489,7 @@ int omc_ctx_destroy(omc_ctx* c)
     c->comm = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->persist_scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc,
-                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt})
+                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
     for (auto& ev : c->ev)
@@ -866,6 +867,18 @@ static int check_params(const omc_params* p)
     return 0;
 }
 
+static int enqueue_paths(omc_ctx* c, const omc_params* p, float* S, int64_t ld)
+{
+    if (p->model == OMC_MODEL_GBM)
+        HIP_TRY(omc::launch_gbm_paths(c->stream, S, ld, p->n_paths, p->n_steps, p->S0, p->r, p->sigma, p->T, p->seed,
+                                      (uint32_t)p->stream, p->pair_offset, p->antithetic, c->gbm_vec));
+    else
+        HIP_TRY(omc::launch_heston_paths(c->stream, S, ld, p->n_paths, p->n_steps, p->S0, p->r, p->T, p->v0,
+                                         p->kappa, p->theta, p->xi, p->rho, p->seed, (uint32_t)p->stream,
+                                         p->pair_offset, p->heston_scheme, c->heston_vec));
+    return 0;
+}
+
 // Enqueue one whole pricing (paths + backward induction) on the context's stream; its 8 result sums
 // go to `result_dev` (device-visible memory) or, when null, to the workspace's device buffer, which is
 // returned through *result_out.  Events are recorded only when `timed`.
@@ -890,13 +903,7 @@ static int enqueue_pricing(omc_ctx* c, const omc_params* p, float* S_keep, int64
         w.ev_p1_begin = c->ev[3]; w.ev_p1_end = c->ev[4]; w.ev_p2_begin = c->ev[5]; w.ev_p2_end = c->ev[6];
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     }
-    if (p->model == OMC_MODEL_GBM)
-        HIP_TRY(omc::launch_gbm_paths(c->stream, S, ld, M, N, p->S0, p->r, p->sigma, p->T, p->seed,
-                                      (uint32_t)p->stream, p->pair_offset, p->antithetic, c->gbm_vec));
-    else
-        HIP_TRY(omc::launch_heston_paths(c->stream, S, ld, M, N, p->S0, p->r, p->T, p->v0, p->kappa,
-                                         p->theta, p->xi, p->rho, p->seed, (uint32_t)p->stream,
-                                         p->pair_offset, p->heston_scheme, c->heston_vec));
+    if ((rc = enqueue_paths(c, p, S, ld))) return rc;
     if (timed) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     if (result_dev) w.result = result_dev;
     if ((rc = enqueue_lsm(c, prob, w, p->semantics, false))) return rc;
@@ -948,6 +955,164 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
                 c->distributed() ? c->world : 1);  // distributed: sums are global
     return read_kernel_times(c, p, res);
 }
+
+// ------------------------------------------------------------------ per-step ContNet flow (v1 / v2 regressor)
+namespace {
+
+// The reference's per-step loop (Options_model.py:112-151 = options_model_2.py:283-312) on a device path
+// matrix: for t = N-1 .. 1 { set = in the money & not exercised; skip if empty; fresh net; `epochs` full-batch
+// Adam steps; exercise where payoff > net(input) }.  One host read per step (the set's size, which sizes the
+// trainer's launches); everything else is stream-ordered.  Leaves the valuation sums in w.result.
+int contnet_sweep(omc_ctx* c, const omc::LsmProblem& p, omc::LsmWorkspace& w, int hidden, int epochs, double lr,
+                  uint64_t seed, double* rows_total)
+{
+    int rc;
+    const int H = omc::cn_padded_width(hidden);
+    const int np = omc::mlp_train_param_count(H, 2);
+    const int64_t M = p.M;
+    const int N = p.N;
+    if ((rc = c->cn_scratch.ensure(omc::cn_scratch_bytes(M)))) return rc;
+    if ((rc = c->cn_net.ensure(sizeof(float) * 3 * (size_t)np))) return rc;
+    if ((rc = c->cn_cont.ensure(sizeof(float) * (size_t)M))) return rc;
+    if ((rc = c->mlp_wt.ensure(omc::mlp_wt_bytes(H, 2)))) return rc;
+    if ((rc = c->mlp_loss.ensure(sizeof(double)))) return rc;
+    float* net = (float*)c->cn_net.p;
+    w.cont = (const float*)c->cn_cont.p;
+    w.ldc = 0;  // one row, rewritten every step
+    const double* hdr_dev = omc::cn_header(p, c->cn_scratch.p);
+    *rows_total = 0.0;
+    HIP_TRY(omc::lsm_step(c->stream, p, w, OMC_SEM_REFERENCE, N, false));  // state: nobody has exercised
+    for (int t = N - 1; t >= 1; --t) {
+        const double Dt = c->hD[(size_t)(N - t)];
+        HIP_TRY(omc::cn_count(c->stream, p, w, c->cn_scratch.p, t, Dt));
+        double hdr[4];
+        HIP_TRY(hipMemcpyAsync(hdr, hdr_dev, sizeof hdr, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int64_t R = (int64_t)hdr[0];
+        if (R <= 0) continue;  // `if not np.any(itm): continue`
+        *rows_total += (double)R;
+        if ((rc = c->cn_data.ensure(sizeof(float) * 8 * (size_t)R))) return rc;
+        if ((rc = c->mlp_part.ensure(omc::mlp_partial_bytes(H, 2, R)))) return rc;
+        HIP_TRY(omc::cn_rows(c->stream, p, w, c->cn_scratch.p, t, Dt, (float*)c->cn_data.p));
+        HIP_TRY(omc::cn_init(c->stream, hidden, t, seed, net, net + np, net + 2 * (size_t)np));
+        omc::MlpTrainPlan plan;
+        plan.data = (const float*)c->cn_data.p;
+        plan.params = net; plan.adam_m = net + np; plan.adam_v = net + 2 * (size_t)np;
+        plan.partial = (float*)c->mlp_part.p; plan.loss_acc = (double*)c->mlp_loss.p;
+        plan.nrows = R; plan.batch = R; plan.hidden = H; plan.layers = 2;
+        plan.wt = (float*)c->mlp_wt.p;
+        plan.lr = lr; plan.beta1 = 0.9; plan.beta2 = 0.999; plan.eps = 1e-8;  // optim.Adam defaults
+        plan.weight_decay = 0.0; plan.dropout = 0.0; plan.seed = 0; plan.shuffle_key = 0;
+        for (int e = 0; e < epochs; ++e) {
+            plan.first_step = e;
+            HIP_TRY(omc::mlp_train_steps(c->stream, plan));
+        }
+        HIP_TRY(omc::cn_forward(c->stream, p, w, c->cn_scratch.p, t, Dt, hidden, net, (float*)c->cn_cont.p));
+        HIP_TRY(omc::lsm_step(c->stream, p, w, OMC_SEM_REFERENCE, t, false));
+    }
+    return 0;
+}
+
+int check_contnet(omc_ctx* c, int hidden, int epochs, double lr)
+{
+    if (hidden < 1 || omc::cn_padded_width(hidden) < 0) return fail(-4, "nn_hidden must be in 1 .. 128.");
+    if (epochs < 0) return fail(-4, "nn_epochs must be non-negative.");
+    if (!(lr > 0.0)) return fail(-4, "nn_lr must be positive.");
+    if (c->distributed()) return fail(-10, "the per-step network flow runs on one GPU.");
+    return 0;
+}
+
+int finish_contnet(omc_ctx* c, const omc::LsmProblem& p, omc::LsmWorkspace& w, double rows_total, omc_result* res,
+                   float* sx_out, int32_t* tex_out)
+{
+    int rc;
+    HIP_TRY(omc::lsm_final_reduce(c->stream, p, w, 1, true, sx_out || tex_out));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = copy_outputs(c, w, p.M, p.N, nullptr, sx_out, tex_out))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    c->hres[4] = rows_total;
+    fill_result(res, c->hres, p.M);
+    return 0;
+}
+
+}  // namespace
+
+int omc_lsm_contnet(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r,
+                    double T, int is_put, int nn_hidden, int nn_epochs, double nn_lr, uint64_t nn_seed,
+                    omc_result* res, float* sx_out, int32_t* tex_out)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_market(1.0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if ((rc = check_contnet(c, nn_hidden, nn_epochs, nn_lr))) return rc;
+    if (!res) return fail(-7, "null pointer.");
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, false, &w))) return rc;
+    omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
+    double rows = 0.0;
+    if ((rc = contnet_sweep(c, p, w, nn_hidden, nn_epochs, nn_lr, nn_seed, &rows))) return rc;
+    return finish_contnet(c, p, w, rows, res, sx_out, tex_out);
+}
+
+/* the initial parameters of step t's net, in the trainer's padded layout (host float32 [n]) */
+int omc_contnet_init_params(omc_ctx* c, int nn_hidden, int t, uint64_t nn_seed, float* params_out, int n)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    const int H = omc::cn_padded_width(nn_hidden);
+    if (nn_hidden < 1 || H < 0) return fail(-4, "nn_hidden must be in 1 .. 128.");
+    const int np = omc::mlp_train_param_count(H, 2);
+    if (!params_out || n != np) return fail(-7, "params_out must hold the padded net's parameters.");
+    if ((rc = c->cn_net.ensure(sizeof(float) * 3 * (size_t)np))) return rc;
+    float* net = (float*)c->cn_net.p;
+    HIP_TRY(omc::cn_init(c->stream, nn_hidden, t, nn_seed, net, net + np, net + 2 * (size_t)np));
+    HIP_TRY(hipMemcpyAsync(params_out, net, sizeof(float) * (size_t)np, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_price_american_contnet(omc_ctx* c, const omc_params* p, int nn_hidden, int nn_epochs, double nn_lr,
+                               uint64_t nn_seed, omc_result* res)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_params(p))) return rc;
+    if (p->semantics != OMC_SEM_REFERENCE)
+        return fail(-4, "the per-step network is the regressor of the reference flow (semantics 0).");
+    if ((rc = check_contnet(c, nn_hidden, nn_epochs, nn_lr))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    const int64_t M = p->n_paths;
+    const int N = p->n_steps;
+    const int64_t ld = (M + 63) / 64 * 64;
+    if ((rc = c->S.ensure(sizeof(float) * (size_t)ld * (size_t)(N + 1)))) return rc;
+    float* S = (float*)c->S.p;
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, M, N, p->r, p->T, false, false, &w))) return rc;
+    omc::LsmProblem prob{S, ld, M, N, p->is_put ? 1 : 0, p->K, p->r, p->T};
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = enqueue_paths(c, p, S, ld))) return rc;
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    double rows = 0.0;
+    if ((rc = contnet_sweep(c, prob, w, nn_hidden, nn_epochs, nn_lr, nn_seed, &rows))) return rc;
+    HIP_TRY(omc::lsm_final_reduce(c->stream, prob, w, 1, true, false));
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    c->hres[4] = rows;
+    fill_result(res, c->hres, M);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    res->ms_paths = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+    res->ms_lsm = ms;
+    res->ms_total = res->ms_paths + res->ms_lsm;
+    return 0;
+}
+
 
 // n pricings back to back on the stream with NO host synchronisation in between: pricing i + 1 is
 // enqueued while pricing i runs, every pricing's sums land in their own slot of a host-mapped buffer,
@@ -1307,7 +1472,7 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
     int rc = bind(c);
     if (rc) return rc;
     if (omc::mlp_train_kernel_choice(hidden, layers, batch) == 0)
-        return fail(-9, "the fused trainer supports hidden = 64 or 128 with 2 or 3 hidden layers.");
+        return fail(-9, "the fused trainer supports hidden = 64 or 128 with 2 or 3 hidden layers (and 32 x 2).");
     if (!data || !params || !adam_m || !adam_v || !step || !mean_loss) return fail(-7, "null pointer.");
     if (n_rows <= 0 || batch <= 0 || *step < 0) return fail(-3, "n_rows, batch must be positive.");
     if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");

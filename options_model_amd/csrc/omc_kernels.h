@@ -163,4 +163,19 @@ hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, 
 // one epoch: ceil(nrows / batch) optimizer steps (forward+backward kernel, reduce+Adam kernel)
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t);
 
+// ---- omc_contnet.hip: the per-step ContNet(1 -> h -> h -> 1) regressor of the reference's v1 / v2 pricers
+int cn_padded_width(int hidden);          // width of the trainer that hosts h units (32 / 64 / 128), -1: too wide
+size_t cn_scratch_bytes(int64_t M);
+const double* cn_header(const LsmProblem& p, void* scratch);  // device: n, mean, 1/std (1 if std == 0), std
+// members of step t's regression set (in the money, not exercised): row offsets and header
+hipError_t cn_count(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, void* scratch, int t, double Dt);
+// the set as trainer rows [xs, 0 x 6, y = payoff(S_N) Dt] in path order; data holds >= n rows of 8 floats
+hipError_t cn_rows(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, void* scratch, int t, double Dt,
+                   float* data);
+// nn.Linear default initialisation keyed by (seed, t) in the trainer's parameter layout; Adam moments zeroed
+hipError_t cn_init(hipStream_t st, int hidden, int t, uint64_t seed, float* params, float* m, float* v);
+// cont[j] = net(xs_j) for the members of step t (float32)
+hipError_t cn_forward(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, void* scratch, int t, double Dt,
+                      int hidden, const float* params, float* cont);
+
 }  // namespace omc

@@ -1507,11 +1507,13 @@ int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
     static const int quad = getenv("OMC_MLP_QUAD") ? atoi(getenv("OMC_MLP_QUAD")) : 1;
     if (hidden == 64) return tiles <= 32 ? (quad ? 3 : 2) : 1;
     if (hidden == 128) return (quad && tiles <= kMlpMaxGroups) ? 3 : 2;
+    if (hidden == 32 && layers == 2) return 3;  // the per-step ContNet of omc_contnet.hip: any number of tiles
     return 0;
 }
 
 int mlp_train_param_count(int hidden, int layers)
 {
+    if (hidden == 32 && layers == 2) return mlp_params_of(32, 2);
     if ((hidden != 64 && hidden != 128) || (layers != 2 && layers != 3)) return -1;
     return mlp_params_of(hidden, layers);
 }
@@ -1522,7 +1524,8 @@ size_t mlp_partial_bytes(int hidden, int layers, int64_t batch)
     if (choice == 1) return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride3;
     if (choice == 2 || choice == 3) {
         const int64_t tiles = (batch + 31) / 32, cap = tile_waves_max(hidden);
-        return sizeof(float) * (size_t)(tiles < cap ? tiles : cap) * tile_pstride(hidden, layers);
+        // 32 units: one partial per tile however many (the kernel never accumulates across tiles)
+        return sizeof(float) * (size_t)(hidden == 32 || tiles < cap ? tiles : cap) * tile_pstride(hidden, layers);
     }
     return 0;
 }
@@ -1714,6 +1717,7 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         return t.layers == 2 ? tile_steps<128, 2>(st, t) : tile_steps<128, 3>(st, t);
     }
     if (choice == 3) {
+        if (t.hidden == 32) return quad_steps<32, 2>(st, t);
         if (t.hidden == 64) return t.layers == 2 ? quad_steps<64, 2>(st, t) : quad_steps<64, 3>(st, t);
         return t.layers == 2 ? quad_steps<128, 2>(st, t) : quad_steps<128, 3>(st, t);
     }

@@ -198,6 +198,60 @@ def lsm_per_step(S, K, r, T, is_put, textbook=False, fit=_fit_poly2, cont_values
     return cf, ex, betas, nitm
 
 
+def lsm_per_step_contnet(S, K, r, T, is_put, hidden=32, epochs=10, lr=1e-3, init=None):
+    """The per-step loop of Options_model.py:108-157 / options_model_2.py:278-313 WITH its regressor:
+    a fresh ContNet(1 -> hidden -> hidden -> 1) per step (Options_model.py:14-25), inputs standardised by
+    the set's own mean / population std (:124), raw cash-flows as targets, `epochs` full-batch Adam steps
+    on the MSE (:129-139), continuation = net(inputs) in float32 (:141-142), strict > (:145).
+    init(t) -> dict(w0 [h,1], b0 [h], w1 [h,h], b1 [h], w2 [1,h], b2 [1]) replaces torch's own
+    initialisation (None: torch default, as the reference).  torch on the CPU, float32, like the
+    reference without a GPU.  Returns cash-flows, exercised mask, set sizes, dense continuation values."""
+    import torch
+    import torch.nn as nn
+
+    N, M = S.shape[0] - 1, S.shape[1]
+    disc = np.exp(-r * T / N)
+    cf = payoff(S[-1], K, is_put).astype(np.float64)
+    ex = np.zeros(M, bool)
+    nitm = np.zeros(N + 1, np.int64)
+    cont_all = np.zeros((N + 1, M), np.float32)
+    for t in range(N - 1, 0, -1):
+        cf *= disc
+        pay = payoff(S[t], K, is_put)
+        itm = (pay > 0) & ~ex
+        if not itm.any():
+            continue
+        X = S[t, itm].astype(np.float64)
+        Y = cf[itm]
+        Xs = (X - X.mean()) / X.std() if X.std() > 0 else X - X.mean()
+        net = nn.Sequential(nn.Linear(1, hidden), nn.ReLU(), nn.Linear(hidden, hidden), nn.ReLU(),
+                            nn.Linear(hidden, 1))
+        if init is not None:
+            w = init(t)
+            with torch.no_grad():
+                for lin, (kw, kb) in zip((net[0], net[2], net[4]), (("w0", "b0"), ("w1", "b1"), ("w2", "b2"))):
+                    lin.weight.copy_(torch.from_numpy(np.asarray(w[kw], np.float32)))
+                    lin.bias.copy_(torch.from_numpy(np.asarray(w[kb], np.float32)))
+        opt = torch.optim.Adam(net.parameters(), lr=lr)
+        xt = torch.from_numpy(Xs.reshape(-1, 1)).float()
+        yt = torch.from_numpy(Y.reshape(-1, 1)).float()
+        for _ in range(epochs):
+            loss = nn.MSELoss()(net(xt), yt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        with torch.no_grad():
+            cont = net(xt).numpy().flatten()
+        nitm[t] = itm.sum()
+        cont_all[t, itm] = cont
+        imm = pay[itm]
+        doex = imm > cont
+        idx = np.where(itm)[0][doex]
+        cf[idx] = imm[doex]
+        ex[idx] = True
+    return cf, ex, nitm, cont_all
+
+
 def lsm_two_pass(S, K, r, T, is_put, regress, predict):
     """v3 control flow, options_model_3.py:482-516 (pass 1: no decisions, targets are the
     discounted terminal payoff) and :615-651 (pass 2: sticky mask, strict >, valued at

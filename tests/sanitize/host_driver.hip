@@ -62,7 +62,7 @@ int main()
     REQUIRE(omc_comm_init(nullptr, 0, 1, small, sizeof small) != 0);
     REQUIRE(omc_mlp_param_count(64, 2) > 0 && omc_mlp_param_count(63, 2) < 0);
     REQUIRE(omc_localvol_param_count(64, 4) > 0);
-    REQUIRE(omc_mlp_train_supported(128, 3, 256) == 1 && omc_mlp_train_supported(32, 2, 256) == 0);
+    REQUIRE(omc_mlp_train_supported(128, 3, 256) == 1 && omc_mlp_train_supported(32, 2, 256) == 1 && omc_mlp_train_supported(32, 3, 256) == 0 && omc_mlp_train_supported(48, 2, 256) == 0);
     if (ctx) omc_ctx_destroy(ctx);
 
     // ---- batched path: slab planning and the per-problem table (host arithmetic only; the "device"

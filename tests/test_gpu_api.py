@@ -143,7 +143,8 @@ def test_advanced_pricer_defaults_to_the_reference_regressor(golden):
 # ---------------------------------------------------------------- v1 / v2 surfaces
 def test_v1_functional_surface():
     from options_model_amd.compat.Options_model import compute_curve_for_S0, price_american_option
-    mean, std, zero = price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, 20000, 50, "put", 2, False, 42)
+    mean, std, zero = price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, 20000, 50, "put", 2, False, 42,
+                                            regressor="poly")
     ref = orc.lsm_poly(orc.gbm_paths(20000, 50, 100.0, R, SIG, T, 42), K, R, T, True, "reference")
     assert abs(mean - ref["price"]) <= 1e-3 * ref["price"]
     var = ref["sumsq"] / 20000 - ref["price"] ** 2
@@ -155,6 +156,41 @@ def test_v1_functional_surface():
         price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, lsm_poly_degree=-1)
     recs = compute_curve_for_S0(100.0, 100.0, 0.05, 0.2, 2000, 1, 3, "call", 2, False, 2025)
     assert set(recs[0]) == {"S0", "Days to Expiry", "Option Value", "Std Dev", "Zero Prob"}
+
+
+def test_v1_v2_default_regressor_is_the_references_per_step_network(ctx, golden, monkeypatch):
+    """Called the way the reference is called, the drop-ins fit a fresh ContNet per step (omc_contnet.hip):
+    the price is the one omc_price_american_contnet returns, it sits where the recorded run of the reference
+    sits (same contract, the reference's own normals -> Monte-Carlo noise of 2048 paths apart), nn_* of the v2
+    constructor change it, and OMC_REGRESSOR=poly / regressor="poly" switch to the polynomial."""
+    from options_model_amd import _ffi
+    from options_model_amd.compat.Options_model import price_american_option
+    from options_model_amd.compat.options_model_2 import OptionPricer
+    monkeypatch.delenv("OMC_REGRESSOR", raising=False)
+    mean, std, zero = price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, 2048, 20, "put", 2, False, 42)
+    direct = ctx.price_american_contnet(_ffi.make_params(is_put=True, n_paths=2048, n_steps=20, seed=42), 32, 10, 1e-3, 42)
+    assert (mean, std, zero) == (direct["price"], direct["std"], direct["zero_prob"])
+    ref_mean, ref_std, ref_zero = golden["per_step"]["v1_put_stats"]        # the reference, same arguments
+    assert abs(mean - ref_mean) <= 4 * ref_std / math.sqrt(2048)
+    assert std == pytest.approx(ref_std, rel=0.08) and abs(zero - ref_zero) < 0.04
+    means = [price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, 20000, 20, "put", 2, False, s)[0] for s in range(4)]
+    # 80k paths pin OUR expectation (+-0.03); the reference's one recorded sample of 2048 paths carries a
+    # standard error of 0.185 (on ITS paths our flow returns its price: tests/test_gpu_contnet.py)
+    assert abs(np.mean(means) - ref_mean) <= 3 * ref_std / math.sqrt(2048) and np.std(means) < 0.08
+    poly = price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, 2048, 20, "put", 2, False, 42, regressor="poly")
+    assert poly[0] != mean
+    monkeypatch.setenv("OMC_REGRESSOR", "poly")
+    assert price_american_option(100.0, 100.0, 1.0, 0.05, 0.2, 2048, 20, "put", 2, False, 42) == poly
+    monkeypatch.delenv("OMC_REGRESSOR")
+    a = OptionPricer(100.0, 0.05, 0.2, "put", 2, 42).price_american_option(100.0, 1.0, 4000, 16)
+    b = OptionPricer(100.0, 0.05, 0.2, "put", 2, 42, nn_hidden=16, nn_epochs=200, nn_lr=1e-2).price_american_option(
+        100.0, 1.0, 4000, 16)
+    c = OptionPricer(100.0, 0.05, 0.2, "put", 2, 42, regressor="poly").price_american_option(100.0, 1.0, 4000, 16)
+    assert a != b and a != c and b != c
+    # 200 epochs at lr 1e-2 actually train the nets: the price moves towards the regression-based one
+    assert abs(b - c) < abs(a - c)
+    with pytest.raises(ValueError, match="regressor"):
+        OptionPricer(100.0, 0.05, 0.2, "put", regressor="forest")
 
 
 def test_v2_worker_surface_as_the_ui_calls_it():

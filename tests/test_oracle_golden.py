@@ -251,3 +251,25 @@ def test_heston_put_frozen_mlp_pass2_reproduces_reference_decisions(golden):
     assert int((ex != g[f"{tag}_ex_eval"]).sum()) <= 2
     assert cf.mean() == pytest.approx(float(g[f"{tag}_price_eval"]), rel=1e-3)
     assert 0.2 < g[f"{tag}_ex_eval"].mean() < 0.99  # decisions really happen
+
+
+@pytest.mark.parametrize("tag", PER_STEP_TAGS)
+def test_contnet_restatement_prices_the_references_paths_like_the_reference(golden, tag):
+    """The restatement of the per-step regressor itself (fresh ContNet, standardised inputs, raw targets,
+    10 Adam steps): on the reference's recorded paths its price sits within the spread the reference's own
+    unseeded initialisation produces (~0.5 %) of the recorded price, and the continuation values it
+    produces are as small as the recorded ones (barely trained nets: SURVEY F1)."""
+    torch = pytest.importorskip("torch")
+    g = golden["per_step"]
+    S0, Kp, Tp, rp, sig, is_put, seed = g[f"{tag}_params"]
+    prices, scale = [], []
+    for s in range(3):
+        torch.manual_seed(s)
+        cf, ex, nitm, cont = rf.lsm_per_step_contnet(g[f"{tag}_S"], Kp, rp, Tp, bool(is_put))
+        prices.append(cf.mean())
+        scale.append(np.abs(cont[cont != 0]).mean())
+    ref = g[f"{tag}_stats"][0]
+    assert abs(np.mean(prices) - ref) <= 0.01 * ref and max(abs(p - ref) for p in prices) <= 0.02 * ref
+    rec = g[f"{tag}_cont"]
+    rec_scale = np.abs(rec[np.isfinite(rec)]).mean()
+    assert 0.3 * rec_scale < np.mean(scale) < 3.0 * rec_scale
