@@ -24,7 +24,7 @@
 // raises a global error word that every other spin polls, all workgroups leave, and the host falls back to
 // the launch-per-step sweep -- the kernel cannot hang.
 //
-// OUTCOME (MI355X, profiles/r02_persist_stamps.txt): OFF by default.  The exchange of one epoch -- partials
+// OUTCOME (MI355X, profiles/persist_stamps_r02g.txt): OFF by default.  The exchange of one epoch -- partials
 // published, workgroup 0 sweeps them, solves, publishes the fit, everyone picks it up -- takes 6.4 us at the
 // median workgroup (two write-through-store -> remote sc1-load hops at ~3 us each under 255 polling waves)
 // against 1.3 us of launch gap + ~2.3 us of cold-start latency for the launch-per-step kernel: 8.5 vs
