@@ -1005,6 +1005,7 @@ int contnet_sweep(omc_ctx* c, const omc::LsmProblem& p, omc::LsmWorkspace& w, in
         plan.weight_decay = 0.0; plan.dropout = 0.0; plan.seed = 0; plan.shuffle_key = 0;
         for (int e = 0; e < epochs; ++e) {
             plan.first_step = e;
+            plan.wt_current = e > 0;
             HIP_TRY(omc::mlp_train_steps(c->stream, plan));
         }
         HIP_TRY(omc::cn_forward(c->stream, p, w, c->cn_scratch.p, t, Dt, hidden, net, (float*)c->cn_cont.p));

@@ -131,6 +131,7 @@ struct MlpTrainPlan {
     double lr, beta1, beta2, eps, weight_decay, dropout;
     uint64_t seed;         // dropout bits
     uint64_t shuffle_key;  // 0: rows in storage order; else a keyed pseudo-random permutation
+    bool wt_current = false;  // `wt` already mirrors `params` (the Adam kernel of an earlier call kept it so)
 };
 size_t mlp_partial_bytes(int hidden, int layers, int64_t batch);
 size_t mlp_wt_bytes(int hidden, int layers);

@@ -1607,7 +1607,7 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
+    if (!t.wt_current) hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
     const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
     int64_t step = t.first_step;
     for (int64_t o = 0; o < t.nrows; o += t.batch) {
@@ -1662,7 +1662,7 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
 template <int H, int L>
 static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
 {
-    hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
+    if (!t.wt_current) hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
     const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
     int64_t step = t.first_step;
     for (int64_t o = 0; o < t.nrows; o += t.batch) {
