@@ -48,7 +48,7 @@ def compute_curve_for_S0(S0, K, r, sigma, num_simulations, intervals_per_day, to
                          option_type, lsm_poly_degree, plot_paths, seed, *, regressor=None):
     """Options_model.py:190-211.  All points share `seed` (the reference reseeds per pricing) and are
     independent: with the polynomial regressor they run as one batched set of launches, with the per-step
-    network one pricing after the other."""
+    network as concurrent pricings on a small pool of contexts (_ffi.map_contexts)."""
     regressor = resolve(regressor)
     points = []
     for i in range(total_points, 0, -1):
@@ -73,10 +73,10 @@ def compute_curve_for_S0(S0, K, r, sigma, num_simulations, intervals_per_day, to
     params = [_ffi.make_params(model="gbm", is_put=(option_type == "put"), semantics="reference",
                                n_paths=M, n_steps=steps, S0=S0, K=K, r=r, sigma=sigma, T=T,
                                seed=int(seed), stream=0) for _, T, steps in points]
-    ctx = _ffi.default_context()
     if regressor == "nn":
-        outs = [ctx.price_american_contnet(q, NN_HIDDEN, NN_EPOCHS, NN_LR, int(seed)) for q in params]
+        outs = _ffi.map_contexts(lambda ctx, q: ctx.price_american_contnet(q, NN_HIDDEN, NN_EPOCHS, NN_LR, int(seed)),
+                                 params)
     else:
-        outs = ctx.price_american_batch(params)
+        outs = _ffi.default_context().price_american_batch(params)
     return [{"S0": S0, "Days to Expiry": d, "Option Value": o["price"], "Std Dev": o["std"],
              "Zero Prob": o["zero_prob"]} for (d, _, _), o in zip(points, outs)]

@@ -62,8 +62,8 @@ class OptionPricer:
                          f"simulations={num_simulations}, steps={num_time_steps}, heston={self.use_heston})")
         return out["price"]
 
-    def _price(self, params):
-        ctx = _ffi.default_context()
+    def _price(self, params, ctx=None):
+        ctx = ctx or _ffi.default_context()
         if self.regressor == "nn":
             if not (1 <= int(self.nn_hidden) <= 128):
                 raise ValueError("nn_hidden must be in 1 .. 128.")
@@ -105,7 +105,7 @@ class OptionPricer:
             raise ValueError("num_simulations and num_time_steps must be positive integers.")
         params = [self._params(S0, T, M, st) for _, T, st in points]
         if self.regressor == "nn":
-            outs = [self._price(q) for q in params]
+            outs = _ffi.map_contexts(lambda ctx, q: self._price(q, ctx), params)
         else:
             outs = _ffi.default_context().price_american_batch(params)
         self.last_result = outs[-1]

@@ -124,3 +124,34 @@ def test_contnet_fused_pricing_and_degenerate_sets(ctx):
         ctx.price_american_contnet(_ffi.make_params(n_paths=1000, n_steps=5, semantics="two_pass"), 32, 10, 1e-3, 0)
     with pytest.raises(ValueError):
         ctx.price_american_contnet(p, 500, 10, 1e-3, 0)
+
+
+def test_curves_with_the_network_run_concurrently_and_equal_the_point_by_point_prices(ctx, monkeypatch):
+    """compute_curve_for_S0 (v1) / OptionPricer.compute_curve_for_S0 (v2) in their default (network) mode issue
+    the points from several host threads, one context each: same numbers as one pricing after the other."""
+    import math
+    import time
+    from options_model_amd.compat import Options_model as v1
+    from options_model_amd.compat.options_model_2 import OptionPricer
+    monkeypatch.delenv("OMC_REGRESSOR", raising=False)
+    monkeypatch.setenv("OMC_CURVE_STREAMS", "1")
+    t0 = time.perf_counter()
+    seq = v1.compute_curve_for_S0(100.0, 100.0, 0.05, 0.2, 10000, 2, 40, "put", 2, False, 2025)
+    t_seq = time.perf_counter() - t0
+    monkeypatch.setenv("OMC_CURVE_STREAMS", "8")
+    v1.compute_curve_for_S0(100.0, 100.0, 0.05, 0.2, 10000, 2, 8, "put", 2, False, 2025)  # contexts created
+    t0 = time.perf_counter()
+    par = v1.compute_curve_for_S0(100.0, 100.0, 0.05, 0.2, 10000, 2, 40, "put", 2, False, 2025)
+    t_par = time.perf_counter() - t0
+    assert par == seq
+    print(f"\n40-point network curve: {t_seq * 1e3:.0f} ms sequential, {t_par * 1e3:.0f} ms on 8 contexts")
+    d = par[0]["Days to Expiry"]
+    m, s, z = v1.price_american_option(100.0, 100.0, d / 365, 0.05, 0.2, 10000, max(10, min(130, int(math.ceil(d)))),
+                                       "put", 2, False, 2025)
+    assert (par[0]["Option Value"], par[0]["Std Dev"], par[0]["Zero Prob"]) == (m, s, z)
+    p = OptionPricer(100.0, 0.05, None, "put", 2, 7, True, dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7),
+                     nn_hidden=16, nn_epochs=5)
+    recs = p.compute_curve_for_S0(95.0, 1, 6, 4000, False)
+    for r in recs:
+        d = r["Days to Expiry"]
+        assert r["Option Value"] == p.price_american_option(95.0, d / 365, 4000, max(10, min(130, int(math.ceil(d)))))
