@@ -241,3 +241,29 @@ def test_sequence_of_pricings_equals_individual_calls(ctx):
         for k in ("price", "sum", "sumsq", "n_exercised", "n_zero", "sum_nitm", "n_paths"):
             assert s[k] == one[k], k
     assert all(s["ms_total"] > 0 for s in seq)
+
+
+def test_v1_5_class_surface(ctx, monkeypatch):
+    """options_model_v1.5.py: one never-reseeded generator per pricer (consecutive pricings differ, a fresh pricer
+    repeats them), its own step rule for curves, exceptions propagate from the worker."""
+    from options_model_amd import _ffi
+    from options_model_amd.compat.options_model_v1_5 import OptionPricer, compute_curve_worker
+    monkeypatch.delenv("OMC_REGRESSOR", raising=False)
+    p = OptionPricer(100.0, 0.05, 0.2, "put", 2, 42)
+    a, b = p.price_american_option(100.0, 1.0, 8000, 20), p.price_american_option(100.0, 1.0, 8000, 20)
+    assert a != b and abs(a - b) < 0.6                       # fresh normals, same contract
+    q = OptionPricer(100.0, 0.05, 0.2, "put", 2, 42)
+    assert q.price_american_option(100.0, 1.0, 8000, 20) == a
+    direct = ctx.price_american_contnet(_ffi.make_params(is_put=True, n_paths=8000, n_steps=20, seed=42, stream=1),
+                                        32, 10, 1e-3, 43)
+    assert b == direct["price"]
+    recs = compute_curve_worker(100.0, 100.0, 0.05, 0.2, "call", 2, 7, 4, 6, 2000, False)
+    assert [r["Days to Expiry"] for r in recs] == [1.5, 1.25, 1.0, 0.75, 0.5, 0.25]
+    seq = OptionPricer(100.0, 0.05, 0.2, "call", 2, 7)
+    for r in recs:                                           # steps = max(2, min(500, ceil(d * intervals)))
+        d = r["Days to Expiry"]
+        assert r["Option Value"] == seq.price_american_option(100.0, d / 365.0, 2000, max(2, min(500, math.ceil(d * 4))))
+    poly = OptionPricer(100.0, 0.05, 0.2, "call", 2, 7, regressor="poly").compute_curve_for_S0(100.0, 4, 6, 2000, False)
+    assert len(poly) == 6 and poly != recs
+    with pytest.raises(ValueError, match="sigma must be positive"):
+        compute_curve_worker(100.0, 100.0, 0.05, -0.2, "call", 2, 7, 4, 6, 2000, False)
