@@ -124,3 +124,23 @@ def test_config4_size_heston_put_real_decisions_and_idempotence(ctx):
     tb = ctx.lsm_poly(S, 100.0, 0.05, 1.0, True, "textbook")
     assert european < tb["price"] < a["price"] + 0.05  # textbook (adapted rule) below the look-ahead flows
     S.free()
+
+
+@pytest.mark.parametrize("model,M,sems", [("gbm", 1_000_000, ("two_pass", "reference", "textbook")),
+                                          ("heston", 4_000_000, ("two_pass",))])
+def test_full_size_pricing_is_exactly_homogeneous_in_spot_and_strike(ctx, model, M, sems):
+    """Doubling S0 and K (a power of two: exact in binary floating point) doubles every float32 path value, leaves
+    u = S/K - 1 and every regression moment of u unchanged and doubles every payoff sum -- so the WHOLE pricing
+    (paths, moments, 3x3 solves, exercise decisions, valuation) must return exactly twice the price, the same
+    exercise counts and the same regression-set sizes, bit for bit, at BASELINE's sizes (configs 2 and 4).  Any
+    mis-indexed row, dropped path or order-dependent reduction breaks this."""
+    from options_model_amd import _ffi
+    for sem in sems:
+        kw = dict(model=model, is_put=True, semantics=sem, n_paths=M, n_steps=252, seed=77, **(HP if model == "heston" else {}))
+        a = ctx.price_american(_ffi.make_params(S0=100.0, K=100.0, **kw))
+        b = ctx.price_american(_ffi.make_params(S0=200.0, K=200.0, **kw))
+        c = ctx.price_american(_ffi.make_params(S0=25.0, K=25.0, **kw))
+        for o, f in ((b, 2.0), (c, 0.25)):
+            assert o["price"] == f * a["price"] and o["sum"] == f * a["sum"] and o["sumsq"] == f * f * a["sumsq"]
+            assert (o["n_exercised"], o["n_zero"], o["sum_nitm"]) == (a["n_exercised"], a["n_zero"], a["sum_nitm"])
+        assert a["n_exercised"] > M // 10
