@@ -92,7 +92,11 @@ int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
  * geometry costs milliseconds), "step_persistent" (1: run the per-step
  * reference sweep as ONE persistent launch with an in-launch exchange of the partial moments --
  * csrc/omc_lsm_persist.hip; bounded spins, falls back to launches if its workgroups cannot all be
- * resident; default 0: measured slower than one launch per step on MI355X) */
+ * resident; default 0: measured slower than one launch per step on MI355X),
+ * "seq_overlap" (omc_price_american_seq on a context with a communicator, two-pass flow, equal geometry:
+ * 1 = the moment all-reduce of pricing k runs on a second stream under the path generation of pricing k+1
+ * (second path buffer) and all result sums travel in one collective at the end -- bit-identical results;
+ * 0 = one pricing after the other; -1 = default: on when the communicator has more than one rank) */
 int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
 /* measurement aid: with option "step_stamps" = 1 the per-step reference sweep runs a build of its kernel
  * that records eight 100 MHz time stamps per launch and workgroup (entry, partials in, fit solved,
@@ -305,9 +309,11 @@ int omc_localvol_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, 
 /* n independent pricings enqueued back to back on the context's stream (pricing i + 1 is launched while
  * pricing i runs; every pricing's result sums land in their own slot of a host-mapped buffer; one wait
  * at the end).  res[i] equals what omc_price_american(p[i]) returns, bit for bit; ms_paths / ms_pass1 /
- * ms_pass2 are measured on the first pricing, ms_total is the average over the sequence.  An installed
- * all-reduce hook (multi-GPU) is called as usual; it must only ENQUEUE its collective on the stream
- * (as torch.distributed does), then the sequence stays free of host waits across ranks too. */
+ * ms_pass2 are measured on the first pricing, ms_total is the average over the sequence.  Across GPUs the
+ * moment tables are all-reduced per pricing as usual, but the result sums of all n pricings travel in ONE
+ * collective of 8n doubles after the last pricing (the hook is called once with count = 8n); a hook must only
+ * ENQUEUE its collective on the stream (as torch.distributed does), then the sequence stays free of host
+ * waits across ranks too.  With a native communicator see also option "seq_overlap". */
 int omc_price_american_seq(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
 
 /* ---- many small pricings in one go ------------------------------------------------------- */

@@ -96,6 +96,13 @@ struct omc_ctx {
     omc_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
     omc::Comm* comm = nullptr;  // native RCCL communicator (omc_comm_init); takes precedence over the hook
+    // omc_price_american_seq across GPUs: the moment all-reduce of pricing k runs on its own stream while the
+    // main stream generates the paths of pricing k+1 into the second path buffer
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_moments[2] = {nullptr, nullptr}, ev_reduced[2] = {nullptr, nullptr};
+    DevBuf S2, seq_local, part1b, gmomb;
+    int seq_overlap = -1;  // -1: default (on when the communicator has more than one rank), 0 off, 1 on
+    bool defer_result_allreduce = false;  // inside omc_price_american_seq: one collective for all result sums
     // captured per-step sweep (N launches + valuation + finalize), replayed for every pricing of the
     // same geometry; its kernels read their arguments from `sweep_args`
     hipGraph_t sweep_graph = nullptr;
@@ -369,7 +376,7 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
     }
     // {sum, sumsq, n_exercised, n_zero, sum_nitm, ..} -> global sums.  Slot 4 is built from the moment
     // table, which is ALREADY global on every rank: fill_result divides it by the world size again.
-    if (c->distributed() && (rc = allreduce(c, w.result, 8))) return rc;
+    if (c->distributed() && !c->defer_result_allreduce && (rc = allreduce(c, w.result, 8))) return rc;
     return 0;
 }
 
@@ -489,9 +496,14 @@ int omc_ctx_destroy(omc_ctx* c)
     c->comm = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->persist_scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc,
-                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont})
+                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    for (int b = 0; b < 2; ++b) {
+        if (c->ev_moments[b]) (void)hipEventDestroy(c->ev_moments[b]);
+        if (c->ev_reduced[b]) (void)hipEventDestroy(c->ev_reduced[b]);
+    }
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->hres_pin) (void)hipHostFree(c->hres_pin);
@@ -558,6 +570,7 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
     else if (!strcmp(key, "step_graph")) c->step_graph = value < 0 ? -1 : (value ? 1 : 0);
     else if (!strcmp(key, "step_stamps")) c->step_stamps = value ? 1 : 0;
+    else if (!strcmp(key, "seq_overlap")) c->seq_overlap = value < 0 ? -1 : (value ? 1 : 0);
     else if (!strcmp(key, "step_persistent")) {
         c->step_persistent = value < 0 ? -1 : (value ? 1 : 0);
         if (value > 0) c->persist_failed = 0;  // explicit request: try again
@@ -1119,6 +1132,104 @@ int omc_price_american_contnet(omc_ctx* c, const omc_params* p, int nn_hidden, i
 // enqueued while pricing i runs, every pricing's sums land in their own slot of a host-mapped buffer,
 // one wait at the end.  Results are those of n omc_price_american calls; kernel times are measured on
 // the first pricing, ms_total is the average over the sequence (first launch to last completion).
+// omc_price_american_seq across GPUs, two-pass flow, native communicator: per pricing the only exchange the
+// decisions wait for is the all-reduce of the [N+1][8] moment table between pass 1 and the solves.  Left on
+// the main stream it idles the GPU for a collective's latency once per pricing; here it runs on its own
+// stream while the main stream generates the NEXT pricing's paths into a second path buffer AND runs its pass 1
+// (second partial / moment buffers), and the 8 result sums of all n pricings are all-reduced once, at the end.
+// Kernel adjacency stays that of a single pricing -- pass 1 right behind its generator (it starts with the
+// rows that are still in the Infinity Cache), pass 2 behind a pass 1 (measured: a pass 2 right behind a
+// generator of ANOTHER buffer pays that generator's write-back, +55 us).  Same kernels, same order of every
+// reduction: results are bit-identical to the one-at-a-time path.
+static bool seq_overlap_enabled(const omc_ctx* c)
+{
+    if (c->seq_overlap >= 0) return c->seq_overlap != 0;
+    static const int env = [] {
+        const char* e = getenv("OMC_SEQ_OVERLAP");
+        return e ? atoi(e) : -1;
+    }();
+    if (env >= 0) return env != 0;
+    // default: whenever there is a collective worth hiding (with one rank the extra stream only costs its
+    // event hand-overs: 0.606 against 0.591 ms per pricing at C2)
+    return c->comm && omc::comm_world(c->comm) > 1;
+}
+
+static bool seq_can_overlap(const omc_ctx* c, const omc_params* p, int n)
+{
+    if (!c->comm || n < 2 || !seq_overlap_enabled(c)) return false;
+    for (int i = 0; i < n; ++i)
+        if (p[i].semantics != OMC_SEM_TWO_PASS || p[i].n_paths != p[0].n_paths || p[i].n_steps != p[0].n_steps ||
+            p[i].r != p[0].r || p[i].T != p[0].T || p[i].n_steps < 2)
+            return false;
+    return true;
+}
+
+static int enqueue_seq_overlapped(omc_ctx* c, const omc_params* p, int n, double* out_pin)
+{
+    int rc;
+    const int64_t M = p[0].n_paths;
+    const int N = p[0].n_steps;
+    const int64_t ld = (M + 63) / 64 * 64;
+    const size_t sbytes = sizeof(float) * (size_t)ld * (size_t)(N + 1);
+    if ((rc = c->S.ensure(sbytes))) return rc;
+    if ((rc = c->S2.ensure(sbytes))) return rc;
+    if ((rc = c->seq_local.ensure(sizeof(double) * 8 * (size_t)n))) return rc;
+    omc::LsmWorkspace w[2];
+    if ((rc = prepare_lsm(c, M, N, p[0].r, p[0].T, true, false, &w[0]))) return rc;
+    // second set of the buffers a pricing owns between its pass 1 and its solves
+    if ((rc = c->part1b.ensure(sizeof(double) * 8 * (size_t)(N + 1) * (size_t)w[0].part1_tiles))) return rc;
+    if ((rc = c->gmomb.ensure(sizeof(double) * 8 * (size_t)(N + 1)))) return rc;
+    w[1] = w[0];
+    w[1].part1 = (double*)c->part1b.p;
+    w[1].gmom = (double*)c->gmomb.p;
+    if (!c->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        if (!c->ev_moments[b]) HIP_TRY(hipEventCreateWithFlags(&c->ev_moments[b], hipEventDisableTiming));
+        if (!c->ev_reduced[b]) HIP_TRY(hipEventCreateWithFlags(&c->ev_reduced[b], hipEventDisableTiming));
+    }
+    float* Sb[2] = {(float*)c->S.p, (float*)c->S2.p};
+    double* local = (double*)c->seq_local.p;
+    auto problem = [&](int k) {
+        return omc::LsmProblem{Sb[k & 1], ld, M, N, p[k].is_put ? 1 : 0, p[k].K, p[k].r, p[k].T};
+    };
+    // paths + pass 1 of pricing k on the main stream, then its moment table's all-reduce on the other one
+    auto phase_a = [&](int k) -> int {
+        const int b = k & 1;
+        omc::LsmWorkspace wk = w[b];
+        if (k == 0) {  // the first pricing carries the timing events
+            wk.ev_p1_begin = c->ev[3]; wk.ev_p1_end = c->ev[4];
+            HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        }
+        int r2;
+        if ((r2 = enqueue_paths(c, &p[k], Sb[b], ld))) return r2;
+        if (k == 0) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        HIP_TRY(omc::lsm_pass1_moments(c->stream, problem(k), wk));
+        HIP_TRY(hipEventRecord(c->ev_moments[b], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_moments[b], 0));
+        std::string err;
+        if ((r2 = omc::comm_allreduce_f64(c->comm, wk.gmom, (size_t)(8 * (N + 1)), 0, c->comm_stream, &err)))
+            return fail(r2, err.c_str());
+        HIP_TRY(hipEventRecord(c->ev_reduced[b], c->comm_stream));
+        return 0;
+    };
+    if ((rc = phase_a(0))) return rc;
+    for (int k = 0; k < n; ++k) {
+        // pricing k+1's paths and pass 1 run while pricing k's collective is in flight
+        if (k + 1 < n && (rc = phase_a(k + 1))) return rc;
+        const int b = k & 1;
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_reduced[b], 0));
+        omc::LsmWorkspace wk = w[b];
+        if (k == 0) { wk.ev_p2_begin = c->ev[5]; wk.ev_p2_end = c->ev[6]; }
+        wk.result = local + 8 * (size_t)k;
+        HIP_TRY(omc::lsm_solve_all(c->stream, problem(k), wk));
+        HIP_TRY(omc::lsm_pass2_apply(c->stream, problem(k), wk, false));
+        if (k == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    }
+    if ((rc = allreduce(c, local, 8 * n))) return rc;  // all result sums in one collective
+    HIP_TRY(hipMemcpyAsync(out_pin, local, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
 int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* res)
 {
     int rc;
@@ -1142,19 +1253,27 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     hipEvent_t ev_end = c->ev[2];
     if (!c->ev_seq) HIP_TRY(hipEventCreate(&c->ev_seq));
     ev_end = c->ev_seq;
+    const bool overlapped = seq_can_overlap(c, p, n);
     for (int attempt = 0;; ++attempt) {
         c->persist_used = 0;
-        for (int i = 0; i < n; ++i) {
-            // with an all-reduce hook the sums stay in device memory for the collective (which the hook
-            // enqueues on the stream, no host wait) and are copied to the slot afterwards
-            double* result = nullptr;
-            if ((rc = enqueue_pricing(c, &p[i], nullptr, 0, c->distributed() ? nullptr : c->seq_dev + 8 * (size_t)i,
-                                      i == 0, &result)))
-                return rc;
-            if (c->distributed())
-                HIP_TRY(hipMemcpyAsync(c->seq_pin + 8 * (size_t)i, result, sizeof(double) * 8, hipMemcpyDeviceToHost,
-                                       c->stream));
-            if (i == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        if (overlapped && (rc = enqueue_seq_overlapped(c, p, n, c->seq_pin))) return rc;
+        // across GPUs the sums stay in device memory (one slot per pricing) and are all-reduced together after
+        // the last pricing -- the hook / communicator sees ONE call with 8n doubles -- then copied out
+        const bool dist = c->distributed() && !overlapped;
+        if (dist && (rc = c->seq_local.ensure(sizeof(double) * 8 * (size_t)n))) return rc;
+        double* local = (double*)c->seq_local.p;
+        c->defer_result_allreduce = dist;
+        for (int i = 0; i < n && !overlapped; ++i) {
+            rc = enqueue_pricing(c, &p[i], nullptr, 0, dist ? local + 8 * (size_t)i : c->seq_dev + 8 * (size_t)i,
+                                 i == 0, nullptr);
+            if (rc) break;
+            if (i == 0 && hipEventRecord(c->ev[2], c->stream) != hipSuccess) { rc = fail(999, "hipEventRecord failed"); break; }
+        }
+        c->defer_result_allreduce = false;
+        if (rc) return rc;
+        if (dist) {
+            if ((rc = allreduce(c, local, 8 * n))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->seq_pin, local, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         }
         HIP_TRY(hipEventRecord(ev_end, c->stream));
         if ((rc = wait_stream(c))) return rc;

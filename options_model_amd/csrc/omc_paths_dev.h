@@ -8,15 +8,24 @@
 namespace omc {
 
 
+#ifndef OMC_NT_STORE
+#define OMC_NT_STORE 0  // experiment: path rows written with the nontemporal hint
+#endif
+
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
 {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
     if constexpr (VEC == 1) {
-        *p = v[0];
+        if (OMC_NT_STORE) __builtin_nontemporal_store(v[0], p);
+        else *p = v[0];
     } else if constexpr (VEC == 2) {
-        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+        if (OMC_NT_STORE) __builtin_nontemporal_store((f2v){v[0], v[1]}, reinterpret_cast<f2v*>(p));
+        else *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
     } else {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        if (OMC_NT_STORE) __builtin_nontemporal_store((f4v){v[0], v[1], v[2], v[3]}, reinterpret_cast<f4v*>(p));
+        else *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 

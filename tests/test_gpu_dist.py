@@ -247,6 +247,20 @@ def test_native_rccl_communicator_world_size_one(ctx):
             base = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=20_000, n_steps=12, seed=4,
                                                        stream=s))
             assert o["price"] == pytest.approx(base["price"], rel=1e-12)
+        # the overlapped sequence (collective of pricing k under the path generation of pricing k+1, two path
+        # buffers, one result collective at the end) against one pricing after the other: the same bits
+        streams = list(range(1, 8))
+        sp.ctx.set_option("seq_overlap", 1)   # (default: only with more than one rank)
+        on = sp.price_american_seq(300_000, streams, semantics="two_pass", n_steps=40, seed=9)
+        sp.ctx.set_option("seq_overlap", 0)
+        off = sp.price_american_seq(300_000, streams, semantics="two_pass", n_steps=40, seed=9)
+        sp.ctx.set_option("seq_overlap", -1)
+        for a, b, s in zip(on, off, streams):
+            assert (a["price"], a["sumsq"], a["n_exercised"], a["n_zero"], a["sum_nitm"]) == (
+                b["price"], b["sumsq"], b["n_exercised"], b["n_zero"], b["sum_nitm"])
+            base = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=300_000, n_steps=40, seed=9, stream=s))
+            assert a["price"] == base["price"] and a["sum_nitm"] == base["sum_nitm"]
+        assert len({o["price"] for o in on}) == len(streams)
     finally:
         sp.close()
 
