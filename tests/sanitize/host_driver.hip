@@ -53,6 +53,10 @@ int main()
     REQUIRE(omc_price_american(nullptr, &p, &res, nullptr, 0) != 0);
     REQUIRE(omc_price_american_seq(nullptr, &p, 1, &res) != 0);
     REQUIRE(omc_price_american_batch(nullptr, &p, 1, &res) != 0);
+    REQUIRE(omc_price_american_contnet(nullptr, &p, 32, 10, 1e-3, 1, &res) != 0);
+    REQUIRE(omc_lsm_contnet(nullptr, nullptr, 0, 1000, 10, 100.0, 0.05, 1.0, 1, 32, 10, 1e-3, 1, &res, nullptr, nullptr) != 0);
+    float net[8];
+    REQUIRE(omc_contnet_init_params(nullptr, 32, 1, 1, net, 8) != 0);
     REQUIRE(omc_set_option(nullptr, "gbm_vec", 1) != 0);
     REQUIRE(omc_set_allreduce_hook(nullptr, nullptr, nullptr) != 0);
     REQUIRE(omc_comm_info(nullptr, nullptr, nullptr) != 0);
@@ -104,6 +108,17 @@ int main()
     }
 
     // ---- per-step sweep: geometry helpers and the device argument image
+    // per-step network flow: scratch carving and the trainer width that hosts a net
+    REQUIRE(omc::cn_padded_width(1) == 32 && omc::cn_padded_width(32) == 32 && omc::cn_padded_width(33) == 64 &&
+            omc::cn_padded_width(128) == 128 && omc::cn_padded_width(129) < 0);
+    for (int64_t M : {int64_t(1), int64_t(2047), int64_t(2048), int64_t(2049), int64_t(8000000)}) {
+        omc::LsmProblem lp{nullptr, M, M, 10, 1, 100.0, 0.05, 1.0};
+        std::vector<char> scratch(omc::cn_scratch_bytes(M));
+        const char* hdr = (const char*)omc::cn_header(lp, scratch.data());
+        REQUIRE(hdr >= scratch.data() && hdr + 32 <= scratch.data() + scratch.size());
+        REQUIRE(((uintptr_t)(hdr - scratch.data()) & 7) == 0);
+    }
+    REQUIRE(omc::mlp_partial_bytes(32, 2, 32 * 5000) == sizeof(float) * 5000 * 1408);
     REQUIRE(omc::lsm_sweep_blocks(1) == 1);
     REQUIRE(omc::lsm_sweep_blocks(1000000) <= 256 && omc::lsm_sweep_blocks(64000000) <= 256);
     REQUIRE(omc::lsm_step_blocks(1000000) <= omc::kMaxLsmBlocks);

@@ -155,3 +155,22 @@ def test_curves_with_the_network_run_concurrently_and_equal_the_point_by_point_p
     for r in recs:
         d = r["Days to Expiry"]
         assert r["Option Value"] == p.price_american_option(95.0, d / 365, 4000, max(10, min(130, int(math.ceil(d)))))
+
+
+@pytest.mark.parametrize("M,N,hidden", [(2, 1, 32), (2, 2, 1), (66, 3, 5), (1002, 7, 32), (4098, 4, 64)])
+def test_contnet_edge_geometries_follow_the_restatement(ctx, M, N, hidden):
+    """Degenerate shapes of the reference loop: a single step (no regression at all), two steps (one fit), sets
+    of a handful of paths, a one-unit net, path counts that break every vector width."""
+    rng = np.random.default_rng(M * 131 + N)
+    z = rng.standard_normal((N, M // 2))
+    S = rf.gbm_paths_from_normals(z, 100.0, 0.05, 0.3, 0.5).astype(np.float32)
+    for is_put in (True, False):
+        cf_o, ex_o, nitm_o, _ = rf.lsm_per_step_contnet(S.astype(np.float64), 100.0, 0.05, 0.5, is_put, hidden=hidden,
+                                                        epochs=3, lr=1e-3,
+                                                        init=lambda t: ctx.contnet_init_params(hidden, t, 17))
+        Sd = ctx.to_device(S)
+        out = ctx.lsm_contnet(Sd, 100.0, 0.05, 0.5, is_put, hidden, 3, 1e-3, 17)
+        Sd.free()
+        assert int(((out["tex"] < N) != ex_o).sum()) <= max(1, M // 300)
+        assert out["sum_nitm"] == pytest.approx(nitm_o.sum(), abs=max(1, M // 300))
+        assert out["price"] == pytest.approx(cf_o.mean(), rel=5e-3, abs=1e-9)
