@@ -51,7 +51,7 @@ bench)
   for SEM in two_pass reference; do
     OUT="$R/gpurun_out/prof_${TAG}_$SEM"
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- \
-        python "$R/bench.py" --steps 10 --warmup 2 --semantics $SEM --no-cpu-baseline --no-variants --no-sustained \
+        python "$R/bench.py" --semantics $SEM --no-cpu-baseline --no-variants --no-sustained \
         > "$R/gpurun_out/bench_prof_${TAG}_$SEM.json" 2> "$R/gpurun_out/prof_${TAG}_$SEM.err"; rc=$?
     echo "rocprof $SEM exit=$rc"
     ok $rc || exit 1
@@ -59,10 +59,17 @@ bench)
   done
   OUT="$R/gpurun_out/prof_${TAG}_c4"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- \
-      python "$R/bench.py" --config c4 --steps 5 --warmup 1 --no-cpu-baseline --no-variants --no-sustained \
+      python "$R/bench.py" --config c4 --steps 20 --warmup 20 --no-cpu-baseline --no-variants --no-sustained \
       > "$R/gpurun_out/bench_prof_${TAG}_c4.json" 2> "$R/gpurun_out/prof_${TAG}_c4.err"; rc=$?
   echo "rocprof c4 exit=$rc"
   find "$OUT" -name "*kernel_stats.csv" | head -1 | xargs -r head -8
+  ok $rc || exit 1
+  cd "$R"
+  # the other single-GPU configurations as plain bench lines (no profiler)
+  timeout -k 10 400 python bench.py --config c3 --steps 10 --warmup 5 --no-variants > gpurun_out/bench_${TAG}_c3.json 2> gpurun_out/bench_${TAG}_c3.err; rc=$?
+  echo "bench c3 exit=$rc"; ok $rc || exit 1
+  timeout -k 10 400 python bench.py --config c4 --steps 20 --warmup 20 --no-variants > gpurun_out/bench_${TAG}_c4.json 2> gpurun_out/bench_${TAG}_c4.err; rc=$?
+  echo "bench c4 exit=$rc"
   ;;
 pmc)
   cd /tmp && export TMPDIR=/tmp
