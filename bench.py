@@ -292,8 +292,32 @@ def main():
         out = ctx.price_american(params(a.semantics, i))
         return out["price"], out
 
-    for i in range(a.warmup):
-        one_step(1000 + i)
+    # Across GPUs a sequence overlaps each pricing's moment all-reduce with the next pricing's paths + pass 1
+    # (library option "seq_overlap", default on for more than one rank).  Before anything is timed, every rank
+    # prices the same three streams both ways; unless all ranks see identical bits the overlap is switched off
+    # for the run -- and the line says which it was.
+    seq_overlap = "n/a"
+    if pricer is not None and comm.startswith("rccl-native") and a.semantics == "two_pass" and not a.sync_every_step:
+        if world > 1:
+            def bits(outs):
+                return [(o["sum"], o["sumsq"], o["n_exercised"], o["n_zero"], o["sum_nitm"]) for o in outs]
+            ctx.set_option("seq_overlap", 1)
+            on = bits(price_group([2000, 2001, 2002])[1])
+            ctx.set_option("seq_overlap", 0)
+            off = bits(price_group([2000, 2001, 2002])[1])
+            agree = pricer.allreduce_max(0.0 if on == off else 1.0) == 0.0
+            ctx.set_option("seq_overlap", 1 if agree else 0)
+            seq_overlap = "on" if agree else "off (self-check: overlapped != sequential)"
+        else:
+            seq_overlap = "off (one rank)"
+
+    # W untimed steps through the same entry point as the timed ones (buffers, clocks, code paths warm)
+    if a.sync_every_step:
+        for i in range(a.warmup):
+            one_step(1000 + i)
+    else:
+        for lo in range(0, a.warmup, a.group):
+            price_group([1000 + i for i in range(lo, min(lo + a.group, a.warmup))])
     barrier()
     ctx.sync()
     t0 = time.perf_counter()
@@ -352,7 +376,7 @@ def main():
                    "arithmetic": "f32 paths, f64 moments / solve / decisions / sums"},
         "paths_x252_per_sec_per_gpu": M * N * a.steps / elapsed / 252.0,
         "price": price, "price_stream": last_stream,
-        "rccl_ranks": rccl_ranks, "comm": comm,
+        "rccl_ranks": rccl_ranks, "comm": comm, "seq_overlap": seq_overlap,
     }
 
     # ---- roofline: every big kernel of the pricing, HIP-event time per launch inside the timed
