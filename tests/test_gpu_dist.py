@@ -273,4 +273,13 @@ def test_bench_force_dist_uses_native_rccl():
                      "--paths-per-gpu", "100000", "--n-steps", "50", "--force-dist", "--no-variants",
                      "--no-cpu-baseline", "--no-sustained"], root)
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["comm"].startswith("rccl-native")
-    assert d["price_check"]["rel_err"] < 1e-3
+    assert d["price_check"]["rel_err"] < 1e-3 and d["seq_overlap"] == "off (one rank)"
+    # the multi-rank start-up self-check (overlapped sequence == sequential one, bit for bit), rehearsed with one rank
+    os.environ["OMC_BENCH_SELFCHECK"] = "1"
+    try:
+        d2 = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--paths-per-gpu", "100000", "--n-steps", "50", "--force-dist", "--no-variants",
+                          "--no-cpu-baseline", "--no-sustained"], root)
+    finally:
+        del os.environ["OMC_BENCH_SELFCHECK"]
+    assert d2["seq_overlap"] == "on" and d2["price_check"]["rel_err"] < 1e-3
