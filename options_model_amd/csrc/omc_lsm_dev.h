@@ -168,7 +168,7 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { st[v] = sm[v] = sx[v] = 0.f; tex[v] = 0; }
     auto load_chunk = [&](int64_t jj) {
-        loadf<VEC>(St + jj, st);
+        loadf<VEC>(St + jj, st);  // (the nontemporal hint on this row, last read here, changes nothing: measured)
         if (do_mom) loadf<VEC>(Sm + jj, sm);
         if (!init) {
             if (SEM == 0) {
@@ -531,7 +531,7 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         if ((lane & 7) == 0) a.part1[((size_t)t * 8 + (lane >> 3)) * a.ntiles + tg] = s;
     };
     // Rows are read with the nontemporal hint (each byte is used once per launch): 253 -> 218 us at
-    // C2; the same hint on pass 2 or on the generator's stores did nothing or lost a little.
+    // C2 (pass 2 reads its rows the same way; on the generator's stores the hint only moves time between kernels).
     // Three rotating register buffers, rows fetched TWO steps ahead of their use; row indices are
     // clamped to the chunk, so every load is unconditional and the compiler can count them
     // (vmcnt(7..4) in the ISA instead of vmcnt(0)).  Measured (SQ counters):
@@ -677,19 +677,22 @@ __device__ __forceinline__ void lsm_pass2_body(Pass2Args a)
             for (int v = 0; v < VEC; ++v) l |= (tex[v] == N);
             return l;
         };
-        constexpr int U = 8;  // full blocks of U rows: U unconditional 16-byte loads in flight per lane
+        // full blocks of U rows: U unconditional 16-byte loads in flight per lane (4 and 16 measured slower).
+        // Rows are read with the nontemporal hint, each byte being used once per launch: 0.187 -> 0.169 ms at C2
+        // (tools/exp_pass2.sh; in round 1, before the sweep was restructured, the same hint did nothing here).
+        constexpr int U = 8;
         int t = N - 1;
         const float* col = a.S + j;
         for (; t >= U && live(); t -= U) {
             float st[U][VEC];
 #pragma unroll
-            for (int k = 0; k < U; ++k) loadf<VEC>(col + (int64_t)(t - k) * a.ld, st[k]);
+            for (int k = 0; k < U; ++k) loadf_stream<VEC>(col + (int64_t)(t - k) * a.ld, st[k]);
 #pragma unroll
             for (int k = 0; k < U; ++k) decide(st[k], t - k);
         }
         for (; t >= 1 && live(); --t) {
             float st[VEC];
-            loadf<VEC>(col + (int64_t)t * a.ld, st);
+            loadf_stream<VEC>(col + (int64_t)t * a.ld, st);
             decide(st, t);
         }
 #pragma unroll

@@ -107,6 +107,55 @@ __global__ __launch_bounds__(256) void read_lds_kernel(const float* __restrict__
     if (fold == 0x12345678u) sink[threadIdx.x] = 1.0f;
 }
 
+// the pass-2 pattern: a thread owns Q x 4 consecutive-in-tile paths for the WHOLE sweep and walks the rows
+// N-1 .. 1 in blocks of U (U x Q independent 16-byte loads in flight per lane, nothing prefetched across blocks);
+// a wave touches Q KB per row.  NT: nontemporal hint on or off.
+template <int Q, int U, bool NT>
+__global__ __launch_bounds__(256) void walk_kernel(const float* __restrict__ S, int64_t M, int N, float* sink)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = ((int64_t)blockIdx.x * 4 + wave) * (256 * Q);
+    if (tile >= M) return;
+    const float* col = S + tile + lane * 4;
+    uint32_t fold = 0;
+    int t = N - 1;
+    for (; t >= U; t -= U) {
+        f4 b[U][Q];
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const f4* p = reinterpret_cast<const f4*>(col + (int64_t)(t - k) * M + q * 256);
+                b[k][q] = NT ? __builtin_nontemporal_load(p) : *p;
+            }
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                fold ^= __float_as_uint(b[k][q].x) ^ __float_as_uint(b[k][q].y) ^ __float_as_uint(b[k][q].z) ^ __float_as_uint(b[k][q].w);
+    }
+    if (fold == 0x12345678u) sink[threadIdx.x] = 1.0f;
+}
+
+template <int Q, int U, bool NT>
+static void run_walk(const float* S, int64_t M, int N, float* sink, hipEvent_t e0, hipEvent_t e1)
+{
+    const unsigned grid = (unsigned)((M + 1024 * Q - 1) / (1024 * Q));
+    float best = 1e9f;
+    for (int rep = 0; rep < 12; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((walk_kernel<Q, U, NT>), dim3(grid), dim3(256), 0, 0, S, M, N, sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 4 && ms < best) best = ms;
+    }
+    const double b = 4.0 * M * (N - 1 - (N - 1) % U);
+    printf("walk  %d KB per wave-row, %2d rows in flight, %s, %5u workgroups: %7.3f ms  %6.2f TB/s\n", Q, U,
+           NT ? "nt" : "  ", grid, best, b / best / 1e9);
+}
+
 int main()
 {
     const int64_t M = 1000000;
@@ -157,6 +206,13 @@ int main()
                    mode == 0 ? grid0 : (int)(grows.x * grows.y), best, b / best / 1e9, b / best / 1e9 / 8.0 * 100);
         }
     }
+    run_walk<1, 8, false>(S, M, N, sink, e0, e1);   // lsm_pass2_kernel's pattern
+    run_walk<1, 8, true>(S, M, N, sink, e0, e1);
+    run_walk<1, 16, false>(S, M, N, sink, e0, e1);
+    run_walk<2, 8, false>(S, M, N, sink, e0, e1);
+    run_walk<2, 4, false>(S, M, N, sink, e0, e1);
+    run_walk<4, 4, false>(S, M, N, sink, e0, e1);
+    run_walk<4, 2, false>(S, M, N, sink, e0, e1);
     if (hipGetLastError() != hipSuccess) { printf("HIP error\n"); return 1; }
     return 0;
 }
