@@ -344,8 +344,7 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
     if (semantics == OMC_SEM_TWO_PASS) {
         HIP_TRY(omc::lsm_pass1_moments(st, p, w));
         if (c->distributed() && (rc = allreduce(c, w.gmom, 8 * (p.N + 1)))) return rc;
-        HIP_TRY(omc::lsm_solve_all(st, p, w));
-        HIP_TRY(omc::lsm_pass2_apply(st, p, w, write_state));
+        HIP_TRY(omc::lsm_pass2_apply(st, p, w, write_state, true));  // solves the fits itself
     } else {
         const bool ext = c->distributed();
         const bool flags = semantics == OMC_SEM_REFERENCE;
@@ -1221,8 +1220,7 @@ static int enqueue_seq_overlapped(omc_ctx* c, const omc_params* p, int n, double
         omc::LsmWorkspace wk = w[b];
         if (k == 0) { wk.ev_p2_begin = c->ev[5]; wk.ev_p2_end = c->ev[6]; }
         wk.result = local + 8 * (size_t)k;
-        HIP_TRY(omc::lsm_solve_all(c->stream, problem(k), wk));
-        HIP_TRY(omc::lsm_pass2_apply(c->stream, problem(k), wk, false));
+        HIP_TRY(omc::lsm_pass2_apply(c->stream, problem(k), wk, false, true));
         if (k == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     }
     if ((rc = allreduce(c, local, 8 * n))) return rc;  // all result sums in one collective

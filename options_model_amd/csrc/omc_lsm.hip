@@ -291,12 +291,16 @@ hipError_t lsm_solve_all(hipStream_t st, const LsmProblem& p, const LsmWorkspace
 }
 
 hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w,
-                           bool write_state)
+                           bool write_state, bool solve_from_moments)
 {
     Pass2Args a;
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
     a.K = p.K; a.invK = 1.0 / p.K; a.D = w.D; a.betas = w.betas; a.sx = w.sx; a.tex = w.tex;
     a.part = w.part;
+    if (solve_from_moments) {
+        a.gmom = w.gmom;
+        a.betas_out = w.betas;
+    }
     const int nblk = lsm_step_blocks(p.M);
     a.nblk = nblk; a.pstride = kPStride;
     const size_t dyn = sizeof(double) * 4 * (size_t)(p.N + 1);

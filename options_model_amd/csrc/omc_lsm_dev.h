@@ -622,6 +622,11 @@ struct Pass2Args {
     int32_t* tex;
     double* part;
     int nblk, pstride;
+    // non-null: the fits are not given but solved here from the reduced moment table [N+1][8] (every workgroup
+    // solves all steps itself, one step per thread: cheaper than a dependent launch in between), and workgroup 0
+    // writes them to betas_out [N+1][4]
+    const double* gmom = nullptr;
+    double* betas_out = nullptr;
 };
 
 // Pass 2 (options_model_3.py:615-651) with frozen per-step fits: every path is
@@ -638,10 +643,29 @@ __device__ __forceinline__ void lsm_pass2_body(Pass2Args a)
     const int N = a.N;
     // a step with an empty regression set never exercises: give it an infinite continuation
     // value instead of a branch in the sweep
-    for (int k = tid; k < (N + 1) * 4; k += kBlock) {
-        const int t = k >> 2;
-        const bool fit = t >= 1 && t < N && a.betas[(size_t)t * 4 + 3] > 0.5;
-        sh_b[k] = fit ? a.betas[k] : ((k & 3) == 0 ? __builtin_huge_val() : 0.0);
+    if (a.gmom) {
+        for (int t = tid; t <= N; t += kBlock) {
+            double m[8], beta[3] = {0.0, 0.0, 0.0};
+            const bool inner = t >= 1 && t < N;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = inner ? a.gmom[(size_t)t * 8 + q] : 0.0;
+            if (inner) solve_poly2(m, beta);  // the very function lsm_solve_all_kernel runs: same bits
+            const bool fit = inner && m[0] > 0.5;
+            sh_b[4 * t] = fit ? beta[0] : __builtin_huge_val();
+            sh_b[4 * t + 1] = fit ? beta[1] : 0.0;
+            sh_b[4 * t + 2] = fit ? beta[2] : 0.0;
+            sh_b[4 * t + 3] = 0.0;
+            if (blockIdx.x == 0 && inner && a.betas_out) {
+                double* bo = a.betas_out + (size_t)t * 4;
+                bo[0] = beta[0]; bo[1] = beta[1]; bo[2] = beta[2]; bo[3] = m[0];
+            }
+        }
+    } else {
+        for (int k = tid; k < (N + 1) * 4; k += kBlock) {
+            const int t = k >> 2;
+            const bool fit = t >= 1 && t < N && a.betas[(size_t)t * 4 + 3] > 0.5;
+            sh_b[k] = fit ? a.betas[k] : ((k & 3) == 0 ? __builtin_huge_val() : 0.0);
+        }
     }
     __syncthreads();
     const double K = a.K, invK = a.invK;
