@@ -156,9 +156,9 @@ static void run_walk(const float* S, int64_t M, int N, float* sink, hipEvent_t e
            NT ? "nt" : "  ", grid, best, b / best / 1e9);
 }
 
-int main()
+int main(int argc, char** argv)
 {
-    const int64_t M = 1000000;
+    const int64_t M = argc > 1 ? atoll(argv[1]) : 1000000;
     const int N = 252, tchunk = 32;
     float *S, *sink;
     hipMalloc(&S, sizeof(float) * M * (N + 1));
