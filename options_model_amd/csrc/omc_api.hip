@@ -988,6 +988,7 @@ int contnet_sweep(omc_ctx* c, const omc::LsmProblem& p, omc::LsmWorkspace& w, in
     if ((rc = c->cn_cont.ensure(sizeof(float) * (size_t)M))) return rc;
     if ((rc = c->mlp_wt.ensure(omc::mlp_wt_bytes(H, 2)))) return rc;
     if ((rc = c->mlp_loss.ensure(sizeof(double)))) return rc;
+    HIP_TRY(hipMemsetAsync(c->mlp_loss.p, 0, sizeof(double), c->stream));  // the trainer adds its losses here (unused)
     float* net = (float*)c->cn_net.p;
     w.cont = (const float*)c->cn_cont.p;
     w.ldc = 0;  // one row, rewritten every step
