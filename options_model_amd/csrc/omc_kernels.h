@@ -103,9 +103,8 @@ hipError_t lsm_sweep_persistent(hipStream_t st, const LsmProblem& p, const LsmWo
 
 // two-pass flow (semantics 2)
 hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);
-hipError_t lsm_solve_all(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);
 // sticky sweep with the betas of w.betas -- or, when solve_from_moments, with fits every workgroup solves itself
-// from w.gmom (no lsm_solve_all launch in between; w.betas is still written, by workgroup 0); writes sx/tex
+// from w.gmom (no dependent solve launch in between; w.betas is still written, by workgroup 0); writes sx/tex
 // when write_state, leaves sums in w.result
 hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w,
                            bool write_state, bool solve_from_moments = false);

@@ -59,11 +59,6 @@ __global__ __launch_bounds__(kBlock) void lsm_reduce_pass1_kernel(const double* 
     lsm_reduce_pass1_body(part1, gmom, ntiles, N);
 }
 
-__global__ void lsm_solve_all_kernel(const double* gmom, double* betas, int N)
-{
-    lsm_solve_all_body(gmom, betas, N);
-}
-
 template <int VEC, bool WRITE_STATE>
 __global__ __launch_bounds__(kBlock) void lsm_pass2_kernel(Pass2Args a) { lsm_pass2_body<VEC, WRITE_STATE>(a); }
 
@@ -280,13 +275,6 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     if (w.ev_p1_end) (void)hipEventRecord(w.ev_p1_end, st);
     hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1, 8), dim3(kBlock), 0, st, w.part1, w.gmom,
                        a.ntiles, p.N);
-    return hipGetLastError();
-}
-
-hipError_t lsm_solve_all(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w)
-{
-    hipLaunchKernelGGL(lsm_solve_all_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, w.gmom,
-                       w.betas, p.N);
     return hipGetLastError();
 }
 
