@@ -522,6 +522,24 @@ def main():
                                                     "frac": rows_seen * flop / tk / 1e12 / 157.3}
             except Exception as e:
                 var["nn_2x64"] = {"error": repr(e)}
+        # the regressor the reference's v1 / v2 pricers really use: a fresh ContNet per time step (omc_contnet.hip),
+        # at the size those files default to and at this workload's size
+        try:
+            cn = {}
+            for tag, (m_, n_) in (("10k_x_50", (10_000, 50)), ("workload", (M, N))):
+                pp = _ffi.make_params(model=model, is_put=is_put, semantics="reference", n_paths=m_, n_steps=n_, seed=42,
+                                      heston_scheme="full_truncation" if model == "heston" else "reference")
+                ctx.price_american_contnet(pp, 32, 10, 1e-3, 42)  # warm
+                t1 = time.perf_counter()
+                reps = 5 if m_ <= 100_000 else 2
+                for k in range(reps):
+                    o = ctx.price_american_contnet(pp, 32, 10, 1e-3, 42)
+                dt = (time.perf_counter() - t1) / reps
+                cn[tag] = {"paths": m_, "steps": n_, "ms_per_pricing": dt * 1e3, "ms_per_time_step": dt * 1e3 / max(1, n_ - 1),
+                           "path_steps_per_s": m_ * n_ / dt, "price": o["price"], "training_rows": o["sum_nitm"]}
+            var["contnet_per_step"] = cn
+        except Exception as e:
+            var["contnet_per_step"] = {"error": repr(e)}
         line["variants"] = var
 
     if rank == 0 and a.gpus == 1 and not a.force_dist and not a.no_cpu_baseline:
