@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 CONFIGS = {  # BASELINE.json configs[1..3]
     "c2": dict(model="gbm", paths_per_gpu=1_000_000),
     "c3": dict(model="gbm", paths_per_gpu=8_000_000),
+    "c3x1": dict(model="gbm", paths_per_gpu=64_000_000),  # ALL of configs[2] on one GPU (65 GB of paths)
     "c4": dict(model="heston", paths_per_gpu=4_000_000),
 }
 MARKET = dict(S0=100.0, K=100.0, r=0.05, sigma=0.2, T=1.0)

@@ -144,3 +144,22 @@ def test_full_size_pricing_is_exactly_homogeneous_in_spot_and_strike(ctx, model,
             assert o["price"] == f * a["price"] and o["sum"] == f * a["sum"] and o["sumsq"] == f * f * a["sumsq"]
             assert (o["n_exercised"], o["n_zero"], o["sum_nitm"]) == (a["n_exercised"], a["n_zero"], a["sum_nitm"])
         assert a["n_exercised"] > M // 10
+
+
+def test_config3_at_full_size_on_one_gpu(ctx):
+    """BASELINE config 3 names 64M paths x 252 steps across 8 GPUs; the whole of it (65 GB of paths) also fits ONE
+    MI355X.  Largest size the suite touches: 64-bit indexing everywhere, exact homogeneity (see above), agreement
+    with the 1M-path pricing of the same contract within Monte-Carlo error, and the per-step flow's counters."""
+    from options_model_amd import _ffi
+    M, N = 64_000_000, 252
+    a = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=M, n_steps=N, seed=5))
+    b = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=M, n_steps=N, seed=5, S0=400.0, K=400.0))
+    assert b["price"] == 4.0 * a["price"] and b["n_exercised"] == a["n_exercised"] and b["sum_nitm"] == a["sum_nitm"]
+    small = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=1_000_000, n_steps=N, seed=1234))
+    se = math.sqrt(a["std"] ** 2 / M + small["std"] ** 2 / 1e6)
+    assert abs(a["price"] - small["price"]) < 5 * se + 0.01
+    assert a["n_paths"] == M and 0.4 * M < a["n_exercised"] < 0.7 * M and a["sum_nitm"] > 100 * M
+    r = ctx.price_american(_ffi.make_params(semantics="reference", n_paths=M, n_steps=N, seed=5))
+    assert 5.9 < r["price"] < 6.1 and r["n_exercised"] > 0.9 * M
+    print(f"\nconfig 3 on one GPU: two-pass {a['ms_total']:.1f} ms = {M * N / a['ms_total'] / 1e-3:.3e} path-steps/s, "
+          f"per-step flow {r['ms_total']:.1f} ms")

@@ -69,7 +69,9 @@ bench)
   timeout -k 10 400 python bench.py --config c3 --steps 10 --warmup 5 --no-variants > gpurun_out/bench_${TAG}_c3.json 2> gpurun_out/bench_${TAG}_c3.err; rc=$?
   echo "bench c3 exit=$rc"; ok $rc || exit 1
   timeout -k 10 400 python bench.py --config c4 --steps 20 --warmup 20 --no-variants > gpurun_out/bench_${TAG}_c4.json 2> gpurun_out/bench_${TAG}_c4.err; rc=$?
-  echo "bench c4 exit=$rc"
+  echo "bench c4 exit=$rc"; ok $rc || exit 1
+  timeout -k 10 500 python bench.py --config c3x1 --steps 5 --warmup 3 --no-variants > gpurun_out/bench_${TAG}_c3x1.json 2> gpurun_out/bench_${TAG}_c3x1.err; rc=$?
+  echo "bench c3x1 exit=$rc"
   ;;
 pmc)
   cd /tmp && export TMPDIR=/tmp
