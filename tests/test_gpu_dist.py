@@ -110,8 +110,16 @@ def test_world_size_normalisation_with_doubling_hook(tctx, ctx):
         c.set_option("world_size", 2)
         with torch.cuda.stream(stream):
             out = c.price_american(p)
+            # a sequence defers the result sums of all its pricings to ONE hook call of 8n doubles
+            calls = []
+            c.set_allreduce_hook(lambda dptr, count: (calls.append(count), hook(dptr, count)))
+            seq = c.price_american_seq([p, p, p])
         c.set_allreduce_hook(None)
         c.set_option("world_size", 1)
+        assert calls[-1] == 24 and calls.count(24) == 1
+        for o in seq:
+            assert (o["price"], o["n_exercised"], o["sum_nitm"], o["n_paths"]) == (
+                out["price"], out["n_exercised"], out["sum_nitm"], out["n_paths"])
         assert out["n_paths"] == 60000 and out["n_exercised"] == 2 * base["n_exercised"]
         # the regression-set sizes come from the moment table, which is global on every rank BEFORE the
         # result sums are all-reduced: they must come out once per rank, not world_size times each
