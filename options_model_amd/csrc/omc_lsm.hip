@@ -248,7 +248,25 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     const int tpw = (v4 && (tpw_env == 1 || tpw_env == 2 || tpw_env == 8)) ? tpw_env : 4;
     const int64_t per_wave = 64 * (int64_t)(v4 ? 4 : 1) * tpw;  // paths per wave per step
     a.ntiles = (p.M + per_wave - 1) / per_wave;
-    a.tchunk = (tch_env >= 2 && tch_env <= 64) ? tch_env : 32;
+    // Steps per workgroup.  The kernel holds 3 waves per SIMD (152 VGPRs), i.e. 3 workgroups per CU: when all the
+    // workgroups of a launch fit on the chip at once there is no partly filled last round of dispatch (measured at
+    // C2, 245 tile-workgroups: 8 chunks of 32 steps = 2.55 rounds 0.214 ms, 4 x 63 = 1.28 rounds 0.230, 3 x 84 =
+    // 0.96 round 0.207), so take the most chunks that still fit; larger problems run many rounds and keep 32.
+    // The partition changes no sum: partials are per (step, tile).
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 256;
+        return n > 0 ? n : 256;
+    }();
+    int tchunk = 32;
+    const int64_t wgs_x = (a.ntiles + 3) / 4;
+    if (wgs_x <= 3 * (int64_t)cus && p.N > 2) {
+        const int chunks = (int)((3 * (int64_t)cus) / wgs_x);
+        const int t = (p.N - 1 + chunks - 1) / chunks;
+        if (t <= 126 && t >= 32) tchunk = t;
+    }
+    a.tchunk = (tch_env >= 2 && tch_env <= 126) ? tch_env : tchunk;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
     static const int diag_env = getenv("OMC_PASS1_DIAG") ? atoi(getenv("OMC_PASS1_DIAG")) : 0;
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);

@@ -406,7 +406,7 @@ template <int VEC, int TPW, int PUT = -1, int DIAG = 0>
 __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
 {
     __shared__ double wl[kBlock / 64][kWaveRedDoubles];
-    __shared__ double shD[kBlock / 64][64];
+    __shared__ double shD[kBlock / 64][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tg = (int64_t)blockIdx.x * (kBlock / 64) + wave;
     if (tg >= a.ntiles) return;  // whole wave leaves; no workgroup barrier below
@@ -423,7 +423,7 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     // The chunk's discount factors go through the wave's LDS patch: a vector-memory load of
     // D[N-t] inside the loop would sit behind the row prefetch in the in-order vmcnt queue
     // and expose the prefetch latency every step.
-    if (lane < t1 - t0) shD[wave][lane] = a.D[a.N - (t0 + lane)];
+    for (int i = lane; i < t1 - t0; i += 64) shD[wave][i] = a.D[a.N - (t0 + i)];
     // Padding columns (beyond M) read column 0 and are masked out: every load below is
     // unconditional, so the compiler can count outstanding loads instead of draining them.
     const float* colp[TPW];
