@@ -163,3 +163,17 @@ def test_config3_at_full_size_on_one_gpu(ctx):
     assert 5.9 < r["price"] < 6.1 and r["n_exercised"] > 0.9 * M
     print(f"\nconfig 3 on one GPU: two-pass {a['ms_total']:.1f} ms = {M * N / a['ms_total'] / 1e-3:.3e} path-steps/s, "
           f"per-step flow {r['ms_total']:.1f} ms")
+
+
+def test_pass1_time_partition_changes_no_number():
+    """lsm_pass1_kernel picks the number of time steps per workgroup from the launch's size (one dispatch round when
+    the launch fits the chip); partials are per (step, tile), so ANY partition must return the same bits.
+    tools/soak_tchunk.py prices 120 problems (sizes around every threshold of that choice, GBM and Heston, puts and
+    calls) under the automatic choice and two forced ones in separate processes and compares sums and counters."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_tchunk.py")], capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
