@@ -128,20 +128,41 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(n: int) -> int:
+def launch_ranks(n: int, deadline_s: float, argv=None) -> int:
     """Parent of a `--gpus N` run without a launcher: start N rank processes (this script again, with
     the rank environment) and relay rank 0's JSON line.  No GPU call is made here; a child that fails
-    takes the job down with a non-zero exit code (children are never re-exec'd or retried)."""
+    takes the job down with a non-zero exit code (children are never re-exec'd or retried), and so does
+    the overall deadline (`--rank-timeout`): the ranks still running then are terminated -- exactly the
+    processes started here -- and named on stderr, so that a rank stuck inside a communicator call ends
+    as an error, not as a job that never finishes."""
+    import tempfile
     port = free_port()
+    nonce = os.urandom(8).hex()  # part of the rendezvous file names: no collision with any other launch
     procs = []
+    out0 = tempfile.TemporaryFile()  # rank 0's stdout (a file, so that nobody blocks on a full pipe)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMC_RDZV_NONCE=nonce)
+        # the host driver only supports dmabuf IPC: RCCL needs this (it is exported on the GPU boxes; set it for
+        # launches from a bare environment too, never override what the caller chose)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+        procs.append(subprocess.Popen(argv or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else sys.stderr.fileno()))
     rc = 0
     alive = set(range(n))
+    t0 = time.monotonic()
+
+    def stop(ranks):
+        for q in ranks:  # exactly the processes started above
+            procs[q].terminate()
+        t1 = time.monotonic()
+        for q in ranks:
+            try:
+                procs[q].wait(max(0.1, 10.0 - (time.monotonic() - t1)))
+            except subprocess.TimeoutExpired:
+                procs[q].kill()
+                procs[q].wait()
+
     while alive:
         for r in sorted(alive):
             code = procs[r].poll()
@@ -151,11 +172,16 @@ def launch_ranks(n: int) -> int:
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
                 print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
-                for q in alive:  # exactly the processes started above
-                    procs[q].terminate()
+                stop(sorted(alive))
+        if alive and rc == 0 and time.monotonic() - t0 > deadline_s:
+            rc = 124
+            print(f"bench.py: rank(s) {sorted(alive)} did not finish within --rank-timeout {deadline_s:.0f} s; "
+                  f"terminating them", file=sys.stderr)
+            stop(sorted(alive))
         if alive:
             time.sleep(0.05)
-    out = procs[0].stdout.read().decode()
+    out0.seek(0)
+    out = out0.read().decode()
     if rc == 0:
         sys.stdout.write(out)
         sys.stdout.flush()
@@ -194,6 +220,14 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="go through the communicator even with one rank (rehearsal of the N>1 path)")
+    ap.add_argument("--rank-timeout", type=float, default=300.0,
+                    help="multi-rank runs: overall deadline in seconds; ranks still running then are ended and the job "
+                         "exits non-zero (launcher and, inside every rank, a watchdog)")
+    ap.add_argument("--min-warmup-seconds", type=float, default=0.3,
+                    help="after the --warmup pricings keep pricing until two consecutive groups differ by < 2 %% and at "
+                         "least this much time has passed (the GPU's clocks come up over the first ~0.1-0.3 s of work)")
+    ap.add_argument("--kernel-samples", type=int, default=8,
+                    help="at least this many pricings of the timed region carry their own HIP events")
     a = ap.parse_args()
     if a.only_timed:
         a.no_cpu_baseline = a.no_variants = a.no_sustained = True
@@ -201,7 +235,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(a.gpus))  # nothing above touched the GPU
+        sys.exit(launch_ranks(a.gpus, a.rank_timeout))  # nothing above touched the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -241,14 +275,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         from options_model_amd import dist as omc_dist
+        # a rank that gets stuck anywhere below (communicator bring-up, a collective whose peer died) ends itself
+        watchdog = omc_dist.Watchdog(a.rank_timeout, f"bench.py rank {rank}")
         if backend == "rccl":
             try:
-                pricer = omc_dist.RcclPricer(local_rank, rank, world)
+                pricer = omc_dist.RcclPricer(local_rank, rank, world, init_timeout_s=min(a.rank_timeout, 300.0))
                 comm = "rccl-native (ncclAllReduce enqueued by libomc.so)"
-            except Exception as e:  # library missing / init refused: same collectives through torch
-                print(f"bench.py rank {rank}: native RCCL unavailable ({e}); using torch.distributed nccl",
+            except omc_dist.RcclUnavailable as e:
+                # raised on EVERY rank or on none (the ranks vote): all of them take the torch transport together
+                print(f"bench.py rank {rank}: native RCCL unavailable for this job ({e}); using torch.distributed",
                       file=sys.stderr)
-                backend = "nccl"
+                backend = "gloo" if a.single_device else "nccl"  # (two ranks cannot share a device under RCCL)
+            # anything else (a rank that never voted, a context that cannot be created) ends this rank non-zero
         if pricer is None:
             import torch
             import torch.distributed as td
@@ -312,52 +350,89 @@ def main():
         else:
             seq_overlap = "off (one rank)"
 
-    # W untimed steps through the same entry point as the timed ones (buffers, clocks, code paths warm)
+    # W untimed steps through the same entry point as the timed ones (buffers, code paths warm) ...
     if a.sync_every_step:
         for i in range(a.warmup):
             one_step(1000 + i)
     else:
         for lo in range(0, a.warmup, a.group):
             price_group([1000 + i for i in range(lo, min(lo + a.group, a.warmup))])
+    # ... then warm-up by TIME, whatever --warmup says: the clocks of a GPU that was idle come up over its first
+    # ~0.1-0.3 s of work (the same kernel ran 1.46 -> 0.93 ms over its first 13 launches, profiles/r02f_c4_*), so a
+    # count-based warm-up of a 0.55 ms pricing ends long before they have.  Groups of `--group` pricings until two
+    # consecutive groups differ by < 2 % AND --min-warmup-seconds have passed (cap 5 s).  Across ranks the decision
+    # is collective (max over ranks), so every rank runs the same number of groups.
+    barrier()
+    ctx.sync()
+    tw0 = time.perf_counter()
+    prev, settled, wgroups = None, False, 0
+    while True:
+        tg = time.perf_counter()
+        if a.sync_every_step:
+            for i in range(a.group):
+                one_step(1500 + i)
+        else:
+            price_group([1500 + i for i in range(a.group)])
+        ctx.sync()
+        cur = time.perf_counter() - tg
+        wgroups += 1
+        close = prev is not None and abs(cur - prev) <= 0.02 * max(cur, prev)
+        spent = time.perf_counter() - tw0
+        stop = (close and spent >= a.min_warmup_seconds) or spent >= 5.0
+        if dist_mode:  # all ranks leave the loop together
+            stop = pricer.allreduce_max(0.0 if stop else 1.0) == 0.0
+        if stop:
+            settled = close
+            break
+        prev = cur
+    warm_s = time.perf_counter() - tw0
+    # per-kernel HIP events: not only on every group's first pricing but on every `stride`-th one, so that the timed
+    # region yields at least --kernel-samples samples (an event costs a stream marker, hence not on every pricing)
+    ev_stride = max(1, a.steps // max(1, a.kernel_samples))
+    ctx.set_option("seq_event_stride", ev_stride)
     barrier()
     ctx.sync()
     t0 = time.perf_counter()
     ms_paths = ms_lsm = ms_p1 = ms_p2 = 0.0
     price = 0.0
     last_stream = a.steps - 1
+    nsamp = 0
     if not a.sync_every_step:
         # The K pricings are enqueued through omc_price_american_seq in groups of `--group` (no host
         # synchronisation inside a group: pricing i + 1 is launched while pricing i runs; with several
-        # ranks the all-reduces are stream-ordered too); every group's first pricing carries the HIP
-        # events (on the library's own stream) the per-kernel times come from.
-        nsamp = 0
+        # ranks the all-reduces are stream-ordered too); the pricings marked `timed` carry HIP events (on
+        # the library's own stream): the per-kernel times are averaged over them.
+        tot_lsm = 0.0
         for lo in range(0, a.steps, a.group):
             ids = list(range(lo, min(lo + a.group, a.steps)))
             price, outs = price_group(ids)
-            ms_paths += outs[0]["ms_paths"]
-            ms_lsm += outs[0]["ms_lsm"] if len(outs) == 1 else sum(o["ms_total"] for o in outs) / len(outs) - outs[0]["ms_paths"]
-            ms_p1 += outs[0].get("ms_pass1", 0.0)
-            ms_p2 += outs[0].get("ms_pass2", 0.0)
-            nsamp += 1
-        scale = a.steps / nsamp  # the averages below divide by a.steps
-        ms_paths *= scale; ms_lsm *= scale; ms_p1 *= scale; ms_p2 *= scale
+            last_out = outs[-1]
+            for o in outs:
+                if o.get("timed"):
+                    ms_paths += o["ms_paths"]
+                    ms_p1 += o.get("ms_pass1", 0.0)
+                    ms_p2 += o.get("ms_pass2", 0.0)
+                    nsamp += 1
+            tot_lsm += sum(o["ms_total"] for o in outs)
+        ms_paths /= max(nsamp, 1); ms_p1 /= max(nsamp, 1); ms_p2 /= max(nsamp, 1)
+        ms_lsm = tot_lsm / a.steps - ms_paths
     else:
         for i in range(a.steps):
             price, loc = one_step(i)
+            last_out = loc
             ms_paths += loc["ms_paths"]
             ms_lsm += loc["ms_lsm"]
             ms_p1 += loc.get("ms_pass1", 0.0)
             ms_p2 += loc.get("ms_pass2", 0.0)
+        nsamp = a.steps
+        ms_paths /= a.steps; ms_lsm /= a.steps; ms_p1 /= a.steps; ms_p2 /= a.steps
     barrier()
     ctx.sync()
     elapsed = time.perf_counter() - t0
     if dist_mode:
         elapsed = pricer.allreduce_max(elapsed)
+    ctx.set_option("seq_event_stride", 0)
 
-    ms_paths /= a.steps
-    ms_lsm /= a.steps
-    ms_p1 /= a.steps
-    ms_p2 /= a.steps
     b_gen = 4.0 * (N + 1) * M
     b_lsm = lsm_algorithmic_bytes(a.semantics, M, N)
     line = {
@@ -377,7 +452,12 @@ def main():
                    "arithmetic": "f32 paths, f64 moments / solve / decisions / sums"},
         "paths_x252_per_sec_per_gpu": M * N * a.steps / elapsed / 252.0,
         "price": price, "price_stream": last_stream,
+        "last_pricing": {k: last_out[k] for k in ("n_paths", "n_exercised", "n_zero", "sum_nitm", "sum", "sumsq")},
         "rccl_ranks": rccl_ranks, "comm": comm, "seq_overlap": seq_overlap,
+        "clock_settled": bool(settled),
+        "warmup_by_time": {"seconds": warm_s, "pricings": wgroups * a.group, "rule": "two consecutive groups within 2 %, "
+                           f">= {a.min_warmup_seconds} s (cap 5 s), after the --warmup pricings"},
+        "kernel_event_samples": nsamp,
     }
 
     # ---- roofline: every big kernel of the pricing, HIP-event time per launch inside the timed
@@ -441,7 +521,8 @@ def main():
             dt = pricer.allreduce_max(dt)
         ms_sweep = sum(o["ms_total"] for o in outs) / len(outs) - outs[0]["ms_paths"]
         r = rf("lsm_step_kernel", step_bytes_per_path("reference") * M, ms_sweep / N, launches=N)
-        r.update(flow="reference (per-step sticky flow: Options_model.py:108-157)", price=pr,
+        r.update(flow="reference (per-step sticky flow: Options_model.py:108-157)", price=pr, price_stream=reps - 1,
+                 last_pricing={k: outs[-1][k] for k in ("n_paths", "n_exercised", "n_zero", "sum_nitm")},
                  ms_per_pricing=1e3 * dt / reps, path_steps_per_s=world * M * N * reps / dt,
                  note="ms_per_launch = HIP-event time of the whole N-launch sweep / N (kernel boundaries included)")
         line["roofline_per_step"] = r
@@ -467,6 +548,7 @@ def main():
         line["sustained"] = {"pricings": n, "seconds": dt, "ms_per_step": 1e3 * dt / n,
                              "value": world * M * N * n / dt, "unit": "path-steps/s",
                              "vs_timed_region": (world * M * N * n / dt) / line["value"]}
+        line["timed_vs_sustained_ms"] = line["ms_per_step"] / line["sustained"]["ms_per_step"]
 
     # ---- parity in the bench line: GPU vs the CPU oracle on the SAME Philox (seed, stream), bounded slice
     if rank == 0 and not a.only_timed:
@@ -538,6 +620,10 @@ def main():
                 dt = (time.perf_counter() - t1) / reps
                 cn[tag] = {"paths": m_, "steps": n_, "ms_per_pricing": dt * 1e3, "ms_per_time_step": dt * 1e3 / max(1, n_ - 1),
                            "path_steps_per_s": m_ * n_ / dt, "price": o["price"], "training_rows": o["sum_nitm"]}
+            cn["parity"] = ("the reference's v1 / v2 regressor (fresh ContNet per step, Options_model.py:14-25,127-142) is UNSEEDED "
+                            "there, so a price-for-price match does not exist: checked as <= 0.2 % flipped exercise decisions and "
+                            "2e-3 on the price against a torch restatement started from the same initial nets, and within 1 % of "
+                            "the reference's recorded prices (tests/test_gpu_contnet.py)")
             var["contnet_per_step"] = cn
         except Exception as e:
             var["contnet_per_step"] = {"error": repr(e)}
@@ -545,6 +631,12 @@ def main():
 
     if rank == 0 and a.gpus == 1 and not a.force_dist and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(model, M, N, a.semantics, is_put, 42, last_stream)
+        # the reference itself cannot run on the GPU box (it only exists in the build container): its measured
+        # figure is quoted from BASELINE.md section 2 beside the port's
+        line["cpu_baseline"]["reference_quoted"] = {
+            "value": 3.5e3, "unit": "path-steps/s", "cores": 8, "kind": "reference",
+            "sample": "BASELINE.md section 2: options_model_3.AdvancedOptionPricer, configs[0] (GBM American put, 10k paths x 50 "
+                      "steps, its NN regressor, 133-147 s on the 8-vCPU build container); quoted, not re-run here"}
     elif rank == 0:
         line["cpu_baseline"] = None
     if stdout_fd is not None:
@@ -559,6 +651,7 @@ def main():
         if comm.startswith("torch"):
             import torch.distributed as td
             td.destroy_process_group()
+        watchdog.cancel()
     else:
         ctx.close()
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OMC_ABI_VERSION 4
+#define OMC_ABI_VERSION 5
 
 typedef struct omc_ctx omc_ctx;
 
@@ -71,6 +71,8 @@ typedef struct {
     int64_t n_paths, n_exercised, n_zero, sum_nitm;
     double ms_paths, ms_lsm, ms_total; /* HIP-event times of this call on the context's stream */
     double ms_pass1, ms_pass2;         /* omc_price_american, two-pass flow: the two big LSM kernels */
+    int64_t timed;         /* omc_price_american_seq: 1 = this pricing carried its own HIP events (the ms_* kernel
+                              times above are its own), 0 = they repeat those of the latest timed pricing before it */
 } omc_result;
 
 /* ---- library / context --------------------------------------------------------------- */
@@ -96,7 +98,10 @@ int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
  * "seq_overlap" (omc_price_american_seq on a context with a communicator, two-pass flow, equal geometry:
  * 1 = the moment all-reduce of pricing k runs on a second stream under the path generation of pricing k+1
  * (second path buffer) and all result sums travel in one collective at the end -- bit-identical results;
- * 0 = one pricing after the other; -1 = default: on when the communicator has more than one rank) */
+ * 0 = one pricing after the other; -1 = default: off -- a job turns it on after it has checked, on its live
+ * communicator, that both forms return the same bits, as bench.py does),
+ * "seq_event_stride" (omc_price_american_seq: k > 0 = every k-th pricing of a sequence carries its own HIP
+ * events, so a sequence yields several samples of the per-kernel times; 0 = default: the first pricing only) */
 int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
 /* measurement aid: with option "step_stamps" = 1 the per-step reference sweep runs a build of its kernel
  * that records eight 100 MHz time stamps per launch and workgroup (entry, partials in, fit solved,
@@ -309,7 +314,8 @@ int omc_localvol_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, 
 /* n independent pricings enqueued back to back on the context's stream (pricing i + 1 is launched while
  * pricing i runs; every pricing's result sums land in their own slot of a host-mapped buffer; one wait
  * at the end).  res[i] equals what omc_price_american(p[i]) returns, bit for bit; ms_paths / ms_pass1 /
- * ms_pass2 are measured on the first pricing, ms_total is the average over the sequence.  Across GPUs the
+ * ms_pass2 are measured on the first pricing (and on every k-th one with option "seq_event_stride" = k;
+ * res[i].timed marks them), ms_total is the average over the sequence.  Across GPUs the
  * moment tables are all-reduced per pricing as usual, but the result sums of all n pricings travel in ONE
  * collective of 8n doubles after the last pricing (the hook is called once with count = 8n); a hook must only
  * ENQUEUE its collective on the stream (as torch.distributed does), then the sequence stays free of host

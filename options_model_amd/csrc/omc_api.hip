@@ -91,6 +91,10 @@ struct omc_ctx {
     int seq_cap = 0;
     hipEvent_t ev_seq = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // omc_price_american_seq: further event sets (7 each) for the pricings of a sequence that carry their own
+    // kernel timings ("seq_event_stride": every k-th pricing; 0 = the first one only)
+    std::vector<hipEvent_t> ev_pool;
+    int seq_event_stride = 0;
     int gbm_vec = 0, heston_vec = 0;
     int world = 1;  // ranks whose sums the hook / communicator adds up (equal shards)
     omc_allreduce_fn hook = nullptr;
@@ -505,6 +509,8 @@ int omc_ctx_destroy(omc_ctx* c)
     }
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->ev_pool)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->hres_pin) (void)hipHostFree(c->hres_pin);
     if (c->seq_pin) (void)hipHostFree(c->seq_pin);
     if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
@@ -570,6 +576,7 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     else if (!strcmp(key, "step_graph")) c->step_graph = value < 0 ? -1 : (value ? 1 : 0);
     else if (!strcmp(key, "step_stamps")) c->step_stamps = value ? 1 : 0;
     else if (!strcmp(key, "seq_overlap")) c->seq_overlap = value < 0 ? -1 : (value ? 1 : 0);
+    else if (!strcmp(key, "seq_event_stride")) c->seq_event_stride = value > 0 ? (int)value : 0;
     else if (!strcmp(key, "step_persistent")) {
         c->step_persistent = value < 0 ? -1 : (value ? 1 : 0);
         if (value > 0) c->persist_failed = 0;  // explicit request: try again
@@ -895,8 +902,9 @@ static int enqueue_paths(omc_ctx* c, const omc_params* p, float* S, int64_t ld)
 // go to `result_dev` (device-visible memory) or, when null, to the workspace's device buffer, which is
 // returned through *result_out.  Events are recorded only when `timed`.
 static int enqueue_pricing(omc_ctx* c, const omc_params* p, float* S_keep, int64_t ld, double* result_dev,
-                           bool timed, double** result_out)
+                           hipEvent_t* evs, double** result_out)
 {
+    const bool timed = evs != nullptr;
     int rc;
     const int64_t M = p->n_paths;
     const int N = p->n_steps;
@@ -912,32 +920,61 @@ static int enqueue_pricing(omc_ctx* c, const omc_params* p, float* S_keep, int64
     if ((rc = prepare_lsm(c, M, N, p->r, p->T, p->semantics == OMC_SEM_TWO_PASS, false, &w))) return rc;
     omc::LsmProblem prob{S, ld, M, N, p->is_put ? 1 : 0, p->K, p->r, p->T};
     if (timed) {
-        w.ev_p1_begin = c->ev[3]; w.ev_p1_end = c->ev[4]; w.ev_p2_begin = c->ev[5]; w.ev_p2_end = c->ev[6];
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        // (pass 1 starts where the generator ends: evs[1] is its begin; an event costs ~3 us of dispatch gap)
+        w.ev_p1_end = evs[4]; w.ev_p2_begin = evs[5]; w.ev_p2_end = evs[6];
+        HIP_TRY(hipEventRecord(evs[0], c->stream));
     }
     if ((rc = enqueue_paths(c, p, S, ld))) return rc;
-    if (timed) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if (timed) HIP_TRY(hipEventRecord(evs[1], c->stream));
     if (result_dev) w.result = result_dev;
     if ((rc = enqueue_lsm(c, prob, w, p->semantics, false))) return rc;
     if (result_out) *result_out = w.result;
     return 0;
 }
 
-static int read_kernel_times(omc_ctx* c, const omc_params* p, omc_result* res)
+static int read_kernel_times(const hipEvent_t* evs, const omc_params* p, omc_result* res, bool has_end = true)
 {
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms, evs[0], evs[1]));
     res->ms_paths = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-    res->ms_lsm = ms;
-    res->ms_total = res->ms_paths + res->ms_lsm;
+    if (has_end) {
+        HIP_TRY(hipEventElapsedTime(&ms, evs[1], evs[2]));
+        res->ms_lsm = ms;
+        res->ms_total = res->ms_paths + res->ms_lsm;
+    }
     if (p->semantics == OMC_SEM_TWO_PASS && p->n_steps >= 2) {
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+        HIP_TRY(hipEventElapsedTime(&ms, evs[1], evs[4]));
         res->ms_pass1 = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[5], c->ev[6]));
+        HIP_TRY(hipEventElapsedTime(&ms, evs[5], evs[6]));
         res->ms_pass2 = ms;
     }
     return 0;
+}
+
+// The event set of the s-th timed pricing of a sequence: the context's own seven events for s == 0, further
+// sets from a pool that grows on demand.
+static int sample_events(omc_ctx* c, int s, hipEvent_t** out)
+{
+    if (s == 0) {
+        *out = c->ev;
+        return 0;
+    }
+    const size_t need = 7 * (size_t)s;
+    while (c->ev_pool.size() < need) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    *out = c->ev_pool.data() + 7 * (size_t)(s - 1);
+    return 0;
+}
+
+// is pricing i of a sequence one that carries kernel timings, and if so which sample is it
+static inline int seq_sample_index(const omc_ctx* c, int i)
+{
+    if (i == 0) return 0;
+    const int k = c->seq_event_stride;
+    return (k > 0 && i % k == 0) ? i / k : -1;
 }
 
 int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* S_keep, int64_t ld)
@@ -954,7 +991,7 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     for (int attempt = 0;; ++attempt) {
         c->persist_used = 0;
         double* result = nullptr;
-        if ((rc = enqueue_pricing(c, p, S_keep, ld, zero_copy ? c->hres_dev : nullptr, true, &result))) return rc;
+        if ((rc = enqueue_pricing(c, p, S_keep, ld, zero_copy ? c->hres_dev : nullptr, c->ev, &result))) return rc;
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         if (!zero_copy)
             HIP_TRY(hipMemcpyAsync(hres, result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -965,7 +1002,7 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     memset(res, 0, sizeof *res);
     fill_result(res, hres, c->distributed() ? p->n_paths * c->world : p->n_paths,
                 c->distributed() ? c->world : 1);  // distributed: sums are global
-    return read_kernel_times(c, p, res);
+    return read_kernel_times(c->ev, p, res);
 }
 
 // ------------------------------------------------------------------ per-step ContNet flow (v1 / v2 regressor)
@@ -1149,9 +1186,11 @@ static bool seq_overlap_enabled(const omc_ctx* c)
         return e ? atoi(e) : -1;
     }();
     if (env >= 0) return env != 0;
-    // default: whenever there is a collective worth hiding (with one rank the extra stream only costs its
-    // event hand-overs: 0.606 against 0.591 ms per pricing at C2)
-    return c->comm && omc::comm_world(c->comm) > 1;
+    // default: off.  The mechanism uses one communicator from two streams; callers switch it on once the job has
+    // checked, with its real communicator, that the overlapped sequence returns the sequential one's bits
+    // (bench.py does so before anything is timed).  With one rank it only costs its event hand-overs
+    // (0.606 against 0.591 ms per pricing at C2).
+    return false;
 }
 
 static bool seq_can_overlap(const omc_ctx* c, const omc_params* p, int n)
@@ -1196,13 +1235,16 @@ static int enqueue_seq_overlapped(omc_ctx* c, const omc_params* p, int n, double
     auto phase_a = [&](int k) -> int {
         const int b = k & 1;
         omc::LsmWorkspace wk = w[b];
-        if (k == 0) {  // the first pricing carries the timing events
-            wk.ev_p1_begin = c->ev[3]; wk.ev_p1_end = c->ev[4];
-            HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        }
         int r2;
+        hipEvent_t* evs = nullptr;  // the first pricing (and every seq_event_stride-th) carries timing events
+        const int smp = seq_sample_index(c, k);
+        if (smp >= 0) {
+            if ((r2 = sample_events(c, smp, &evs))) return r2;
+            wk.ev_p1_end = evs[4];
+            HIP_TRY(hipEventRecord(evs[0], c->stream));
+        }
         if ((r2 = enqueue_paths(c, &p[k], Sb[b], ld))) return r2;
-        if (k == 0) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        if (evs) HIP_TRY(hipEventRecord(evs[1], c->stream));
         HIP_TRY(omc::lsm_pass1_moments(c->stream, problem(k), wk));
         HIP_TRY(hipEventRecord(c->ev_moments[b], c->stream));
         HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_moments[b], 0));
@@ -1219,10 +1261,15 @@ static int enqueue_seq_overlapped(omc_ctx* c, const omc_params* p, int n, double
         const int b = k & 1;
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_reduced[b], 0));
         omc::LsmWorkspace wk = w[b];
-        if (k == 0) { wk.ev_p2_begin = c->ev[5]; wk.ev_p2_end = c->ev[6]; }
+        hipEvent_t* evs = nullptr;
+        const int smp = seq_sample_index(c, k);
+        if (smp >= 0) {
+            if ((rc = sample_events(c, smp, &evs))) return rc;
+            wk.ev_p2_begin = evs[5]; wk.ev_p2_end = evs[6];
+        }
         wk.result = local + 8 * (size_t)k;
         HIP_TRY(omc::lsm_pass2_apply(c->stream, problem(k), wk, false, true));
-        if (k == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        if (evs && smp == 0) HIP_TRY(hipEventRecord(evs[2], c->stream));
     }
     if ((rc = allreduce(c, local, 8 * n))) return rc;  // all result sums in one collective
     HIP_TRY(hipMemcpyAsync(out_pin, local, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -1263,10 +1310,13 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
         double* local = (double*)c->seq_local.p;
         c->defer_result_allreduce = dist;
         for (int i = 0; i < n && !overlapped; ++i) {
+            hipEvent_t* evs = nullptr;
+            const int smp = seq_sample_index(c, i);
+            if (smp >= 0 && (rc = sample_events(c, smp, &evs))) break;
             rc = enqueue_pricing(c, &p[i], nullptr, 0, dist ? local + 8 * (size_t)i : c->seq_dev + 8 * (size_t)i,
-                                 i == 0, nullptr);
+                                 evs, nullptr);
             if (rc) break;
-            if (i == 0 && hipEventRecord(c->ev[2], c->stream) != hipSuccess) { rc = fail(999, "hipEventRecord failed"); break; }
+            if (evs && smp == 0 && hipEventRecord(evs[2], c->stream) != hipSuccess) { rc = fail(999, "hipEventRecord failed"); break; }
         }
         c->defer_result_allreduce = false;
         if (rc) return rc;
@@ -1282,18 +1332,25 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     }
     float ms_all = 0;
     HIP_TRY(hipEventElapsedTime(&ms_all, c->ev[0], ev_end));
-    omc_result first;
-    memset(&first, 0, sizeof first);
-    if ((rc = read_kernel_times(c, &p[0], &first))) return rc;
+    // kernel times: a pricing that carried events reports its own, the others those of the latest one before them
+    omc_result timed;
+    memset(&timed, 0, sizeof timed);
     for (int i = 0; i < n; ++i) {
+        const int smp = seq_sample_index(c, i);
+        if (smp >= 0) {
+            hipEvent_t* evs = nullptr;
+            if ((rc = sample_events(c, smp, &evs))) return rc;
+            if ((rc = read_kernel_times(evs, &p[i], &timed, smp == 0))) return rc;
+        }
         memset(&res[i], 0, sizeof res[i]);
         fill_result(&res[i], c->seq_pin + 8 * (size_t)i, c->distributed() ? p[i].n_paths * c->world : p[i].n_paths,
                     c->distributed() ? c->world : 1);
-        res[i].ms_paths = first.ms_paths;
-        res[i].ms_pass1 = first.ms_pass1;
-        res[i].ms_pass2 = first.ms_pass2;
+        res[i].ms_paths = timed.ms_paths;
+        res[i].ms_pass1 = timed.ms_pass1;
+        res[i].ms_pass2 = timed.ms_pass2;
         res[i].ms_total = ms_all / (float)n;
-        res[i].ms_lsm = res[i].ms_total - first.ms_paths;
+        res[i].ms_lsm = res[i].ms_total - timed.ms_paths;
+        res[i].timed = smp >= 0 ? 1 : 0;
     }
     return 0;
 }

@@ -98,43 +98,96 @@ class _ShardedBase:
         self.ctx.close()
 
 
+class RcclUnavailable(RuntimeError):
+    """The native communicator cannot be used by this JOB.  Raised on every rank or on none: the ranks vote
+    (rendezvous.agree) before and after omc_comm_init, so a caller may fall back to another transport knowing
+    that all its peers do the same."""
+
+
+class Watchdog:
+    """Ends the process (exit code 3, message on stderr) unless cancel()led within `seconds`: the one bound
+    that also covers a rank stuck INSIDE ncclCommInitRank or a collective, which have no timeout of their own
+    and cannot be interrupted from Python.  Used around communicator bring-up and, by bench.py, around a whole
+    multi-rank run."""
+
+    def __init__(self, seconds: float, what: str):
+        import threading
+        self._ev = threading.Event()
+        self._t = threading.Thread(target=self._run, args=(float(seconds), what), daemon=True)
+        self._t.start()
+
+    def _run(self, seconds, what):
+        if not self._ev.wait(seconds):
+            import os
+            import sys
+            print(f"options_model_amd: {what} did not finish within {seconds:.0f} s; exiting", file=sys.stderr, flush=True)
+            os._exit(3)
+
+    def cancel(self):
+        self._ev.set()
+
+
 class RcclPricer(_ShardedBase):
     """One per rank, NO torch: the library owns an RCCL communicator (omc_comm_init) and enqueues its
-    all-reduces itself.  The unique id travels from rank 0 through options_model_amd.rendezvous."""
+    all-reduces itself.  The unique id travels from rank 0 through options_model_amd.rendezvous.
+
+    Bring-up is a collective decision with a deadline: (1) rank 0 draws the id (or publishes that it cannot);
+    (2) every rank votes "I have a context, the library and the id"; unless all do, ALL raise RcclUnavailable;
+    (3) omc_comm_init under a watchdog (`init_timeout_s`; a peer that died inside RCCL's bootstrap would
+    otherwise block the others for ever); (4) every rank votes on the outcome, and again all continue or all
+    raise.  A rank that never votes makes the others raise TimeoutError after `timeout_s`."""
 
     transport = "rccl-native"
 
-    def __init__(self, local_rank: int, rank: int, world: int, tag: str | None = None, timeout_s: float = 120.0):
+    def __init__(self, local_rank: int, rank: int, world: int, tag: str | None = None, timeout_s: float = 120.0,
+                 init_timeout_s: float = 300.0):
         from . import _ffi, rendezvous
 
         self._ffi = _ffi
         self.rank, self.world = int(rank), int(world)
         self.ctx = _ffi.Context(local_rank)
         marker = b"OMC_RCCL_UNAVAILABLE"
-        failure = []
+        why = []
 
         def make_uid():  # rank 0; a failure is published too, so that the other ranks do not wait for it
             try:
                 return _ffi.comm_unique_id()
             except Exception as e:
-                failure.append(e)
+                why.append(f"rank 0 has no unique id: {e}")
                 return marker.ljust(128, b"\0")
 
         uid, path = rendezvous.exchange(self.rank, make_uid, 128, tag, timeout_s)
-        if uid.startswith(marker):
-            if path:
-                time.sleep(0.5)  # let the other ranks read the marker
-                rendezvous.retire(path)
-            self.ctx.close()
-            raise RuntimeError(f"RCCL unique id unavailable on rank 0: {failure[0] if failure else 'see rank 0'}")
+        ok = not uid.startswith(marker)
+        if not ok and not why:
+            why.append("rank 0 has no unique id (see its log)")
         try:
-            self.ctx.comm_init(self.rank, self.world, uid)  # collective
+            all_ok = rendezvous.agree(self.rank, self.world, ok, "uid", tag, timeout_s)
         finally:
             if path:
-                rendezvous.retire(path)
-        r, w = self.ctx.comm_info()
-        if (r, w) != (self.rank, self.world):
-            raise RuntimeError(f"RCCL communicator reports rank {r} of {w}, expected {self.rank} of {self.world}")
+                rendezvous.retire(path)  # every rank has voted, i.e. has read the id
+        if not all_ok:
+            self.ctx.close()
+            raise RcclUnavailable("; ".join(why) or "another rank cannot use the native communicator")
+        dog = Watchdog(init_timeout_s, f"rank {self.rank}: omc_comm_init ({self.world} ranks)")
+        try:
+            self.ctx.comm_init(self.rank, self.world, uid)  # collective
+            r, w = self.ctx.comm_info()
+            ok = (r, w) == (self.rank, self.world)
+            if not ok:
+                why.append(f"communicator reports rank {r} of {w}, expected {self.rank} of {self.world}")
+        except Exception as e:
+            ok = False
+            why.append(f"omc_comm_init failed on rank {self.rank}: {e}")
+        finally:
+            dog.cancel()
+        all_ok = rendezvous.agree(self.rank, self.world, ok, "init", tag, max(timeout_s, init_timeout_s))
+        if not all_ok:
+            try:
+                if ok:
+                    self.ctx.comm_destroy()
+            finally:
+                self.ctx.close()
+            raise RcclUnavailable("; ".join(why) or "omc_comm_init failed on another rank")
 
     def comm_ranks(self) -> int:
         return self.ctx.comm_info()[1]

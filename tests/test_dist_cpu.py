@@ -7,6 +7,7 @@ pricing, to float64 round-off.
 """
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -168,3 +169,116 @@ def test_bench_world_size_must_match_gpus():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
                          capture_output=True, text=True, timeout=120, cwd=root)
     assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr
+
+
+# ------------------------------------------------------------------ round 3: hardened rendezvous + launcher deadline
+def _agree_worker(rank, world, ok, tag, q, d):
+    os.environ["OMC_RDZV_DIR"] = d
+    from options_model_amd import rendezvous
+    try:
+        q.put((rank, rendezvous.agree(rank, world, ok, "phase", tag, timeout_s=20.0)))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("votes,expect", [((True, True, True), True), ((True, False, True), False)])
+def test_ranks_agree_collectively(tmp_path, votes, expect):
+    """Every rank gets the same verdict: True only if ALL voted True (the transport decision of dist.RcclPricer)."""
+    import multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    tag = f"agree{os.getpid()}"
+    ps = [ctxm.Process(target=_agree_worker, args=(r, len(votes), v, tag, q, str(tmp_path))) for r, v in enumerate(votes)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(30)
+    assert got == {r: expect for r in range(len(votes))}
+    assert len([f for f in os.listdir(tmp_path) if tag in f]) <= len(votes)  # at most late votes stay behind
+
+
+def test_agree_names_the_rank_that_never_voted(tmp_path, monkeypatch):
+    from options_model_amd import rendezvous
+    monkeypatch.setenv("OMC_RDZV_DIR", str(tmp_path))
+    with pytest.raises(TimeoutError, match=r"rank\(s\) \[1\]"):
+        rendezvous.agree(0, 2, True, "lonely", tag=f"l{os.getpid()}", timeout_s=0.3)
+
+
+def test_rendezvous_files_are_private_fresh_and_never_followed(tmp_path, monkeypatch):
+    """0600, O_EXCL|O_NOFOLLOW, stale files of an earlier run under the same name are not accepted,
+    and rank 0 replaces whatever sits under its name."""
+    import stat
+    import struct
+
+    from options_model_amd import rendezvous
+    monkeypatch.setenv("OMC_RDZV_DIR", str(tmp_path))
+    tag = "sec"
+    path = rendezvous.publish(b"x" * 128, tag)
+    assert stat.S_IMODE(os.stat(path).st_mode) == 0o600
+    assert rendezvous.fetch(128, tag, timeout_s=1.0) == b"x" * 128
+    # a frame written long before this process started (a killed earlier run) is ignored
+    raw = open(path, "rb").read()
+    old = raw[:8] + struct.pack("<d", 1.0e9) + raw[16:]
+    os.unlink(path)
+    open(path, "wb").write(old)
+    with pytest.raises(TimeoutError):
+        rendezvous.fetch(128, tag, timeout_s=0.2)
+    # a bare 128-byte file (round 2's format) or another tag's frame is not accepted either
+    open(path, "wb").write(b"y" * 128)
+    with pytest.raises(TimeoutError):
+        rendezvous.fetch(128, tag, timeout_s=0.2)
+    other = rendezvous.publish(b"z" * 128, "other")
+    os.replace(other, path)
+    with pytest.raises(TimeoutError):
+        rendezvous.fetch(128, tag, timeout_s=0.2)
+    # a symlink planted under the name: readers do not follow it, rank 0 replaces it without writing through it
+    victim = tmp_path / "victim"
+    victim.write_bytes(b"precious")
+    os.unlink(path)
+    os.symlink(victim, path)
+    with pytest.raises(TimeoutError):
+        rendezvous.fetch(128, tag, timeout_s=0.2)
+    path2 = rendezvous.publish(b"w" * 128, tag)
+    assert path2 == path and not os.path.islink(path) and victim.read_bytes() == b"precious"
+    assert rendezvous.fetch(128, tag, timeout_s=1.0) == b"w" * 128
+
+
+def test_tag_carries_the_launch_nonce(monkeypatch):
+    from options_model_amd import rendezvous
+    monkeypatch.setenv("MASTER_PORT", "12345")
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    monkeypatch.setenv("OMC_RDZV_NONCE", "abc123")
+    assert rendezvous.default_tag() == f"12345_{os.getppid()}_abc123"
+    monkeypatch.delenv("OMC_RDZV_NONCE")
+    assert rendezvous.default_tag() == f"12345_{os.getppid()}"
+
+
+def test_launcher_deadline_ends_ranks_that_never_finish():
+    """bench.launch_ranks: ranks that hang (here: sleep) are terminated at --rank-timeout and the job exits 124."""
+    import importlib.util
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(2, 1.0, argv=[sys.executable, "-c", "import time; time.sleep(120)"])
+    assert rc == 124 and time.monotonic() - t0 < 30
+    # a rank that fails takes the others down at once, with its own exit code
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(2, 60.0, argv=[sys.executable, "-c",
+                                           "import os, sys, time; sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(120)"])
+    assert rc == 7 and time.monotonic() - t0 < 30
+
+
+def test_watchdog_ends_a_stuck_process():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from options_model_amd.dist import Watchdog\n"
+            "w = Watchdog(0.5, 'test section'); time.sleep(30)\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 3 and "test section did not finish within" in out.stderr
+    code = code.replace("time.sleep(30)", "w.cancel(); time.sleep(1.0)")
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60).returncode == 0

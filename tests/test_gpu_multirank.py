@@ -1,0 +1,95 @@
+"""The N > 1 native-communicator path of libomc.so with 2 and 4 ranks -- on ONE GPU.
+
+Real RCCL refuses two ranks on one device, so csrc/omc_comm.hip is pointed (through its OMC_RCCL_LIB hook) at
+tests/rccl_standin: the seven ncclXxx entry points over POSIX shared memory, all-reduces enqueued on the given
+stream like RCCL's.  Everything above that library is the product's own code, run exactly as the driver's 8-GPU
+job runs it: bench.py's launcher, the unique-id rendezvous, the collective transport decision, omc_comm_init, the
+251 per-step all-reduces enqueued from C, the overlapped two-stream sequence and its one result collective.
+(Ranks are limited to 4 here: a GPU box admits at most 6 processes on its card, and pytest is one of them.)
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+M_PER_GPU, N = 100_000, 50
+
+
+@pytest.fixture(scope="module")
+def standin():
+    import rccl_standin
+    return rccl_standin.build()
+
+
+def _bench(args, standin, extra_env=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMC_RCCL_LIB=standin, MASTER_ADDR="127.0.0.1")
+    env.update(extra_env or {})
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                         text=True, timeout=timeout, cwd=ROOT)
+    return out, time.monotonic() - t0
+
+
+def _line(out):
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("sem", ["two_pass", "reference", "textbook"])
+def test_ranks_sharing_one_gpu_equal_the_unsharded_pricing(ctx, standin, world, sem):
+    from options_model_amd import _ffi
+    out, _ = _bench(["--gpus", str(world), "--single-device", "--backend", "rccl", "--steps", "4", "--warmup", "2",
+                     "--paths-per-gpu", str(M_PER_GPU), "--n-steps", str(N), "--semantics", sem, "--group", "4",
+                     "--min-warmup-seconds", "0.05", "--no-variants", "--no-cpu-baseline", "--no-sustained"], standin)
+    d = _line(out)
+    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["comm"].startswith("rccl-native")
+    # the sharded job == ONE pricing of world x paths: same Philox pairs (global pair index), sums in another order
+    ref = ctx.price_american(_ffi.make_params(semantics=sem, n_paths=world * M_PER_GPU, n_steps=N, seed=42, stream=3))
+    assert d["price"] == pytest.approx(ref["price"], rel=1e-12)
+    lp = d["last_pricing"]
+    assert (lp["n_paths"], lp["n_exercised"], lp["n_zero"], lp["sum_nitm"]) == (
+        ref["n_paths"], ref["n_exercised"], ref["n_zero"], ref["sum_nitm"])
+    if sem == "two_pass":
+        # before timing, every rank priced three streams overlapped (moment all-reduce on a second stream under the
+        # next pricing's paths + pass 1) and one after the other, and all ranks saw the same bits
+        assert d["seq_overlap"] == "on"
+        ps = d["roofline_per_step"]  # ... and the per-step reference flow went through 49 all-reduces per pricing
+        ref2 = ctx.price_american(_ffi.make_params(semantics="reference", n_paths=world * M_PER_GPU, n_steps=N,
+                                                   seed=42, stream=ps["price_stream"]))
+        assert ps["price"] == pytest.approx(ref2["price"], rel=1e-12)
+        assert ps["last_pricing"]["sum_nitm"] == ref2["sum_nitm"]
+        assert ps["last_pricing"]["n_exercised"] == ref2["n_exercised"]
+
+
+def test_a_rank_whose_init_fails_ends_the_job_within_the_deadline(standin):
+    """Rank 1's ncclCommInitRank fails at once; rank 0 sits inside its own (a dead peer, as real RCCL would see it:
+    the stand-in's own bound is set far away).  The launcher's deadline must end the job, non-zero, naming the rank."""
+    out, took = _bench(["--gpus", "2", "--single-device", "--backend", "rccl", "--steps", "2", "--warmup", "1",
+                        "--paths-per-gpu", "20000", "--n-steps", "20", "--rank-timeout", "25", "--no-variants",
+                        "--no-cpu-baseline", "--no-sustained"], standin,
+                       {"OMC_STANDIN_FAIL_RANK": "1", "OMC_STANDIN_TIMEOUT_S": "600"})
+    assert out.returncode != 0 and took < 90
+    assert out.stdout.strip() == ""
+    assert "did not finish within --rank-timeout" in out.stderr or "exited with" in out.stderr
+
+
+def test_failed_init_is_a_collective_fallback(standin):
+    """Rank 1's init fails, rank 0's gives up after 3 s: both vote, both learn that the native communicator is not
+    usable for this JOB, and both switch to the torch.distributed transport together (gloo here: one device)."""
+    out, _ = _bench(["--gpus", "2", "--single-device", "--backend", "rccl", "--steps", "2", "--warmup", "1",
+                     "--paths-per-gpu", "20000", "--n-steps", "20", "--no-variants", "--no-cpu-baseline",
+                     "--no-sustained", "--min-warmup-seconds", "0.05"], standin,
+                    {"OMC_STANDIN_FAIL_RANK": "1", "OMC_STANDIN_TIMEOUT_S": "3"})
+    d = _line(out)
+    assert d["rccl_ranks"] == 2 and d["comm"].startswith("torch.distributed gloo")
+    assert out.stderr.count("native RCCL unavailable for this job") == 2
