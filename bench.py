@@ -510,21 +510,47 @@ def main():
     if a.only_timed:
         line["roofline_per_step"] = kernels[1] if a.semantics == "reference" else None
     elif a.semantics != "reference":
-        price_group([900, 901], "reference")  # warm (graph capture, workspaces)
-        barrier(); ctx.sync()
-        t1 = time.perf_counter()
-        reps = max(5, a.steps // 2)
-        pr, outs = price_group(list(range(reps)), "reference")
-        barrier(); ctx.sync()
-        dt = time.perf_counter() - t1
-        if dist_mode:
-            dt = pricer.allreduce_max(dt)
-        ms_sweep = sum(o["ms_total"] for o in outs) / len(outs) - outs[0]["ms_paths"]
-        r = rf("lsm_step_kernel", step_bytes_per_path("reference") * M, ms_sweep / N, launches=N)
-        r.update(flow="reference (per-step sticky flow: Options_model.py:108-157)", price=pr, price_stream=reps - 1,
-                 last_pricing={k: outs[-1][k] for k in ("n_paths", "n_exercised", "n_zero", "sum_nitm")},
-                 ms_per_pricing=1e3 * dt / reps, path_steps_per_s=world * M * N * reps / dt,
-                 note="ms_per_launch = HIP-event time of the whole N-launch sweep / N (kernel boundaries included)")
+        # (a) ONE pricing per launch: the latency of a single pricing's time step; (b) K pricings of the sequence
+        # per launch (omc_price_american_seq, option "seq_step_k"): the throughput of the same kernel when the
+        # chip is filled.  Same kernel body, same bits per pricing (tests/test_gpu_step_multi.py).
+        def per_step(k, reps):
+            ctx.set_option("seq_step_k", k)
+            plist = [params("reference", i) for i in range(max(k, 2))]
+            k_eff = ctx.seq_step_width(plist)
+            price_group(list(range(900, 900 + max(k, 2))), "reference")  # warm (workspaces)
+            barrier(); ctx.sync()
+            t1 = time.perf_counter()
+            pr, outs = price_group(list(range(reps)), "reference")
+            barrier(); ctx.sync()
+            dt = time.perf_counter() - t1
+            if dist_mode:
+                dt = pricer.allreduce_max(dt)
+            ms_sweep = sum(o["ms_total"] for o in outs) / len(outs) - outs[0]["ms_paths"]  # per pricing
+            r = rf("lsm_step_kernel" if k_eff == 1 else "lsm_step_multi_kernel",
+                   step_bytes_per_path("reference") * M * k_eff, ms_sweep * k_eff / N, launches=N)
+            r.update(pricings_per_launch=k_eff, price=pr, price_stream=reps - 1,
+                     last_pricing={q: outs[-1][q] for q in ("n_paths", "n_exercised", "n_zero", "sum_nitm")},
+                     ms_per_pricing=1e3 * dt / reps, path_steps_per_s=world * M * N * reps / dt,
+                     us_per_time_step_per_pricing=1e3 * ms_sweep / N)
+            return r
+        reps1 = max(5, a.steps // 2)
+        one = per_step(1, reps1)
+        by_k = {1: one}
+        for k in (4, 8, 16):
+            r = per_step(k, 2 * k)
+            if r["pricings_per_launch"] not in by_k:
+                by_k[r["pricings_per_launch"]] = r
+        ctx.set_option("seq_step_k", -1)
+        best = max(by_k.values(), key=lambda r: r["frac"])
+        r = dict(best)
+        r.update(flow="reference (per-step sticky flow: Options_model.py:108-157)",
+                 note="ms_per_launch = HIP-event time of the whole N-launch sweep / N (kernel boundaries included); a launch "
+                      "advances `pricings_per_launch` independent pricings of the sequence by one time step",
+                 single_pricing={"us_per_time_step": one["us_per_time_step_per_pricing"], "frac": one["frac"],
+                                 "ms_per_pricing": one["ms_per_pricing"], "path_steps_per_s": one["path_steps_per_s"]},
+                 by_pricings_per_launch={str(k): {"frac": v["frac"], "achieved": v["achieved"], "ms_per_launch": v["ms_per_launch"],
+                                                  "ms_per_pricing": v["ms_per_pricing"], "path_steps_per_s": v["path_steps_per_s"]}
+                                         for k, v in sorted(by_k.items())})
         line["roofline_per_step"] = r
     else:
         line["roofline_per_step"] = kernels[1]

@@ -85,6 +85,7 @@ SIGNATURES = {
     "omc_price_european": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result)]),
     "omc_heston_price_strikes": (C.c_int, [_P, _I64, _I] + [_D] * 8 + [_U64, _U64, _I, _P, _I, _I, _P, _P]),
     "omc_price_american_seq": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
+    "omc_seq_step_width": (C.c_int, [_P, C.POINTER(Params), _I]),
     "omc_price_american_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_price_european_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_mlp_param_count": (C.c_int, [_I, _I]),
@@ -541,6 +542,12 @@ class Context:
         res = (Result * n)()
         _check(self.lib, self.lib.omc_price_american_seq(self.handle, arr, n, res))
         return [r.as_dict() for r in res]
+
+    def seq_step_width(self, params_list) -> int:
+        """How many pricings of this sequence share one launch per time step (per-step flows; 1 = none)."""
+        plist = list(params_list)
+        arr = (Params * len(plist))(*plist)
+        return int(self.lib.omc_seq_step_width(self.handle, arr, len(plist)))
 
     def price_american_batch(self, params_list):
         return self._batch(self.lib.omc_price_american_batch, list(params_list))

@@ -95,6 +95,12 @@ struct omc_ctx {
     // kernel timings ("seq_event_stride": every k-th pricing; 0 = the first one only)
     std::vector<hipEvent_t> ev_pool;
     int seq_event_stride = 0;
+    // omc_price_american_seq, per-step flows: K pricings advanced by one launch per time step
+    DevBuf mS, mstate, mtable;
+    char* mtab_pin = nullptr;  // pinned upload ring for the argument tables (one image per batch of K)
+    int mtab_slot = 0;
+    int seq_step_k = -1;       // -1: default (what fits the Infinity Cache, <= 16), 1: off, k: at most k pricings per launch
+    int seq_step_wgs = 0;      // workgroups one launch of the multi-pricing sweep may use (0: one per CU)
     int gbm_vec = 0, heston_vec = 0;
     int world = 1;  // ranks whose sums the hook / communicator adds up (equal shards)
     omc_allreduce_fn hook = nullptr;
@@ -499,9 +505,11 @@ int omc_ctx_destroy(omc_ctx* c)
     c->comm = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->persist_scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc,
-                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont})
+                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
+                      &c->mS, &c->mstate, &c->mtable})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
+    if (c->mtab_pin) (void)hipHostFree(c->mtab_pin);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     for (int b = 0; b < 2; ++b) {
         if (c->ev_moments[b]) (void)hipEventDestroy(c->ev_moments[b]);
@@ -577,6 +585,8 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     else if (!strcmp(key, "step_stamps")) c->step_stamps = value ? 1 : 0;
     else if (!strcmp(key, "seq_overlap")) c->seq_overlap = value < 0 ? -1 : (value ? 1 : 0);
     else if (!strcmp(key, "seq_event_stride")) c->seq_event_stride = value > 0 ? (int)value : 0;
+    else if (!strcmp(key, "seq_step_k")) c->seq_step_k = value < 0 ? -1 : (int)(value > 32 ? 32 : value);
+    else if (!strcmp(key, "seq_step_wgs")) c->seq_step_wgs = value > 0 ? (int)value : 0;
     else if (!strcmp(key, "step_persistent")) {
         c->step_persistent = value < 0 ? -1 : (value ? 1 : 0);
         if (value > 0) c->persist_failed = 0;  // explicit request: try again
@@ -1276,6 +1286,120 @@ static int enqueue_seq_overlapped(omc_ctx* c, const omc_params* p, int n, double
     return 0;
 }
 
+// ---- per-step flows: K pricings of one geometry per launch --------------------------------------------------
+// One launch of the per-step kernel moves 13 MB at C2 and costs ~6 us, of which ~3.6 us are the launch boundary
+// and the cold start of a new kernel: a single pricing is at its latency floor, the chip
+// is not.  A sequence of pricings that share (n_paths, n_steps, r, T, semantics) therefore advances K of them
+// with every launch: K path matrices, K sets of state / partials / fits, ONE launch boundary per time step; across
+// GPUs the K moment vectors of a step travel in ONE all-reduce of 8K doubles.  Per pricing the arithmetic and
+// the order of every sum are those of its own launches (lsm_step_body), so res[i] keeps the bits of
+// omc_price_american(p[i]).
+static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
+{
+    if (n < 2) return 1;
+    static const int env_k = getenv("OMC_SEQ_STEP_K") ? atoi(getenv("OMC_SEQ_STEP_K")) : -1;
+    int k = c->seq_step_k >= 0 ? c->seq_step_k : env_k;
+    if (k < 0) {
+        // default: as many pricings as keep one launch's rows and state inside the 256 MB Infinity Cache (a launch
+        // re-reads S_t, S_N and the flags its predecessor touched: measured at 1M paths, 16 pricings per launch
+        // 0.66 of the HBM roofline, 32 -- 416 MB per launch -- 0.53), at most 16; problems so large that fewer
+        // than 4 fit are bandwidth-bound one at a time already (8M paths: 0.62 alone, 0.61 with 4 per launch)
+        const double per = (p[0].semantics == OMC_SEM_REFERENCE ? 13.0 : 16.0) * (double)p[0].n_paths;
+        k = (int)(2.2e8 / per);
+        if (k > 16) k = 16;
+        if (k < 4) k = 1;
+    }
+    if (k < 2) return 1;
+    if (p[0].semantics == OMC_SEM_TWO_PASS || p[0].n_steps < 1) return 1;
+    if (c->step_stamps || step_persistent_enabled(c) || step_graph_enabled(c)) return 1;
+    for (int i = 1; i < n; ++i)
+        if (p[i].semantics != p[0].semantics || p[i].n_paths != p[0].n_paths || p[i].n_steps != p[0].n_steps ||
+            p[i].r != p[0].r || p[i].T != p[0].T)
+            return 1;
+    // K path matrices stay resident: bounded by a byte budget (default 64 GB of the 288)
+    static const double budget = getenv("OMC_SEQ_STEP_BYTES") ? atof(getenv("OMC_SEQ_STEP_BYTES")) : 64e9;
+    const int64_t ld = (p[0].n_paths + 63) / 64 * 64;
+    const double sbytes = 4.0 * (double)ld * (double)(p[0].n_steps + 1);
+    const int fit = (int)(budget / sbytes);
+    if (k > fit) k = fit;
+    if (k > n) k = n;
+    if (k > 32) k = 32;
+    return k < 2 ? 1 : k;
+}
+
+static int enqueue_seq_step_multi(omc_ctx* c, const omc_params* p, int n, int K, double* dst)
+{
+    int rc;
+    const int64_t M = p[0].n_paths;
+    const int N = p[0].n_steps;
+    const int sem = p[0].semantics;
+    const int64_t ld = (M + 63) / 64 * 64;
+    const size_t sbytes = sizeof(float) * (size_t)ld * (size_t)(N + 1);
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_sx = 0, o_tex = o_sx + up(sizeof(float) * (size_t)M), o_ex = o_tex + up(sizeof(int32_t) * (size_t)M),
+                 o_part = o_ex + up((size_t)M + 16), o_betas = o_part + up(sizeof(double) * 2 * 8 * omc::kMaxLsmBlocks),
+                 per = o_betas + up(sizeof(double) * 4 * (size_t)(N + 1));
+    const size_t gbytes = up(sizeof(double) * 8 * (size_t)K * (size_t)(N + 1));
+    if ((rc = c->mS.ensure(sbytes * (size_t)K))) return rc;
+    if ((rc = c->mstate.ensure(gbytes + per * (size_t)K))) return rc;
+    const size_t eb = omc::lsm_sweep_args_bytes();
+    const size_t tbytes = eb * (size_t)K;
+    if ((rc = c->mtable.ensure(tbytes))) return rc;
+    constexpr int kSlots = 32;
+    constexpr size_t kSlotBytes = 32 * 1024;
+    if (tbytes > kSlotBytes) return fail(-4, "argument table of the multi-pricing sweep exceeds its upload slot.");
+    if (!c->mtab_pin) HIP_TRY(hipHostMalloc((void**)&c->mtab_pin, kSlotBytes * kSlots, hipHostMallocDefault));
+    omc::LsmWorkspace w0;
+    if ((rc = prepare_lsm(c, M, N, p[0].r, p[0].T, false, false, &w0))) return rc;  // discount table (+ unused singles)
+    const bool ext = c->distributed();
+    const bool vec4 = (M % 4) == 0;  // ld is a multiple of 64 and every matrix starts 256-byte aligned
+    char* state = (char*)c->mstate.p;
+    double* gmomK = (double*)state;
+    for (int i0 = 0; i0 < n; i0 += K) {
+        const int Kb = n - i0 < K ? n - i0 : K;
+        const int G = omc::lsm_multi_groups(M, Kb, c->seq_step_wgs > 0 ? c->seq_step_wgs : c->device_cus);
+        if (c->mtab_slot == kSlots) {  // the ring wraps: earlier uploads must have been consumed
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->mtab_slot = 0;
+        }
+        char* img = c->mtab_pin + kSlotBytes * (size_t)c->mtab_slot++;
+        for (int k = 0; k < Kb; ++k) {
+            const omc_params& q = p[i0 + k];
+            char* st = state + gbytes + per * (size_t)k;
+            omc::LsmWorkspace w = w0;
+            w.sx = (float*)(st + o_sx); w.tex = (int32_t*)(st + o_tex); w.ex = (uint8_t*)(st + o_ex);
+            w.part = (double*)(st + o_part); w.betas = (double*)(st + o_betas);
+            w.gmom = gmomK + 8 * (size_t)k; w.gstride = 8 * Kb;
+            w.result = dst + 8 * (size_t)(i0 + k);
+            omc::LsmProblem prob{(const float*)((char*)c->mS.p + sbytes * (size_t)k), ld, M, N, q.is_put ? 1 : 0, q.K, q.r, q.T};
+            omc::lsm_sweep_args_image(prob, w, sem, false, img + eb * (size_t)k, ext);
+        }
+        HIP_TRY(hipMemcpyAsync(c->mtable.p, img, eb * (size_t)Kb, hipMemcpyHostToDevice, c->stream));
+        if (i0 == 0) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        for (int k = 0; k < Kb; ++k)
+            if ((rc = enqueue_paths(c, &p[i0 + k], (float*)((char*)c->mS.p + sbytes * (size_t)k), ld))) return rc;
+        if (i0 == 0) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        for (int t = N; t >= 1; --t) {
+            HIP_TRY(omc::lsm_step_multi(c->stream, c->mtable.p, Kb, G, sem, vec4, N, t));
+            if (ext && t >= 2) {
+                HIP_TRY(omc::lsm_reduce_step_moments_multi(c->stream, c->mtable.p, Kb, t - 1));
+                if ((rc = allreduce(c, gmomK + (size_t)(t - 1) * 8 * (size_t)Kb, 8 * Kb))) return rc;  // K fits' moments, one collective
+            }
+        }
+        HIP_TRY(omc::lsm_final_multi(c->stream, c->mtable.p, Kb, M));
+        if (i0 == 0) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    }
+    return 0;
+}
+
+int omc_seq_step_width(omc_ctx* c, const omc_params* p, int n)
+{
+    if (!c || !p || n <= 0) return 0;
+    for (int i = 0; i < n; ++i)
+        if (check_params(&p[i])) return 0;
+    return seq_multi_width(c, p, n);
+}
+
 int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* res)
 {
     int rc;
@@ -1300,6 +1424,7 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     if (!c->ev_seq) HIP_TRY(hipEventCreate(&c->ev_seq));
     ev_end = c->ev_seq;
     const bool overlapped = seq_can_overlap(c, p, n);
+    const int multi = overlapped ? 1 : seq_multi_width(c, p, n);
     for (int attempt = 0;; ++attempt) {
         c->persist_used = 0;
         if (overlapped && (rc = enqueue_seq_overlapped(c, p, n, c->seq_pin))) return rc;
@@ -1309,7 +1434,11 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
         if (dist && (rc = c->seq_local.ensure(sizeof(double) * 8 * (size_t)n))) return rc;
         double* local = (double*)c->seq_local.p;
         c->defer_result_allreduce = dist;
-        for (int i = 0; i < n && !overlapped; ++i) {
+        if (multi > 1 && (rc = enqueue_seq_step_multi(c, p, n, multi, dist ? local : c->seq_dev))) {
+            c->defer_result_allreduce = false;
+            return rc;
+        }
+        for (int i = 0; i < n && !overlapped && multi <= 1; ++i) {
             hipEvent_t* evs = nullptr;
             const int smp = seq_sample_index(c, i);
             if (smp >= 0 && (rc = sample_events(c, smp, &evs))) break;
@@ -1337,10 +1466,11 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     memset(&timed, 0, sizeof timed);
     for (int i = 0; i < n; ++i) {
         const int smp = seq_sample_index(c, i);
-        if (smp >= 0) {
+        if (smp >= 0 && (multi <= 1 || i == 0)) {
             hipEvent_t* evs = nullptr;
             if ((rc = sample_events(c, smp, &evs))) return rc;
             if ((rc = read_kernel_times(evs, &p[i], &timed, smp == 0))) return rc;
+            if (multi > 1) timed.ms_paths /= (double)multi;  // ev[0]..ev[1] spans the first batch's K generators
         }
         memset(&res[i], 0, sizeof res[i]);
         fill_result(&res[i], c->seq_pin + 8 * (size_t)i, c->distributed() ? p[i].n_paths * c->world : p[i].n_paths,
@@ -1350,7 +1480,7 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
         res[i].ms_pass2 = timed.ms_pass2;
         res[i].ms_total = ms_all / (float)n;
         res[i].ms_lsm = res[i].ms_total - timed.ms_paths;
-        res[i].timed = smp >= 0 ? 1 : 0;
+        res[i].timed = (smp >= 0 && (multi <= 1 || i == 0)) ? 1 : 0;
     }
     return 0;
 }

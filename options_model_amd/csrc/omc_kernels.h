@@ -57,7 +57,8 @@ struct LsmWorkspace {
     uint8_t* ex;      // [M]   per-step reference flow: sticky "has exercised" flag (sx / tex valid where set)
     double* D;        // [N+1] discount table exp(-r dt k)
     double* part;     // [2][8][kMaxLsmBlocks] per-block partial moments, ping-pong by step parity
-    double* gmom;     // [N+1][8] reduced moments per step
+    double* gmom;     // [N+1][8] reduced moments per step (row stride `gstride` doubles)
+    int gstride = 8;  // K pricings advanced together keep their moments in ONE table [N+1][K][8]: stride 8K
     double* betas;    // [N+1][4] b0,b1,b2,n
     double* part1;    // two-pass: [N+1][8][ntiles] partial moments of pass 1
     int64_t part1_tiles;
@@ -88,7 +89,14 @@ int lsm_step_block_threads();     // its workgroup size (1024; OMC_STEP_BLOCK=51
 // lsm_sweep_args_image): capturable into a HIP graph whose replays serve every pricing of the same
 // geometry (M, N, semantics, ld, alignment of S).
 size_t lsm_sweep_args_bytes();
-void lsm_sweep_args_image(const LsmProblem& p, const LsmWorkspace& w, int semantics, bool fill_state, void* out);
+void lsm_sweep_args_image(const LsmProblem& p, const LsmWorkspace& w, int semantics, bool fill_state, void* out,
+                          bool external_moments = false);
+// K pricings of one geometry per launch (per-step flows): `table_dev` = K images of lsm_sweep_args_image,
+// G = lsm_multi_groups(..) workgroups per pricing.  Per pricing the results are those of its own launches.
+int lsm_multi_groups(int64_t M, int K, int device_cus);
+hipError_t lsm_step_multi(hipStream_t st, const void* table_dev, int K, int G, int semantics, bool vec4, int N, int t);
+hipError_t lsm_reduce_step_moments_multi(hipStream_t st, const void* table_dev, int K, int t);
+hipError_t lsm_final_multi(hipStream_t st, const void* table_dev, int K, int64_t M);
 hipError_t lsm_sweep_indirect(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
                               const void* args_dev);
 

@@ -24,10 +24,16 @@ namespace omc {
 
 // ------------------------------------------------------------------ __global__ entry points
 template <int SEM, int VEC, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void lsm_step_kernel(StepArgs a) { lsm_step_body<SEM, VEC, BLOCK>(a); }
+__global__ __launch_bounds__(BLOCK) void lsm_step_kernel(StepArgs a)
+{
+    lsm_step_body<SEM, VEC, BLOCK>(a, blockIdx.x, a.nblk);
+}
 
 // measurement build (omc_set_option "step_stamps"): same kernel with in-kernel time stamps
-__global__ __launch_bounds__(1024) void lsm_step_stamp_kernel(StepArgs a) { lsm_step_body<0, 4, 1024, true>(a); }
+__global__ __launch_bounds__(1024) void lsm_step_stamp_kernel(StepArgs a)
+{
+    lsm_step_body<0, 4, 1024, true>(a, blockIdx.x, a.nblk);
+}
 
 // the same with the argument block in device memory: the N launches of one sweep differ only in `t`,
 // so a captured HIP graph of them can be replayed for any pricing of the same geometry after
@@ -37,13 +43,13 @@ __global__ __launch_bounds__(BLOCK) void lsm_step_ind_kernel(const StepArgs* __r
 {
     StepArgs a = *ap;
     a.t = t;
-    lsm_step_body<SEM, VEC, BLOCK>(a);
+    lsm_step_body<SEM, VEC, BLOCK>(a, blockIdx.x, a.nblk);
 }
 
 __global__ __launch_bounds__(kBlock) void lsm_reduce_step_kernel(const double* part, double* gmom, int t,
-                                                                 int nblk, int pstride)
+                                                                 int nblk, int pstride, int gstride)
 {
-    lsm_reduce_step_body(part, gmom, t, nblk, pstride);
+    lsm_reduce_step_body(part, gmom, t, nblk, pstride, gstride);
 }
 
 template <int VEC, int TPW, int PUT>
@@ -81,7 +87,7 @@ struct FinalizeArgs {
     const double* part;
     const double* gmom;
     double* result;
-    int nblk, N, pstride;
+    int nblk, N, pstride, gstride;
 };
 // device-resident argument block of a captured per-step sweep
 struct SweepArgs {
@@ -93,7 +99,38 @@ struct SweepArgs {
 __global__ __launch_bounds__(kBlock) void lsm_finalize_ind_kernel(const FinalizeArgs* __restrict__ ap)
 {
     const FinalizeArgs a = *ap;
-    lsm_finalize_body(a.part, a.gmom, a.result, a.nblk, a.N, a.pstride);
+    lsm_finalize_body(a.part, a.gmom, a.result, a.nblk, a.N, a.pstride, a.gstride);
+}
+
+// ---- K pricings of one geometry advanced by ONE launch per time step (omc_price_american_seq, per-step flows).
+// `tab[k]` holds pricing k's arguments; the chip's workgroups are dealt G per pricing (pricing = blockIdx.x / G),
+// so all K pricings are resident together and workgroup w of a pricing walks the slots w, w + G, ... of the
+// single-pricing geometry (lsm_step_body): per pricing the bits of its own launch, per launch K x the bytes.
+template <int SEM, int VEC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void lsm_step_multi_kernel(const SweepArgs* __restrict__ tab, int G, int t)
+{
+    const int k = (int)blockIdx.x / G;
+    StepArgs a = tab[k].step;
+    a.t = t;
+    lsm_step_body<SEM, VEC, BLOCK>(a, (int)blockIdx.x - k * G, G);
+}
+
+__global__ __launch_bounds__(kBlock) void lsm_reduce_step_multi_kernel(const SweepArgs* __restrict__ tab, int t)
+{
+    const StepArgs& a = tab[blockIdx.x].step;
+    lsm_reduce_step_body(a.part, a.gmom, t, a.nblk, a.pstride, a.gstride);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void lsm_final_multi_kernel(const SweepArgs* __restrict__ tab)
+{
+    lsm_final_body<VEC>(tab[blockIdx.z].fin);
+}
+
+__global__ __launch_bounds__(kBlock) void lsm_finalize_multi_kernel(const SweepArgs* __restrict__ tab)
+{
+    const FinalizeArgs a = tab[blockIdx.x].fz;
+    lsm_finalize_body(a.part, a.gmom, a.result, a.nblk, a.N, a.pstride, a.gstride);
 }
 
 // ------------------------------------------------------------------ host launchers
@@ -142,6 +179,7 @@ static void fill_step_args(StepArgs& a, const LsmProblem& p, const LsmWorkspace&
     a.sx = w.sx; a.tex = w.tex; a.ex = w.ex; a.D = w.D; a.part = w.part; a.gmom = w.gmom; a.betas = w.betas;
     a.t = t; a.nblk = lsm_sweep_blocks(p.M); a.external = external_moments ? 1 : 0;
     a.pstride = kPStride;
+    a.gstride = w.gstride;
     a.cont = w.cont; a.ldc = w.ldc;
     a.dbg = w.dbg;
 }
@@ -199,15 +237,66 @@ static void fill_final_args(FinalArgs& a, const LsmProblem& p, const LsmWorkspac
 }
 
 // host image of the device argument block the indirect kernels read
-void lsm_sweep_args_image(const LsmProblem& p, const LsmWorkspace& w, int semantics, bool fill_state, void* out)
+void lsm_sweep_args_image(const LsmProblem& p, const LsmWorkspace& w, int semantics, bool fill_state, void* out,
+                          bool external_moments)
 {
     SweepArgs s;
     memset(&s, 0, sizeof s);
-    fill_step_args(s.step, p, w, 0, false);
+    fill_step_args(s.step, p, w, 0, external_moments);
     fill_final_args(s.fin, p, w, semantics == 1 ? 0 : 1, semantics == 0, fill_state);
     s.fz.part = w.part; s.fz.gmom = w.gmom; s.fz.result = w.result;
-    s.fz.nblk = s.fin.nblk; s.fz.N = p.N; s.fz.pstride = kPStride;
+    s.fz.nblk = s.fin.nblk; s.fz.N = p.N; s.fz.pstride = kPStride; s.fz.gstride = w.gstride;
     memcpy(out, &s, sizeof s);
+}
+
+// workgroups per pricing when K pricings share the launches of a per-step sweep: the chip's workgroups (one
+// 1024-thread workgroup per CU) divided by K, at least what keeps a workgroup within kStepMaxItems slots
+int lsm_multi_groups(int64_t M, int K, int device_cus)
+{
+    const int nblk = lsm_sweep_blocks(M);
+    const int wgs = device_cus > 0 ? device_cus : 256;
+    int G = wgs / (K > 0 ? K : 1);
+    const int gmin = (nblk + kStepMaxItems - 1) / kStepMaxItems;
+    if (G < gmin) G = gmin;
+    if (G < 1) G = 1;
+    return G > nblk ? nblk : G;
+}
+
+hipError_t lsm_step_multi(hipStream_t st, const void* table_dev, int K, int G, int semantics, bool vec4, int N, int t)
+{
+    const SweepArgs* tab = (const SweepArgs*)table_dev;
+    const dim3 grid((unsigned)(K * G));
+    const size_t dyn = semantics == 1 ? sizeof(double) * (size_t)(N + 1) : 0;
+    const bool big = lsm_step_block_threads() == 1024;
+#define OMC_STEPM(SEM, VEC)                                                                                    \
+    do {                                                                                                       \
+        if (big) hipLaunchKernelGGL((lsm_step_multi_kernel<SEM, VEC, 1024>), grid, dim3(1024), dyn, st, tab, G, t); \
+        else hipLaunchKernelGGL((lsm_step_multi_kernel<SEM, VEC, 512>), grid, dim3(512), dyn, st, tab, G, t);  \
+    } while (0)
+    if (semantics == 0) {
+        if (vec4) OMC_STEPM(0, 4); else OMC_STEPM(0, 1);
+    } else {
+        if (vec4) OMC_STEPM(1, 4); else OMC_STEPM(1, 1);
+    }
+#undef OMC_STEPM
+    return hipGetLastError();
+}
+
+hipError_t lsm_reduce_step_moments_multi(hipStream_t st, const void* table_dev, int K, int t)
+{
+    hipLaunchKernelGGL(lsm_reduce_step_multi_kernel, dim3(K), dim3(kBlock), 0, st, (const SweepArgs*)table_dev, t);
+    return hipGetLastError();
+}
+
+// valuation + finalize of all K pricings: two launches
+hipError_t lsm_final_multi(hipStream_t st, const void* table_dev, int K, int64_t M)
+{
+    const SweepArgs* tab = (const SweepArgs*)table_dev;
+    const int nblk = lsm_step_blocks(M);
+    if ((M % 4) == 0) hipLaunchKernelGGL((lsm_final_multi_kernel<4>), dim3(nblk, 1, K), dim3(kBlock), 0, st, tab);
+    else hipLaunchKernelGGL((lsm_final_multi_kernel<1>), dim3(nblk, 1, K), dim3(kBlock), 0, st, tab);
+    hipLaunchKernelGGL(lsm_finalize_multi_kernel, dim3(K), dim3(kBlock), 0, st, tab);
+    return hipGetLastError();
 }
 
 // the whole per-step sweep (N step launches + valuation + finalize) with device-resident arguments:
@@ -231,7 +320,7 @@ hipError_t lsm_sweep_indirect(hipStream_t st, const LsmProblem& p, const LsmWork
 hipError_t lsm_reduce_step_moments(hipStream_t st, const LsmWorkspace& w, int t, int nblk)
 {
     hipLaunchKernelGGL(lsm_reduce_step_kernel, dim3(1), dim3(kBlock), 0, st, w.part, w.gmom, t, nblk,
-                       kPStride);
+                       kPStride, w.gstride);
     return hipGetLastError();
 }
 

@@ -73,6 +73,7 @@ struct StepArgs {
     double* betas;
     int t, nblk, external;
     int pstride;  // slots per quantity row in `part`
+    int gstride;  // doubles between consecutive steps' rows of `gmom` (8; K * 8 when K pricings share one table)
     // "values" mode (omc_lsm_apply_values): the continuation value of path j at step t is cont[t][j]
     // (float32, as the reference's networks return it) instead of the fitted polynomial
     const float* cont;
@@ -96,14 +97,23 @@ struct StepArgs {
 // SEM 1: textbook LSM: the cash-flow of every in-the-money path is payoff(sx) D[tex - t]: state
 //        (sx, tex) is read every step (16 bytes per path and step).
 //
-// Geometry: BLOCK-thread workgroups, at most kStepMaxBlocks of them; workgroup count = number of
-// partials every workgroup's wave 0 re-reads in its prologue (kStepMaxBlocks / 64 per lane and
-// quantity, all issued before anything waits).
+// Geometry.  The paths of a pricing are cut into a.nblk SLOTS (at most kStepMaxBlocks): slot b owns the
+// column chunks (b*BLOCK + tid)*VEC + i * nblk*BLOCK*VEC, and its partial moments -- thread sums over its
+// chunks in column order, wave transpose-reduce, waves added in wave order -- go to part[..][b].  That
+// summation tree depends on (M, BLOCK, VEC) only, NOT on how many workgroups run it:
+//   * one pricing per launch: G = nblk workgroups, one slot each (w = blockIdx.x);
+//   * K pricings per launch (lsm_step_multi_kernel): each pricing gets G = workgroups / K of the chip's
+//     workgroups and workgroup w of a pricing walks slots w, w + G, w + 2G, ...  -- so the K pricings are
+//     co-resident and share ONE launch boundary and ONE cold start per time step, and each of them returns the
+//     bits of its own single launch.
+// Workgroup count per pricing = number of partials every workgroup's wave 0 re-reads in its prologue
+// (kStepMaxBlocks / 64 per lane and quantity, all issued before anything waits).
 constexpr int kStepMaxBlocks = 256;
 constexpr int kStepPL = kStepMaxBlocks / 64;
+constexpr int kStepMaxItems = 32;  // slots one workgroup walks at most (K <= 32 pricings per launch)
 
 template <int SEM, int VEC, int BLOCK, bool STAMP = false>
-__device__ __forceinline__ void lsm_step_body(StepArgs a)
+__device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int G)
 {
     constexpr int WAVES = BLOCK / 64;
     // STAMP: where a launch spends its time, seen from wave 0 of every workgroup (the wave on the
@@ -118,13 +128,13 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
     };
     mark(0);
     __shared__ double wl[WAVES * kWaveRedDoubles];
-    __shared__ double sh_w[WAVES * 8];
+    __shared__ double sh_w[kStepMaxItems * WAVES * 8];
     __shared__ double sh_beta[4];
     extern __shared__ double sh_D[];  // SEM 1 only: [N+1]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = a.t, N = a.N;
-    if ((int)blockIdx.x >= a.nblk || t > N) return;  // batched launch sized for a bigger problem
+    if (w >= a.nblk || t > N) return;  // batched launch sized for a bigger problem
     const bool do_apply = t < N, do_mom = t >= 2, init = (t == N);
     const bool values = a.cont != nullptr;
     const float* controw = values ? a.cont + (int64_t)t * a.ldc : nullptr;
@@ -156,32 +166,62 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- this thread's first row / state loads: in flight across the prologue
+    // ---- the row / state chunks this thread will walk: (slot w, chunk 0), (slot w, chunk 1) ..., (slot w + G, 0) ...
+    // Two chunks are kept in flight (buffers A and B, refilled right after use): the first two go out here, ahead
+    // of the prologue.  With one chunk in flight per thread a workgroup has 53 KB outstanding, which caps the chip
+    // at ~6.2 TB/s of the 13 bytes per path once several pricings share a launch; the second buffer costs 13 VGPRs.
     const float* St = a.S + (int64_t)t * a.ld;
     const float* Sm = St - a.ld;
     const float* Sn = a.S + (int64_t)N * a.ld;
     const int64_t stride = (int64_t)a.nblk * BLOCK * VEC;
-    int64_t j = ((int64_t)blockIdx.x * BLOCK + tid) * VEC;
-    float st[VEC], sm[VEC], sx[VEC];  // sx: SEM 0 terminal spot S_N, SEM 1 spot at the current exercise time
-    int32_t tex[VEC];                 // SEM 1 only
-    uint32_t exw = 0;                 // SEM 0: VEC flag bytes
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) { st[v] = sm[v] = sx[v] = 0.f; tex[v] = 0; }
-    auto load_chunk = [&](int64_t jj) {
-        loadf<VEC>(St + jj, st);  // (the nontemporal hint on this row, last read here, changes nothing: measured)
-        if (do_mom) loadf<VEC>(Sm + jj, sm);
+    struct Chunk {
+        float st[VEC], sm[VEC], sx[VEC];  // sx: SEM 0 terminal spot S_N, SEM 1 spot at the current exercise time
+        int32_t tex[VEC];                 // SEM 1 only
+        uint32_t exw;                     // SEM 0: VEC flag bytes
+        int64_t j;                        // first column of the chunk; >= M: nothing there for this lane
+    };
+    auto load_chunk = [&](Chunk& c) {
+        loadf<VEC>(St + c.j, c.st);  // (the nontemporal hint on this row, last read here, changes nothing: measured)
+        if (do_mom) loadf<VEC>(Sm + c.j, c.sm);
         if (!init) {
             if (SEM == 0) {
-                loadf<VEC>(Sn + jj, sx);
-                if constexpr (VEC == 4) exw = *reinterpret_cast<const uint32_t*>(a.ex + jj);
-                else exw = a.ex[jj];
+                loadf<VEC>(Sn + c.j, c.sx);
+                if constexpr (VEC == 4) c.exw = *reinterpret_cast<const uint32_t*>(a.ex + c.j);
+                else c.exw = a.ex[c.j];
             } else {
-                loadf<VEC>(a.sx + jj, sx);
-                loadi<VEC>(a.tex + jj, tex);
+                loadf<VEC>(a.sx + c.j, c.sx);
+                loadi<VEC>(a.tex + c.j, c.tex);
             }
         }
     };
-    if (j < a.M) load_chunk(j);
+    // chunks of slot vb: as many as its FIRST thread has (uniform over the workgroup; lanes beyond M idle)
+    auto slot_chunks = [&](int vb) { return (int)((a.M - (int64_t)vb * BLOCK * VEC + stride - 1) / stride); };
+    int cur_vb = w, cur_i = 0, cur_n = slot_chunks(w);
+    auto fetch = [&](Chunk& c, bool& valid, bool& last) {
+        valid = cur_vb < a.nblk;
+        last = false;
+        if (!valid) return;
+        c.j = ((int64_t)cur_vb * BLOCK + tid) * VEC + (int64_t)cur_i * stride;
+        if (c.j < a.M) load_chunk(c);
+        last = cur_i + 1 == cur_n;
+        if (last) {
+            cur_vb += G;
+            cur_i = 0;
+            cur_n = cur_vb < a.nblk ? slot_chunks(cur_vb) : 0;
+        } else {
+            ++cur_i;
+        }
+    };
+    Chunk A, B;
+    bool vA, lA, vB, lB;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        A.st[v] = A.sm[v] = A.sx[v] = B.st[v] = B.sm[v] = B.sx[v] = 0.f;
+        A.tex[v] = B.tex[v] = 0;
+    }
+    A.exw = B.exw = 0;
+    fetch(A, vA, lA);
+    fetch(B, vB, lB);
     __builtin_amdgcn_sched_barrier(0);
 
     double b0 = 0.0, b1 = 0.0, b2 = 0.0, nfit = 0.0;
@@ -190,7 +230,7 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
             double m[8];
             if (a.external) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) m[q] = a.gmom[(size_t)t * 8 + q];
+                for (int q = 0; q < 8; ++q) m[q] = a.gmom[(size_t)t * a.gstride + q];
             } else {
                 double acc[8];
 #pragma unroll
@@ -212,12 +252,12 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
             mark(2);
             if (lane == 0) {
                 sh_beta[0] = beta[0]; sh_beta[1] = beta[1]; sh_beta[2] = beta[2]; sh_beta[3] = m[0];
-                if (blockIdx.x == 0) {
+                if (w == 0) {
                     double* bo = a.betas + (size_t)t * 4;
                     bo[0] = beta[0]; bo[1] = beta[1]; bo[2] = beta[2]; bo[3] = m[0];
                     if (!a.external) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) a.gmom[(size_t)t * 8 + q] = m[q];
+                        for (int q = 0; q < 8; ++q) a.gmom[(size_t)t * a.gstride + q] = m[q];
                     }
                 }
             }
@@ -233,114 +273,134 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
         mark(4);
     }
 
-    double acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-    bool added = false;
     const double Dm = do_mom ? a.D[N - (t - 1)] : 0.0;
     const double K = a.K, invK = a.invK;
     const int is_put = a.is_put;
     const bool fit_ok = do_apply && (values || nfit > 0.5);
-    while (j < a.M) {
-        if (SEM == 0) {
-            if (init) {
-                exw = 0;
+    int item = 0;
+    double acc[8];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) sx[v] = st[v];
-                if constexpr (VEC == 4) *reinterpret_cast<uint32_t*>(a.ex + j) = 0u;
-                else a.ex[j] = 0;
-            }
-            if (fit_ok) {
-                uint32_t neww = exw;
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    bool added = false;
+    // one chunk: apply the exercise rule at t, add to the moments of t-1; `last`: the slot ends here
+    auto consume = [&](Chunk& c, const bool last) {
+        const int64_t j = c.j;
+        if (j < a.M) {
+            if (SEM == 0) {
+                if (init) {
+                    c.exw = 0;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const double imm = payoff_d(st[v], K, is_put);
-                    if (imm > 0.0 && ((exw >> (8 * v)) & 0xffu) == 0u) {
-                        const double u = fma((double)st[v], invK, -1.0);
-                        const double cont = values ? (double)controw[j + v] : fma(u, fma(u, b2, b1), b0);
-                        if (imm > cont) {  // each path gets here at most once in the whole sweep
-                            neww |= 1u << (8 * v);
-                            a.sx[j + v] = st[v];
-                            a.tex[j + v] = t;
+                    for (int v = 0; v < VEC; ++v) c.sx[v] = c.st[v];
+                    if constexpr (VEC == 4) *reinterpret_cast<uint32_t*>(a.ex + j) = 0u;
+                    else a.ex[j] = 0;
+                }
+                if (fit_ok) {
+                    uint32_t neww = c.exw;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double imm = payoff_d(c.st[v], K, is_put);
+                        if (imm > 0.0 && ((c.exw >> (8 * v)) & 0xffu) == 0u) {
+                            const double u = fma((double)c.st[v], invK, -1.0);
+                            const double cont = values ? (double)controw[j + v] : fma(u, fma(u, b2, b1), b0);
+                            if (imm > cont) {  // each path gets here at most once in the whole sweep
+                                neww |= 1u << (8 * v);
+                                a.sx[j + v] = c.st[v];
+                                a.tex[j + v] = t;
+                            }
+                        }
+                    }
+                    if (neww != c.exw) {
+                        c.exw = neww;
+                        if constexpr (VEC == 4) *reinterpret_cast<uint32_t*>(a.ex + j) = neww;
+                        else a.ex[j] = (uint8_t)neww;
+                    }
+                }
+                if (do_mom) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double imm = payoff_d(c.sm[v], K, is_put);
+                        if (imm > 0.0 && ((c.exw >> (8 * v)) & 0xffu) == 0u) {
+                            double p = payoff_d(c.sx[v], K, is_put);
+                            p = p > 0.0 ? p : 0.0;
+                            accumulate_moments(acc, fma((double)c.sm[v], invK, -1.0), p * Dm);
+                            added = true;
                         }
                     }
                 }
-                if (neww != exw) {
-                    exw = neww;
-                    if constexpr (VEC == 4) *reinterpret_cast<uint32_t*>(a.ex + j) = exw;
-                    else a.ex[j] = (uint8_t)exw;
-                }
-            }
-            if (do_mom) {
+            } else {
+                bool changed = false;
+                if (init) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const double imm = payoff_d(sm[v], K, is_put);
-                    if (imm > 0.0 && ((exw >> (8 * v)) & 0xffu) == 0u) {
-                        double p = payoff_d(sx[v], K, is_put);
-                        p = p > 0.0 ? p : 0.0;
-                        accumulate_moments(acc, fma((double)sm[v], invK, -1.0), p * Dm);
-                        added = true;
+                    for (int v = 0; v < VEC; ++v) { c.sx[v] = c.st[v]; c.tex[v] = N; }
+                    changed = true;
+                }
+                if (fit_ok) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double imm = payoff_d(c.st[v], K, is_put);
+                        if (imm > 0.0) {
+                            const double u = fma((double)c.st[v], invK, -1.0);
+                            const double cont = values ? (double)controw[j + v] : fma(u, fma(u, b2, b1), b0);
+                            if (imm > cont) { c.sx[v] = c.st[v]; c.tex[v] = t; changed = true; }
+                        }
                     }
                 }
-            }
-        } else {
-            bool changed = false;
-            if (init) {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) { sx[v] = st[v]; tex[v] = N; }
-                changed = true;
-            }
-            if (fit_ok) {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const double imm = payoff_d(st[v], K, is_put);
-                    if (imm > 0.0) {
-                        const double u = fma((double)st[v], invK, -1.0);
-                        const double cont = values ? (double)controw[j + v] : fma(u, fma(u, b2, b1), b0);
-                        if (imm > cont) { sx[v] = st[v]; tex[v] = t; changed = true; }
-                    }
+                if (changed) {
+                    storef<VEC>(a.sx + j, c.sx);
+                    storei<VEC>(a.tex + j, c.tex);
                 }
-            }
-            if (changed) {
-                storef<VEC>(a.sx + j, sx);
-                storei<VEC>(a.tex + j, tex);
-            }
-            if (do_mom) {
+                if (do_mom) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const double imm = payoff_d(sm[v], K, is_put);
-                    if (imm > 0.0) {
-                        double p = payoff_d(sx[v], K, is_put);
-                        p = p > 0.0 ? p : 0.0;
-                        accumulate_moments(acc, fma((double)sm[v], invK, -1.0), p * sh_D[tex[v] - (t - 1)]);
-                        added = true;
+                    for (int v = 0; v < VEC; ++v) {
+                        const double imm = payoff_d(c.sm[v], K, is_put);
+                        if (imm > 0.0) {
+                            double p = payoff_d(c.sx[v], K, is_put);
+                            p = p > 0.0 ? p : 0.0;
+                            accumulate_moments(acc, fma((double)c.sm[v], invK, -1.0), p * sh_D[c.tex[v] - (t - 1)]);
+                            added = true;
+                        }
                     }
                 }
             }
         }
-        j += stride;
-        if (j < a.M) load_chunk(j);
+        if (last) {  // the slot's sums: wave transpose-reduce now, waves added after the last slot
+            if (do_mom) {
+                // a wave none of whose lanes added anything contributes exact zeros: skip its transpose
+                double s = 0.0;
+                if (__builtin_amdgcn_ballot_w64(added) != 0) s = wave_reduce8(acc, wl + wave * kWaveRedDoubles);
+                if ((lane & 7) == 0) sh_w[(item * WAVES + wave) * 8 + (lane >> 3)] = s;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+                added = false;
+            }
+            ++item;
+        }
+    };
+    for (;;) {
+        if (!vA) break;
+        consume(A, lA);
+        fetch(A, vA, lA);
+        if (!vB) break;
+        consume(B, lB);
+        fetch(B, vB, lB);
     }
     mark(5);
     if (do_mom) {
-        // a wave none of whose lanes added anything contributes exact zeros: skip its transpose
-        double s = 0.0;
-        if (__builtin_amdgcn_ballot_w64(added) != 0) s = wave_reduce8(acc, wl + wave * kWaveRedDoubles);
-        if ((lane & 7) == 0) sh_w[wave * 8 + (lane >> 3)] = s;
         __syncthreads();
         mark(6);
-        if (tid < 8) {
+        if (tid < 8 * item) {  // one thread per (slot, quantity): waves added in wave order
+            const int it = tid >> 3, q = tid & 7;
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) tot += sh_w[w * 8 + tid];
-            a.part[(size_t)((t - 1) & 1) * 8 * a.pstride + (size_t)tid * a.pstride + blockIdx.x] = tot;
+            for (int ww = 0; ww < WAVES; ++ww) tot += sh_w[(it * WAVES + ww) * 8 + q];
+            a.part[(size_t)((t - 1) & 1) * 8 * a.pstride + (size_t)q * a.pstride + (w + it * G)] = tot;
         }
     }
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)");
         mark(7);
         if (tid == 0 && a.dbg) {
-            unsigned long long* d = a.dbg + ((size_t)(N - t) * a.nblk + blockIdx.x) * 8;
+            unsigned long long* d = a.dbg + ((size_t)(N - t) * a.nblk + w) * 8;
 #pragma unroll
             for (int k = 0; k < 8; ++k) d[k] = stamp[k];
         }
@@ -349,7 +409,7 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a)
 
 // partial moments of step t -> gmom[t] (used when the moments leave the GPU between steps)
 __device__ __forceinline__ void lsm_reduce_step_body(const double* __restrict__ part, double* __restrict__ gmom,
-                                                     int t, int nblk, int pstride)
+                                                     int t, int nblk, int pstride, int gstride = 8)
 {
     __shared__ double red[kNQ * kRedStride];
     const int tid = threadIdx.x;
@@ -362,7 +422,7 @@ __device__ __forceinline__ void lsm_reduce_step_body(const double* __restrict__ 
         for (int q = 0; q < 8; ++q) acc[q] += pp[q * pstride + i];
     }
     const double s = block_reduce8(acc, red);
-    if (tid < 64 && (tid & 7) == 0) gmom[(size_t)t * 8 + (tid >> 3)] = s;
+    if (tid < 64 && (tid & 7) == 0) gmom[(size_t)t * gstride + (tid >> 3)] = s;
 }
 
 // ------------------------------------------------------------------ two-pass flow
@@ -802,7 +862,7 @@ __device__ __forceinline__ void lsm_final_body(FinalArgs a)
 __device__ __forceinline__ void lsm_finalize_body(const double* __restrict__ part,
                                                   const double* __restrict__ gmom,
                                                   double* __restrict__ result, int nblk, int N,
-                                                  int pstride)
+                                                  int pstride, int gstride = 8)
 {
     __shared__ double red[kNQ * kRedStride];
     const int tid = threadIdx.x;
@@ -813,7 +873,7 @@ __device__ __forceinline__ void lsm_finalize_body(const double* __restrict__ par
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] += part[(size_t)q * pstride + i];
     }
-    for (int t = 1 + tid; t < N; t += kBlock) acc[4] += gmom[(size_t)t * 8];
+    for (int t = 1 + tid; t < N; t += kBlock) acc[4] += gmom[(size_t)t * gstride];
     const double s = block_reduce8(acc, red);
     if (tid < 64 && (tid & 7) == 0) result[tid >> 3] = s;
 }
