@@ -19,6 +19,15 @@ SOURCES = ["omc_paths.hip", "omc_lsm.hip", "omc_lsm_persist.hip", "omc_batch.hip
 HEADERS = ["omc_device.h", "omc_kernels.h", "omc_lsm_dev.h", "omc_paths_dev.h", "omc_batch.h", "omc_comm.h",
            os.path.join("..", "..", "include", "omc.h")]
 ARCH = "gfx950"
+# The extra compiler flags the library was built with (OMC_HIPCC_FLAGS: experiment builds such as
+# -DOMC_DIAG_BUILD or -DOMC_P2_U=16) are recorded next to it: a library left behind by an experiment is
+# stale for every process that does not ask for the same flags, so tests / bench / profiles can never
+# silently run a non-default build.
+FLAGS_STAMP = os.path.join(LIBDIR, "libomc.flags")
+
+
+def _flags() -> str:
+    return " ".join(os.environ.get("OMC_HIPCC_FLAGS", "").split())
 
 
 def _hipcc() -> str:
@@ -30,6 +39,12 @@ def _hipcc() -> str:
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
+        return True
+    try:
+        built_with = open(FLAGS_STAMP).read().strip()
+    except OSError:
+        built_with = ""
+    if built_with != _flags():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -47,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c",
                "-Wall", "-Wno-unused-function", os.path.join(CSRC, s), "-o", o]
-        cmd[1:1] = os.environ.get("OMC_HIPCC_FLAGS", "").split()  # experiments (-D..., -save-temps)
+        cmd[1:1] = _flags().split()  # experiments (-D..., -save-temps)
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd), flush=True)
@@ -60,6 +75,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(_flags() + "\n")
     return LIB
 
 

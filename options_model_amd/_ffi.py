@@ -593,23 +593,22 @@ _pools = {}
 
 
 def context_pool(n: int, device: int = 0) -> list:
-    """n contexts on one device (own stream and workspaces each; the first is default_context()): for work
-    made of many small, latency-bound pricings -- the per-step network flow of the v1 / v2 curves -- which
-    overlap on the GPU when issued from several host threads (ctypes releases the GIL during a call)."""
+    """n DEDICATED contexts on one device (own stream and workspaces each; never default_context(), which other
+    code of the process may be using at the same time -- an omc_ctx is not thread-safe): for work made of many
+    small, latency-bound pricings -- the per-step network flow of the v1 / v2 curves -- which overlap on the GPU
+    when issued from several host threads (ctypes releases the GIL during a call)."""
     key = (os.getpid(), device)
     with _ctx_lock:
         pool = _pools.setdefault(key, [])
-    if not pool:
-        pool.append(default_context(device))
-    with _ctx_lock:
         while len(pool) < n:
-            pool.append(Context(device))
+            pool.append((Context(device), threading.Lock()))
         return pool[:n]
 
 
 def map_contexts(fn, items, workers: int | None = None, device: int = 0) -> list:
     """[fn(ctx, item) for item in items], in order, run by `workers` host threads with one context each
-    (OMC_CURVE_STREAMS, default 8; 1 = plain loop on the default context)."""
+    (OMC_CURVE_STREAMS, default 8; 1 = plain loop on the default context).  Every pool context is used under
+    its own lock, so two map_contexts calls running at once (two threads of the caller) share the pool safely."""
     items = list(items)
     if workers is None:
         workers = int(os.environ.get("OMC_CURVE_STREAMS", "8"))
@@ -617,19 +616,14 @@ def map_contexts(fn, items, workers: int | None = None, device: int = 0) -> list
     if workers == 1:
         ctx = default_context(device)
         return [fn(ctx, it) for it in items]
-    import queue
     from concurrent.futures import ThreadPoolExecutor
-    free = queue.SimpleQueue()
-    for ctx in context_pool(workers, device):
-        free.put(ctx)
+    pool = context_pool(workers, device)
 
-    def one(it):
-        ctx = free.get()
-        try:
+    def one(args):
+        i, it = args
+        ctx, lock = pool[i % workers]
+        with lock:
             return fn(ctx, it)
-        finally:
-            free.put(ctx)
 
     with ThreadPoolExecutor(max_workers=workers) as ex:
-        return list(ex.map(one, items))
-
+        return list(ex.map(one, enumerate(items)))

@@ -18,10 +18,19 @@ semantics (the reference's exercise rule is not textbook LSM, a
 regressor:
   "poly"      OLS on [1,u,u^2], u=S/K-1, one fit per time step (the reference validates
               lsm_poly_degree and then ignores it: Options_model.py:53,69-70)
+n_gpus:
+  1           this process, one GPU (`device`).
+  N > 1       the paths shard by antithetic pair over the N GPUs of one node, ONE PROCESS PER GPU: the call
+              must be made by every rank of an N-rank job (`python -m torch.distributed.run --nproc-per-node
+              N script.py`, or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT); each rank
+              prices its shard through the library's own RCCL communicator (dist.RcclPricer: regression
+              moments and result sums all-reduced over xGMI) and every rank returns the same global result.
+              Called from a lone process it refuses -- it never silently prices on one GPU.
 """
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 from . import _ffi
@@ -77,14 +86,21 @@ def heston_defaults(sigma, heston_params=None):
 def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", option_type="put",
                           regressor="poly", semantics="two_pass", heston_params=None,
                           heston_scheme="reference", antithetic=True, seed=42, stream=0,
-                          device=0, ctx=None) -> PriceResult:
+                          device=None, ctx=None, n_gpus=1) -> PriceResult:
     model_l = str(model).lower()
+    n_gpus = int(n_gpus)
+    if n_gpus < 1:
+        raise ValueError("n_gpus must be a positive integer.")
+    if device is None and n_gpus == 1:
+        device = 0
     if model_l not in ("gbm", "heston"):
         raise ValueError("model must be 'GBM' or 'Heston'.")
     if semantics not in _SEM:
         raise ValueError(f"semantics must be one of {sorted(set(_SEM))}.")
     if regressor != "poly":
         if regressor == "nn":
+            if n_gpus > 1:
+                raise ValueError("n_gpus > 1 shards the polynomial regressor's flows; regressor='nn' runs on one GPU.")
             from . import nn_regressor
             return nn_regressor.price_american_option_nn(
                 S0, K, r, sigma, T, n_paths, n_steps, model=model, option_type=option_type,
@@ -95,6 +111,19 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
     if M <= 0:
         raise ValueError("num_simulations and num_time_steps must be positive integers.")
     hp = heston_defaults(sigma, heston_params)
+    if n_gpus > 1:
+        if ctx is not None:
+            raise ValueError("n_gpus > 1 uses the job's own per-rank context; do not pass ctx.")
+        sp = _job_pricer(n_gpus, device)
+        out = sp.price_american(M, model=model_l, is_put=(option_type == "put"), semantics=_SEM[semantics],
+                                antithetic=antithetic, heston_scheme=heston_scheme, n_steps=int(n_steps), S0=S0,
+                                K=K, r=r, sigma=sigma or 0.0, T=T, seed=seed, stream=stream, **hp)
+        loc = out["local"]
+        return PriceResult(price=out["price"], stderr=out["stderr"], std=out["std"], zero_prob=out["zero_prob"],
+                           n_paths=out["n_paths"], n_exercised=out["n_exercised"], sum_nitm=out["sum_nitm"],
+                           model=model_l, semantics=semantics, option_type=option_type,
+                           timings_ms=dict(paths=loc["ms_paths"], lsm=loc["ms_lsm"], total=loc["ms_total"]),
+                           info=dict(n_gpus=n_gpus, rank=sp.rank, transport=sp.transport))
     c = ctx or _ffi.default_context(device)
     p = _ffi.make_params(model=model_l, is_put=(option_type == "put"), semantics=_SEM[semantics],
                          antithetic=antithetic, heston_scheme=heston_scheme, n_paths=M,
@@ -107,6 +136,32 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
                        sum_nitm=out["sum_nitm"], model=model_l, semantics=semantics,
                        option_type=option_type,
                        timings_ms=dict(paths=out["ms_paths"], lsm=out["ms_lsm"], total=out["ms_total"]))
+
+
+_job = {}
+
+
+def _job_pricer(n_gpus: int, device=None):
+    """The per-process RcclPricer of an n_gpus-rank job (created on first use, closed at exit)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != n_gpus or "RANK" not in os.environ:
+        raise RuntimeError(
+            f"price_american_option(n_gpus={n_gpus}) must be called by every rank of a {n_gpus}-rank job, one process "
+            f"per GPU (e.g. `python -m torch.distributed.run --nnodes=1 --nproc-per-node {n_gpus} script.py`); this "
+            f"process sees WORLD_SIZE={os.environ.get('WORLD_SIZE', 'unset')}, RANK={os.environ.get('RANK', 'unset')}. "
+            f"It does not fall back to one GPU.")
+    key = (os.getpid(), n_gpus)
+    sp = _job.get(key)
+    if sp is None:
+        import atexit
+
+        from .dist import RcclPricer
+        rank = int(os.environ["RANK"])
+        local = int(os.environ.get("LOCAL_RANK", rank)) if device is None else int(device)
+        sp = RcclPricer(local, rank, world)
+        _job[key] = sp
+        atexit.register(sp.close)
+    return sp
 
 
 def price_european_option(S0, K, r, sigma, T, n_paths, n_steps=1, model="GBM", option_type="put",

@@ -358,12 +358,10 @@ template <int H>
 static hipError_t forward_launch(hipStream_t st, const CnFwdArgs& fa)
 {
     constexpr size_t lds = sizeof(float) * (size_t)(H * 8 + H * H + H + H + 1);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn_forward_kernel<H>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<uint64_t> attr_mask{0};  // per device (omc_kernels.h)
+    if (lds > 48 * 1024) {
+        hipError_t e = set_max_dynamic_lds(attr_mask, reinterpret_cast<const void*>(cn_forward_kernel<H>), lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((cn_forward_kernel<H>), dim3((unsigned)((fa.c.M + kCnBlock - 1) / kCnBlock)), dim3(kCnBlock), lds,
                        st, fa);

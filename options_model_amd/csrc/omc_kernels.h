@@ -3,7 +3,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace omc {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of a kernel ON A DEVICE: a process that prices on
+// a second device must set it there too, and host threads with one context each may get here together.  `mask`
+// (one static per kernel instantiation) has a bit per device; setting the attribute twice is harmless.
+inline hipError_t set_max_dynamic_lds(std::atomic<uint64_t>& mask, const void* kernel, size_t bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    mask.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
 
 // ---- omc_paths.hip
 hipError_t launch_gbm_paths(hipStream_t st, float* S, int64_t ld, int64_t n_paths, int n_steps,

@@ -55,9 +55,13 @@ __global__ __launch_bounds__(kBlock) void lsm_reduce_step_kernel(const double* p
 template <int VEC, int TPW, int PUT>
 __global__ __launch_bounds__(kBlock) void lsm_pass1_kernel(Pass1Args a) { lsm_pass1_body<VEC, TPW, PUT>(a); }
 
-// measurement builds (OMC_PASS1_DIAG=1|2|3, wrong results by construction): which part of the kernel costs what
+// measurement builds only (-DOMC_DIAG_BUILD, then OMC_PASS1_DIAG=1|2|3; wrong results by construction): which
+// part of the kernel costs what.  Not compiled into the product library: no environment variable can make a
+// default build return wrong prices.
+#ifdef OMC_DIAG_BUILD
 template <int DIAG>
 __global__ __launch_bounds__(kBlock) void lsm_pass1_diag_kernel(Pass1Args a) { lsm_pass1_body<4, 4, 1, DIAG>(a); }
+#endif
 
 __global__ __launch_bounds__(kBlock) void lsm_reduce_pass1_kernel(const double* part1, double* gmom,
                                                                   int64_t ntiles, int N)
@@ -357,8 +361,9 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     }
     a.tchunk = (tch_env >= 2 && tch_env <= 126) ? tch_env : tchunk;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
-    static const int diag_env = getenv("OMC_PASS1_DIAG") ? atoi(getenv("OMC_PASS1_DIAG")) : 0;
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
+#ifdef OMC_DIAG_BUILD
+    static const int diag_env = getenv("OMC_PASS1_DIAG") ? atoi(getenv("OMC_PASS1_DIAG")) : 0;
     if (diag_env >= 1 && diag_env <= 3 && v4 && tpw == 4 && p.is_put) {
         if (diag_env == 1) hipLaunchKernelGGL((lsm_pass1_diag_kernel<1>), grid, dim3(kBlock), 0, st, a);
         else if (diag_env == 2) hipLaunchKernelGGL((lsm_pass1_diag_kernel<2>), grid, dim3(kBlock), 0, st, a);
@@ -368,6 +373,7 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
                            a.ntiles, p.N);
         return hipGetLastError();
     }
+#endif
     auto launch = [&](auto vec, auto tp) {
         constexpr int V = decltype(vec)::value, T = decltype(tp)::value;
         if (p.is_put) hipLaunchKernelGGL((lsm_pass1_kernel<V, T, 1>), grid, dim3(kBlock), 0, st, a);

@@ -1543,13 +1543,11 @@ hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, 
 template <int L>
 static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
 {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_mask{0};  // per device (omc_kernels.h)
     const size_t lds_bytes = sizeof(float) * (size_t)train_lds_floats(L);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_kernel<L>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (true) {
+        hipError_t e = set_max_dynamic_lds(attr_mask, reinterpret_cast<const void*>(mlp_train_kernel<L>), lds_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
     int64_t step = t.first_step;
@@ -1599,13 +1597,11 @@ static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
 template <int H, int L>
 static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
 {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_mask{0};  // per device (omc_kernels.h)
     const size_t lds_bytes = sizeof(float) * (size_t)tile_lds_floats(H, L);
-    if (!attr_set && lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = set_max_dynamic_lds(attr_mask, reinterpret_cast<const void*>(mlp_train_tile_kernel<H, L>), lds_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     if (!t.wt_current) hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
     const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
@@ -1733,13 +1729,11 @@ int mlp_apply_param_count(int hidden, int layers)
 template <int H, int L>
 static hipError_t launch_apply(hipStream_t st, const MlpApplyArgs& a)
 {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_mask{0};  // per device (omc_kernels.h)
     const size_t lds_bytes = sizeof(float) * (size_t)apply_lds_floats(H, L);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_apply_kernel<H, L>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (true) {
+        hipError_t e = set_max_dynamic_lds(attr_mask, reinterpret_cast<const void*>(mlp_apply_kernel<H, L>), lds_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((mlp_apply_kernel<H, L>), dim3((unsigned)((a.ntiles + 3) / 4)), dim3(256), lds_bytes, st, a);
     return hipGetLastError();

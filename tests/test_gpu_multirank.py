@@ -93,3 +93,50 @@ def test_failed_init_is_a_collective_fallback(standin):
     d = _line(out)
     assert d["rccl_ranks"] == 2 and d["comm"].startswith("torch.distributed gloo")
     assert out.stderr.count("native RCCL unavailable for this job") == 2
+
+
+_FACADE = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+from options_model_amd import price_american_option
+out = {}
+for sem in ("two_pass", "per_step", "textbook"):
+    r = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 200_000, 40, model="GBM", option_type="put",
+                              semantics=sem, seed=5, stream=2, n_gpus=2, device=0)
+    out[sem] = [r.price, r.n_paths, r.n_exercised, r.sum_nitm, r.stderr, r.info["transport"]]
+r = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 200_000, 40, model="Heston", option_type="call",
+                          heston_scheme="full_truncation", seed=5, n_gpus=2, device=0)
+out["heston"] = [r.price, r.n_paths, r.n_exercised, r.sum_nitm, r.stderr, r.info["transport"]]
+print("RESULT" + os.environ["RANK"] + " " + json.dumps(out))
+"""
+
+
+def test_facade_n_gpus_2_shards_through_the_native_communicator(ctx, standin, tmp_path):
+    """North-star facade, n_gpus=2: two rank processes (sharing this GPU through the stand-in) call
+    price_american_option(..., n_gpus=2); both get the price of the unsharded pricing."""
+    from options_model_amd import price_american_option
+    script = tmp_path / "facade2.py"
+    script.write_text(_FACADE % ROOT)
+    port = 29700 + os.getpid() % 200
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMC_RCCL_LIB=standin, OMC_RDZV_NONCE=f"facade{os.getpid()}")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    got = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        line = [ln for ln in so.splitlines() if ln.startswith("RESULT")][0]
+        got.append(json.loads(line.split(" ", 1)[1]))
+    assert got[0] == got[1]                      # every rank returns the same global result
+    for sem in ("two_pass", "per_step", "textbook"):
+        one = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 200_000, 40, semantics=sem, seed=5, stream=2, ctx=ctx)
+        price, n, nex, nitm, stderr, transport = got[0][sem]
+        assert transport == "rccl-native" and n == 200_000
+        assert price == pytest.approx(one.price, rel=1e-12) and stderr == pytest.approx(one.stderr, rel=1e-9)
+        assert (nex, nitm) == (one.n_exercised, one.sum_nitm)
+    one = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 200_000, 40, model="Heston", option_type="call",
+                                heston_scheme="full_truncation", seed=5, ctx=ctx)
+    assert got[0]["heston"][0] == pytest.approx(one.price, rel=1e-12)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is lsm_pass1_kernel slowed down by the generator's dirty lines?  Times the two-pass backward induction on a
 RESIDENT matrix (no generator in front of it) against the fused pricing (generator -> pass 1 -> pass 2).
-usage: exp_lsm_alone.py [paths]   (OMC_PASS1_DIAG=1|2|3 selects the measurement builds of pass 1)"""
+usage: exp_lsm_alone.py [paths]   (OMC_PASS1_DIAG=1|2|3 selects the measurement builds of pass 1; they exist only in a library built with OMC_HIPCC_FLAGS=-DOMC_DIAG_BUILD)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -3,6 +3,8 @@
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
+# whatever happens, leave the DEFAULT library behind (experiment builds must not outlive the experiment)
+trap 'env -u OMC_HIPCC_FLAGS python -c "from options_model_amd import _build; _build.build(force=True)" > /dev/null 2>&1' EXIT
 for V in "base:" "u4:-DOMC_P2_U=4" "u16:-DOMC_P2_U=16" "nt:-DOMC_P2_NT=1" "u16nt:-DOMC_P2_U=16 -DOMC_P2_NT=1"; do
   TAG=${V%%:*}; FLAGS=${V#*:}
   OMC_HIPCC_FLAGS="$FLAGS" timeout -k 10 400 python -c "from options_model_amd import _build; _build.build(force=True)" > gpurun_out/p2_build_$TAG.log 2>&1 || { tail -5 gpurun_out/p2_build_$TAG.log; exit 1; }

@@ -64,8 +64,9 @@ def main():
     elif what == "pass1":
         for M in (1_000_000, 8_000_000):
             run(dict(sem="two_pass", M=M))
-            for diag in (1, 2, 3):
-                run(dict(sem="two_pass", M=M), dict(OMC_PASS1_DIAG=diag))
+            for diag in (1, 2, 3):  # measurement kernels: only in a library built with -DOMC_DIAG_BUILD (the child
+                # process rebuilds when the recorded flags differ; the default library is rebuilt by the next default run)
+                run(dict(sem="two_pass", M=M), dict(OMC_PASS1_DIAG=diag, OMC_HIPCC_FLAGS="-DOMC_DIAG_BUILD"))
             for tpw in (2, 8):
                 run(dict(sem="two_pass", M=M), dict(OMC_PASS1_TPW=tpw))
             for tch in (16, 64):
