@@ -273,6 +273,57 @@ def _dropout_of(net):
     return float(ps[0]) if ps else 0.0
 
 
+class EpochControl:
+    """Host-side control of the reference's training loop (options_model_3/options_model_3.py:574-613), as plain
+    arithmetic on the epoch-mean losses -- no tensors, no optimizer object:
+
+      * `scheduler.step(avg_loss)` of ReduceLROnPlateau(opt, patience=5, factor=0.5, min_lr=1e-6) with torch's other
+        defaults (mode "min", threshold 1e-4 relative, cooldown 0, eps 1e-8): an epoch is "better" when
+        loss < best * (1 - 1e-4); after MORE than 5 epochs in a row that are not, lr <- max(lr / 2, 1e-6) (applied only
+        if it changes lr by more than 1e-8) and the count restarts;
+      * the reference's own rule right after it: `avg_loss < best_loss - 1e-6` keeps the weights of that epoch and
+        resets its counter, anything else counts, and the 8th in a row ends training (":607-611");
+      * at the end the kept weights are restored (":613-615").
+
+    step(avg_loss) -> (keep_weights, stop).  Pinned in tests/test_nn_epoch_control_cpu.py against torch's scheduler on
+    scripted losses and against traces recorded from the reference's real runs (tests/golden/nn_epoch_trace.npz)."""
+
+    def __init__(self, lr, patience=5, factor=0.5, min_lr=1e-6, threshold=1e-4, eps=1e-8, stop_patience=8,
+                 min_delta=1e-6):
+        self.lr = float(lr)
+        self.patience, self.factor, self.min_lr, self.threshold, self.eps = patience, factor, min_lr, threshold, eps
+        self.stop_patience, self.min_delta = stop_patience, min_delta
+        self.sched_best = float("inf")
+        self.num_bad = 0
+        self.best_loss = float("inf")
+        self.best_epoch = -1   # 0-based epoch whose weights are kept (-1: none yet)
+        self.bad = 0
+        self.epoch = -1
+
+    def step(self, avg_loss):
+        avg_loss = float(avg_loss)
+        self.epoch += 1
+        # ReduceLROnPlateau.step (mode min, relative threshold, no cooldown)
+        if avg_loss < self.sched_best * (1.0 - self.threshold):
+            self.sched_best = avg_loss
+            self.num_bad = 0
+        else:
+            self.num_bad += 1
+        if self.num_bad > self.patience:
+            new_lr = max(self.lr * self.factor, self.min_lr)
+            if self.lr - new_lr > self.eps:
+                self.lr = new_lr
+            self.num_bad = 0
+        # the reference's early-stopping rule
+        if avg_loss < self.best_loss - self.min_delta:
+            self.best_loss = avg_loss
+            self.best_epoch = self.epoch
+            self.bad = 0
+            return True, False
+        self.bad += 1
+        return False, self.bad >= self.stop_patience
+
+
 def _train_fused(net, data, epochs, lr, bs, verbose):
     """The epoch loop of :565-613 around omc_mlp_train_epoch (hand-written MFMA forward/backward +
     Adam kernels); shuffling, the plateau scheduler and early stopping stay on the host side."""
@@ -283,33 +334,29 @@ def _train_fused(net, data, epochs, lr, bs, verbose):
     params = flatten_params(net)
     m = torch.zeros_like(params)
     v = torch.zeros_like(params)
-    holder = torch.zeros(1, requires_grad=True)
-    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(torch.optim.SGD([holder], lr=float(lr)), patience=5,
-                                                       factor=0.5, min_lr=1e-6)
+    ctl = EpochControl(lr)
     p_drop = _dropout_of(net)
     seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # drawn from torch's seeded generator
-    best, best_params, bad, step = float("inf"), None, 0, 0
+    best_params, step = None, 0
     t_kernels = 0.0
     torch.cuda.current_stream(dev).synchronize()  # the training matrix is complete
     for epoch in range(epochs):
         t1 = time.perf_counter()
         # the epoch's shuffle (:575 randperm) is a keyed permutation evaluated inside the kernel
         avg, step = ctx.mlp_train_epoch(data.data_ptr(), R, bs, params.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                        step, sched.optimizer.param_groups[0]["lr"], p_drop, seed,
+                                        step, ctl.lr, p_drop, seed,
                                         hidden=_linear_shape(net)[0], layers=_linear_shape(net)[1], shuffle_key=(seed ^ (0x9E3779B97F4A7C15 * (epoch + 1))) % (1 << 64) or 1)
         t_kernels += time.perf_counter() - t1
-        sched.step(avg)
-        if avg < best - 1e-6:
-            best, best_params, bad = avg, params.clone(), 0
-        else:
-            bad += 1
-            if bad >= 8:
-                if verbose:
-                    print(f"Early stopping at epoch {epoch + 1}, restoring best weights")
-                break
+        keep, stop = ctl.step(avg)
+        if keep:
+            best_params = params.clone()
+        elif stop:
+            if verbose:
+                print(f"Early stopping at epoch {epoch + 1}, restoring best weights")
+            break
     unflatten_params(net, best_params if best_params is not None else params)
-    return dict(batch=bs, optimizer_steps=step, epochs_run=epoch + 1, best_loss=best, graphed=False,
-                trainer="hip", seconds_train_kernels=t_kernels)
+    return dict(batch=bs, optimizer_steps=step, epochs_run=epoch + 1, best_loss=ctl.best_loss, best_epoch=ctl.best_epoch,
+                final_lr=ctl.lr, graphed=False, trainer="hip", seconds_train_kernels=t_kernels)
 
 
 def build_rows_fused(S, K, r, T, is_put):
@@ -374,8 +421,8 @@ def train_on_matrix(net, data, epochs, lr, nn_batch=None, verbose=False, use_gra
             for v_ in st_.values():
                 if torch.is_tensor(v_):
                     v_.zero_()
-    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=5, factor=0.5, min_lr=1e-6)
-    best, best_state, bad, steps = float("inf"), None, 0, 0
+    ctl = EpochControl(lr)
+    best_state, steps = None, 0
     for epoch in range(epochs):
         perm = torch.randperm(R, device=dev)
         shuf = data[perm]
@@ -395,19 +442,18 @@ def train_on_matrix(net, data, epochs, lr, nn_batch=None, verbose=False, use_gra
         del shuf
         steps += nb
         avg = float(tot) / max(nb, 1)  # one host sync per epoch
-        sched.step(avg)
-        if avg < best - 1e-6:
-            best, best_state, bad = avg, copy.deepcopy(net.state_dict()), 0
-        else:
-            bad += 1
-            if bad >= 8:
-                if verbose:
-                    print(f"Early stopping at epoch {epoch + 1}, restoring best weights")
-                break
+        keep, stop = ctl.step(avg)
+        lr_t.fill_(ctl.lr)  # the optimizer reads its learning rate from this tensor (capturable Adam)
+        if keep:
+            best_state = copy.deepcopy(net.state_dict())
+        elif stop:
+            if verbose:
+                print(f"Early stopping at epoch {epoch + 1}, restoring best weights")
+            break
     if best_state is not None:
         net.load_state_dict(best_state)
-    return dict(batch=bs, optimizer_steps=steps, epochs_run=epoch + 1, best_loss=best, graphed=graphed,
-                trainer="torch")
+    return dict(batch=bs, optimizer_steps=steps, epochs_run=epoch + 1, best_loss=ctl.best_loss, best_epoch=ctl.best_epoch,
+                final_lr=ctl.lr, graphed=graphed, trainer="torch")
 
 
 def pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, path_chunk=1 << 20):

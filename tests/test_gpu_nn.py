@@ -181,6 +181,27 @@ def test_config1_nn_end_to_end_band(torch_cuda, golden):
     assert p.rng_manager.get_child_seed() == golden["scalars"]["rng_manager_42_child_seeds"][2]
 
 
+def test_config1_nn_mean_over_eight_seeds_is_inside_the_reference_range(torch_cuda, golden):
+    """Round 3: the reference's own prices for config 1 (five seeds, default 3 x 128 net) span [6.81, 7.29].  The mean
+    of OUR pricer over eight seeds must lie inside that range (no widening), and every single price within the range
+    widened by the reference's own standard deviation -- the band a sixth reference seed would be held to."""
+    import numpy as np
+
+    from options_model_amd import AdvancedOptionPricer, RNGManager
+    sc = golden["scalars"]
+    refs = np.array([sc["end_to_end_10k_x_50_seed42"]["gbm_put_cv_off"]] + list(sc["reference_nn_seed_band"].values()))
+    lo, hi, sd = refs.min(), refs.max(), refs.std(ddof=1)
+    prices = []
+    for seed in (42, 1, 2, 3, 4, 5, 6, 7):
+        p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(seed),
+                                 use_control_variate=False)
+        prices.append(p.price_american_option(100.0, 1.0, 10000, 50))
+    prices = np.array(prices)
+    print("config-1 NN prices over 8 seeds:", np.round(prices, 4), "mean", prices.mean(), "reference", np.round(refs, 4))
+    assert lo <= prices.mean() <= hi, (prices, refs)
+    assert np.all((prices > lo - sd) & (prices < hi + sd)), (prices, refs)
+
+
 def test_config1_nn_hidden64_all_hip_lands_in_the_reference_band(torch_cuda, golden):
     """Same flow with nn_hidden=64: SingleLSMNet(7, 64, 3) -- here the network is trained by the
     library's fused MFMA trainer and applied by its pass-2 kernel (no PyTorch autograd, no PyTorch
