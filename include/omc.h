@@ -310,6 +310,32 @@ int omc_localvol_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, 
                            double r, double T, double K, int hidden, int layers, const float* params,
                            double m_scale, double tau_scale, double epsilon, const float* Z);
 
+/* ---- many small networks trained side by side (curves with the NN regressor) --------------------------------- */
+/* The reference prices a value-vs-expiry curve point by point, training a fresh SingleLSMNet per point
+ * (compute_curve_for_S0, options_model_3.py:697-713 -> :565-613); at its minibatch of 256 rows one network occupies
+ * 8 of the chip's 256 CUs.  This trains n networks of ONE shape (hidden x layers) for one epoch each, side by side:
+ * one launch pair per optimizer step for all of them (problem index on the grid), each network on its own rows,
+ * learning rate, dropout / shuffle keys and step counter.  Every network ends the epoch with exactly the parameters,
+ * Adam moments and mean loss that its own omc_mlp_train_epoch call produces (same kernel body, same reductions).
+ * jobs[i].step is advanced by the epoch's steps, jobs[i].mean_loss receives the epoch-mean batch loss.  Pointers are
+ * device pointers as in omc_mlp_train_epoch.  Shapes: 64 | 128 units x 2 | 3 hidden layers (and 32 x 2) at
+ * minibatches of at most 8192 rows. */
+typedef struct {
+    const float* data;     /* [n_rows][8] float32: 7 normalised features + normalised target        */
+    int64_t n_rows, batch;
+    float* params;         /* omc_mlp_param_count(hidden, layers) floats, updated in place           */
+    float* adam_m;
+    float* adam_v;
+    int64_t step;          /* in: optimizer steps taken so far; out: + this epoch's                  */
+    double lr;
+    uint64_t seed;         /* dropout bits                                                          */
+    uint64_t shuffle_key;  /* 0: storage order; else this epoch's keyed permutation                 */
+    double mean_loss;      /* out                                                                   */
+} omc_mlp_job;
+int omc_mlp_train_batch_supported(int hidden, int layers, int64_t batch); /* 1: this shape / minibatch is covered */
+int omc_mlp_train_epoch_batch(omc_ctx* ctx, omc_mlp_job* jobs, int n, int hidden, int layers, double beta1,
+                              double beta2, double eps, double weight_decay, double dropout);
+
 /* ---- a sequence of pricings without host synchronisation in between ------------------------- */
 /* n independent pricings enqueued back to back on the context's stream (pricing i + 1 is launched while
  * pricing i runs; every pricing's result sums land in their own slot of a host-mapped buffer; one wait

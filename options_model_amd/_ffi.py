@@ -46,6 +46,14 @@ class Result(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class MlpJob(C.Structure):
+    """omc_mlp_job: one network of a batch trained side by side (omc_mlp_train_epoch_batch)."""
+    _fields_ = [("data", C.c_void_p), ("n_rows", C.c_int64), ("batch", C.c_int64),
+                ("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+                ("step", C.c_int64), ("lr", C.c_double), ("seed", C.c_uint64), ("shuffle_key", C.c_uint64),
+                ("mean_loss", C.c_double)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
 
 # name -> (restype, argtypes); every symbol include/omc.h declares
@@ -92,6 +100,8 @@ SIGNATURES = {
     "omc_mlp_train_supported": (C.c_int, [_I, _I, _I64]),
     "omc_mlp_train_epoch": (C.c_int, [_P, _P, _I64, _I64, _I, _I, _P, _P, _P, C.POINTER(C.c_int64)]
                             + [_D] * 6 + [_U64, _U64, C.POINTER(C.c_double)]),
+    "omc_mlp_train_batch_supported": (C.c_int, [_I, _I, _I64]),
+    "omc_mlp_train_epoch_batch": (C.c_int, [_P, C.POINTER(MlpJob), _I, _I, _I] + [_D] * 5),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
     "omc_lsm_apply_mlp": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _I, _P, _P, _P, _D, _D, _D, _U64,
                                     C.POINTER(Result), _P, _P]),
@@ -478,6 +488,20 @@ class Context:
             int(m_ptr), int(v_ptr), C.byref(st), float(lr), float(beta1), float(beta2), float(eps),
             float(weight_decay), float(dropout), int(seed), int(shuffle_key), C.byref(loss)))
         return loss.value, st.value
+
+    def mlp_train_epoch_batch(self, jobs, hidden, layers, dropout, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5):
+        """One epoch for every network of `jobs` (list of dicts: data_ptr, n_rows, batch, params_ptr, m_ptr, v_ptr,
+        step, lr, seed, shuffle_key), all of shape hidden x layers, side by side -> [(mean_loss, new_step), ...]."""
+        n = len(jobs)
+        arr = (MlpJob * n)()
+        for a, j in zip(arr, jobs):
+            a.data, a.n_rows, a.batch = int(j["data_ptr"]), int(j["n_rows"]), int(j["batch"])
+            a.params, a.adam_m, a.adam_v = int(j["params_ptr"]), int(j["m_ptr"]), int(j["v_ptr"])
+            a.step, a.lr = int(j["step"]), float(j["lr"])
+            a.seed, a.shuffle_key = int(j["seed"]) & (2**64 - 1), int(j["shuffle_key"]) & (2**64 - 1)
+        _check(self.lib, self.lib.omc_mlp_train_epoch_batch(self.handle, arr, n, int(hidden), int(layers), float(beta1),
+                                                            float(beta2), float(eps), float(weight_decay), float(dropout)))
+        return [(a.mean_loss, a.step) for a in arr]
 
     def lsm_apply_mlp(self, S_ptr, ld, n_paths, n_steps, K, r, T, is_put, params_ptr, feat_mean, feat_std,
                       y_mean, y_std, dropout, seed, want_state=False, hidden=64, layers=2):

@@ -97,6 +97,10 @@ struct omc_ctx {
     int seq_event_stride = 0;
     // omc_price_american_seq, per-step flows: K pricings advanced by one launch per time step
     DevBuf mS, mstate, mtable;
+    DevBuf mb_slab, mb_table, mb_bc;      // omc_mlp_train_epoch_batch: per-problem scratch, table, 1 - beta^step tables
+    std::vector<double> mb_bc_host;       // [2][cap]: bc1 then bc2
+    double mb_beta1 = -1.0, mb_beta2 = -1.0;
+    size_t mb_bc_cap = 0;
     char* mtab_pin = nullptr;  // pinned upload ring for the argument tables (one image per batch of K)
     int mtab_slot = 0;
     int seq_step_k = -1;       // -1: default (what fits the Infinity Cache, <= 16), 1: off, k: at most k pricings per launch
@@ -506,7 +510,7 @@ int omc_ctx_destroy(omc_ctx* c)
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->persist_scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc,
                       &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
-                      &c->mS, &c->mstate, &c->mtable})
+                      &c->mS, &c->mstate, &c->mtable, &c->mb_slab, &c->mb_table, &c->mb_bc})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
     if (c->mtab_pin) (void)hipHostFree(c->mtab_pin);
@@ -1801,6 +1805,82 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
     const int64_t nb = (n_rows + batch - 1) / batch;
     *step += nb;
     *mean_loss = acc / (double)nb;
+    return 0;
+}
+
+int omc_mlp_train_batch_supported(int hidden, int layers, int64_t batch)
+{
+    return omc::mlp_batch_supported(hidden, layers, batch) ? 1 : 0;
+}
+
+int omc_mlp_train_epoch_batch(omc_ctx* c, omc_mlp_job* jobs, int n, int hidden, int layers, double beta1, double beta2,
+                              double eps, double weight_decay, double dropout)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!jobs || n <= 0) return fail(-7, "empty batch.");
+    if (n > 65535) return fail(-3, "batch too large (max 65535 networks per call).");
+    if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
+    int64_t max_steps = 0, max_batch = 0, last_step = 0;
+    for (int i = 0; i < n; ++i) {
+        const omc_mlp_job& j = jobs[i];
+        if (!j.data || !j.params || !j.adam_m || !j.adam_v) return fail(-7, "null pointer.");
+        if (j.n_rows <= 0 || j.batch <= 0 || j.step < 0) return fail(-3, "n_rows, batch must be positive.");
+        if (!(j.lr > 0.0)) return fail(-4, "learning rate must be positive.");
+        if (!omc::mlp_batch_supported(hidden, layers, j.batch))
+            return fail(-9, "the batched trainer covers the one-tile-per-workgroup shapes (64 | 128 units x 2 | 3 layers at "
+                            "minibatches of at most 8192 rows, 32 x 2).");
+        const int64_t nb = (j.n_rows + j.batch - 1) / j.batch;
+        if (nb > max_steps) max_steps = nb;
+        if (j.batch > max_batch) max_batch = j.batch;
+        if (j.step + nb > last_step) last_step = j.step + nb;
+    }
+    if (max_steps > 0x7fffffff) return fail(-3, "too many steps per epoch.");
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t pb = up(omc::mlp_partial_bytes(hidden, layers, max_batch)), wb = up(omc::mlp_wt_bytes(hidden, layers) + 16);
+    const size_t lb = up(sizeof(double) * (size_t)n);
+    if ((rc = c->mb_slab.ensure(lb + (pb + wb) * (size_t)n))) return rc;
+    if ((rc = c->mb_table.ensure(omc::mlp_batch_table_bytes(n)))) return rc;
+    // 1 - beta^step for every step this epoch can reach (host libm pow: the numbers the single-problem path uses)
+    if (c->mb_beta1 != beta1 || c->mb_beta2 != beta2 || c->mb_bc_cap < (size_t)last_step + 2) {
+        const size_t cap = ((size_t)last_step + 2) * 2 + 1024;
+        c->mb_bc_host.assign(2 * cap, 0.0);
+        for (size_t k = 0; k < cap; ++k) {
+            c->mb_bc_host[k] = 1.0 - std::pow(beta1, (double)k);
+            c->mb_bc_host[cap + k] = 1.0 - std::pow(beta2, (double)k);
+        }
+        if ((rc = c->mb_bc.ensure(sizeof(double) * 2 * cap))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->mb_bc.p, c->mb_bc_host.data(), sizeof(double) * 2 * cap, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->mb_bc_cap = cap; c->mb_beta1 = beta1; c->mb_beta2 = beta2;
+    }
+    char* slab = (char*)c->mb_slab.p;
+    double* loss = (double*)slab;
+    std::vector<omc::MlpBatchJob> hj((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        omc::MlpBatchJob& b = hj[(size_t)i];
+        b.data = jobs[i].data; b.nrows = jobs[i].n_rows; b.batch = jobs[i].batch; b.first_step = jobs[i].step;
+        b.params = jobs[i].params; b.adam_m = jobs[i].adam_m; b.adam_v = jobs[i].adam_v;
+        b.partial = (float*)(slab + lb + (pb + wb) * (size_t)i);
+        b.wt = (float*)(slab + lb + (pb + wb) * (size_t)i + pb);
+        b.loss_acc = loss + i;
+        b.lr = jobs[i].lr; b.seed = jobs[i].seed; b.shuffle_key = jobs[i].shuffle_key;
+    }
+    c->h_table.resize(omc::mlp_batch_table_bytes(n));
+    omc::mlp_batch_table_image(hj.data(), n, hidden, layers, beta1, beta2, eps, weight_decay, dropout, c->h_table.data());
+    HIP_TRY(hipMemcpyAsync(c->mb_table.p, c->h_table.data(), c->h_table.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(loss, 0, sizeof(double) * (size_t)n, c->stream));
+    const int max_tiles = (int)((max_batch + 31) / 32);
+    HIP_TRY(omc::mlp_train_epoch_batch(c->stream, c->mb_table.p, n, hidden, layers, max_steps, max_tiles,
+                                       (const double*)c->mb_bc.p, (const double*)c->mb_bc.p + c->mb_bc_cap));
+    c->h_bres.resize((size_t)n);
+    HIP_TRY(hipMemcpyAsync(c->h_bres.data(), loss, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) {
+        const int64_t nb = (jobs[i].n_rows + jobs[i].batch - 1) / jobs[i].batch;
+        jobs[i].step += nb;
+        jobs[i].mean_loss = c->h_bres[(size_t)i] / (double)nb;
+    }
     return 0;
 }
 

@@ -160,6 +160,23 @@ struct MlpTrainPlan {
     uint64_t shuffle_key;  // 0: rows in storage order; else a keyed pseudo-random permutation
     bool wt_current = false;  // `wt` already mirrors `params` (the Adam kernel of an earlier call kept it so)
 };
+// many small networks of one shape trained side by side: ONE launch pair per optimizer step for all of them (the
+// curve entry points train one net per curve point).  Table rows are built on the host (mlp_batch_table_image) and
+// live in device memory; bc1 / bc2 are device tables of 1 - beta^step (host libm pow, as the single path uses).
+struct MlpBatchJob {
+    const float* data;
+    int64_t nrows, batch, first_step;
+    float *params, *adam_m, *adam_v, *partial, *wt;
+    double* loss_acc;
+    double lr;
+    uint64_t seed, shuffle_key;
+};
+size_t mlp_batch_table_bytes(int n);
+bool mlp_batch_supported(int hidden, int layers, int64_t batch);
+void mlp_batch_table_image(const MlpBatchJob* jobs, int n, int hidden, int layers, double beta1, double beta2, double eps,
+                           double weight_decay, double dropout, void* out);
+hipError_t mlp_train_epoch_batch(hipStream_t st, const void* table_dev, int n, int hidden, int layers, int64_t max_steps,
+                                 int max_tiles, const double* bc1_dev, const double* bc2_dev);
 size_t mlp_partial_bytes(int hidden, int layers, int64_t batch);
 size_t mlp_wt_bytes(int hidden, int layers);
 int mlp_train_param_count(int hidden, int layers);               // -1: shape not covered by a trainer

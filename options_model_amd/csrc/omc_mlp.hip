@@ -20,6 +20,7 @@
 #include "omc_device.h"
 #include "omc_kernels.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace omc {
 
@@ -463,7 +464,7 @@ struct MlpAdamArgs {
 // 16 parameters per workgroup, 16 threads per parameter: thread (slice, j) sums partials
 // slice, slice + 16, ... of parameter j (independent loads, all in flight together), the 16 slice
 // sums are added in slice order through LDS, thread (0, j) applies Adam.
-__global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a)
+__device__ __forceinline__ void mlp_adam_body(const MlpAdamArgs& a)
 {
     __shared__ float red[16][17];
     const int j = threadIdx.x & 15, slice = threadIdx.x >> 4;
@@ -503,6 +504,8 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a)
         }
     }
 }
+
+__global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a) { mlp_adam_body(a); }
 
 // ------------------------------------------------------------------ feature statistics
 // Means and population variances of the six non-constant regression features
@@ -988,7 +991,7 @@ __device__ __forceinline__ void relu_dropout_1(v16f& z, uint32_t row, uint32_t s
 }
 
 template <int H, int L>
-__global__ __launch_bounds__(H * 2) void mlp_train_quad_kernel(MlpQuadArgs a)
+__device__ __forceinline__ void mlp_train_quad_body(const MlpQuadArgs& a)
 {
     constexpr int W = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H;
     __shared__ float sAct[L][H * 32];  // H_j, swizzled [unit][32 rows]
@@ -1206,6 +1209,99 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_kernel(MlpQuadArgs a)
             out[NP - 1] = gbo;
             out[NP] = loss;
         }
+    }
+}
+
+template <int H, int L>
+__global__ __launch_bounds__(H * 2) void mlp_train_quad_kernel(MlpQuadArgs a)
+{
+    mlp_train_quad_body<H, L>(a);
+}
+
+// ---- many small networks trained side by side (the curve entry points: one net per curve point) ----------------
+// One table row per problem; blockIdx.y = problem, the step index within the epoch is a kernel argument.  A
+// workgroup builds its problem's argument block exactly as quad_steps() does on the host (same float conversions:
+// the IEEE double division / square root on the device round like the host's) and runs the single-problem body,
+// so every network ends the epoch with the bits of its own omc_mlp_train_epoch call.  Problems whose epoch is
+// shorter leave at once.
+struct MlpBatchProb {
+    const float* data;
+    float* params;
+    float* m;
+    float* v;
+    float* partial;
+    float* wt;
+    double* loss_acc;
+    int64_t nrows, batch, first_step;
+    double lr, beta1, beta2, eps, wd;
+    Shuffle shuf;
+    uint32_t keep16, k0, k1;
+    float inv_keep;
+    int pstride, pad;
+};
+
+template <int H, int L>
+__global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBatchProb* __restrict__ tab, int s)
+{
+    const MlpBatchProb& p = tab[blockIdx.y];
+    const int64_t o = (int64_t)s * p.batch;
+    if (o >= p.nrows) return;
+    const int64_t nb = (p.nrows - o < p.batch) ? p.nrows - o : p.batch;
+    MlpQuadArgs a;
+    a.data = p.data;
+    a.params = p.params;
+    a.wt = p.wt;
+    a.partial = p.partial;
+    a.row0 = o;
+    a.nrows = nb;
+    a.shuf = p.shuf;
+    a.ntiles = (int)((nb + 31) / 32);
+    a.pstride = p.pstride;
+    a.two_over_b = (float)(2.0 / (double)nb);
+    a.keep16 = p.keep16;
+    a.inv_keep = p.inv_keep;
+    a.step = (uint32_t)(p.first_step + s + 1);
+    a.k0 = p.k0;
+    a.k1 = p.k1;
+    mlp_train_quad_body<H, L>(a);
+}
+
+// bc1 / bc2: 1 - beta^step for step = 0 .. (host-computed tables: libm pow, as quad_steps uses)
+__global__ __launch_bounds__(256) void mlp_adam_batch_kernel(const MlpBatchProb* __restrict__ tab, int s, int H, int L,
+                                                            const double* __restrict__ bc1, const double* __restrict__ bc2)
+{
+    const MlpBatchProb& p = tab[blockIdx.y];
+    const int64_t o = (int64_t)s * p.batch;
+    if (o >= p.nrows) return;
+    const int64_t nb = (p.nrows - o < p.batch) ? p.nrows - o : p.batch;
+    const int64_t step = p.first_step + s + 1;
+    MlpAdamArgs b;
+    b.params = p.params;
+    b.m = p.m;
+    b.v = p.v;
+    b.partial = p.partial;
+    b.loss_acc = p.loss_acc;
+    b.nparts = (int)((nb + 31) / 32);
+    b.nparams = mlp_params_of(H, L);
+    b.stride = p.pstride;
+    b.wt = p.wt; b.H = H; b.L = L;
+    b.inv_b = (float)(1.0 / (double)nb);
+    b.lr_t = (float)(p.lr / bc1[step]);
+    b.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2[step]));
+    b.beta1 = (float)p.beta1;
+    b.beta2 = (float)p.beta2;
+    b.eps = (float)p.eps;
+    b.wd = (float)p.wd;
+    mlp_adam_body(b);
+}
+
+__global__ __launch_bounds__(256) void mlp_transpose_batch_kernel(const MlpBatchProb* __restrict__ tab, int H, int L)
+{
+    const MlpBatchProb& p = tab[blockIdx.y];
+    const int n = (L - 1) * H * H;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int j = i / (H * H), rem = i - j * H * H, k = rem / H, u = rem - k * H;
+        p.wt[i] = p.params[H * 8 + (size_t)j * (H * H + H) + (size_t)u * H + k];
     }
 }
 
@@ -1717,6 +1813,60 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         if (t.hidden == 64) return t.layers == 2 ? quad_steps<64, 2>(st, t) : quad_steps<64, 3>(st, t);
         return t.layers == 2 ? quad_steps<128, 2>(st, t) : quad_steps<128, 3>(st, t);
     }
+    return hipErrorInvalidValue;
+}
+
+// ---- batched training: one launch pair per step for ALL problems of a batch (mlp_train_quad_batch_kernel)
+size_t mlp_batch_table_bytes(int n) { return sizeof(MlpBatchProb) * (size_t)n; }
+
+bool mlp_batch_supported(int hidden, int layers, int64_t batch)
+{
+    return mlp_train_kernel_choice(hidden, layers, batch) == 3;  // the one-tile-per-workgroup trainer
+}
+
+void mlp_batch_table_image(const MlpBatchJob* jobs, int n, int hidden, int layers, double beta1, double beta2, double eps,
+                           double weight_decay, double dropout, void* out)
+{
+    MlpBatchProb* tab = (MlpBatchProb*)out;
+    for (int i = 0; i < n; ++i) {
+        const MlpBatchJob& j = jobs[i];
+        MlpBatchProb& p = tab[i];
+        memset(&p, 0, sizeof p);
+        p.data = j.data; p.params = j.params; p.m = j.adam_m; p.v = j.adam_v; p.partial = j.partial; p.wt = j.wt;
+        p.loss_acc = j.loss_acc;
+        p.nrows = j.nrows; p.batch = j.batch; p.first_step = j.first_step;
+        p.lr = j.lr; p.beta1 = beta1; p.beta2 = beta2; p.eps = eps; p.wd = weight_decay;
+        p.shuf = make_shuffle(j.nrows, j.shuffle_key);
+        p.keep16 = dropout > 0.0 ? (uint32_t)llround((1.0 - dropout) * 65536.0) : 65536u;
+        p.inv_keep = p.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)p.keep16);
+        p.k0 = (uint32_t)j.seed;
+        p.k1 = (uint32_t)(j.seed >> 32);
+        p.pstride = hidden == 32 ? tile_pstride(32, 2) : (hidden == 64 ? tile_pstride(64, layers) : tile_pstride(128, layers));
+    }
+}
+
+template <int H, int L>
+static hipError_t batch_epoch(hipStream_t st, const MlpBatchProb* tab, int n, int64_t max_steps, int max_tiles,
+                              const double* bc1, const double* bc2)
+{
+    hipLaunchKernelGGL(mlp_transpose_batch_kernel, dim3(16, n), dim3(256), 0, st, tab, H, L);
+    const dim3 gq((unsigned)max_tiles, (unsigned)n), ga((unsigned)((mlp_params_of(H, L) + 16) / 16), (unsigned)n);
+    for (int64_t s = 0; s < max_steps; ++s) {
+        hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L>), gq, dim3(H * 2), 0, st, tab, (int)s);
+        hipLaunchKernelGGL(mlp_adam_batch_kernel, ga, dim3(256), 0, st, tab, (int)s, H, L, bc1, bc2);
+    }
+    return hipGetLastError();
+}
+
+hipError_t mlp_train_epoch_batch(hipStream_t st, const void* table_dev, int n, int hidden, int layers, int64_t max_steps,
+                                 int max_tiles, const double* bc1_dev, const double* bc2_dev)
+{
+    const MlpBatchProb* tab = (const MlpBatchProb*)table_dev;
+    if (hidden == 32 && layers == 2) return batch_epoch<32, 2>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev);
+    if (hidden == 64) return layers == 2 ? batch_epoch<64, 2>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev)
+                                         : batch_epoch<64, 3>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev);
+    if (hidden == 128) return layers == 2 ? batch_epoch<128, 2>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev)
+                                          : batch_epoch<128, 3>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev);
     return hipErrorInvalidValue;
 }
 

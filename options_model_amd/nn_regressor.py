@@ -324,6 +324,11 @@ class EpochControl:
         return False, self.bad >= self.stop_patience
 
 
+def _epoch_key(seed, epoch):
+    """The keyed permutation of an epoch (stands for the reference's DataLoader shuffle, :575)."""
+    return (seed ^ (0x9E3779B97F4A7C15 * (epoch + 1))) % (1 << 64) or 1
+
+
 def _train_fused(net, data, epochs, lr, bs, verbose):
     """The epoch loop of :565-613 around omc_mlp_train_epoch (hand-written MFMA forward/backward +
     Adam kernels); shuffling, the plateau scheduler and early stopping stay on the host side."""
@@ -345,7 +350,7 @@ def _train_fused(net, data, epochs, lr, bs, verbose):
         # the epoch's shuffle (:575 randperm) is a keyed permutation evaluated inside the kernel
         avg, step = ctx.mlp_train_epoch(data.data_ptr(), R, bs, params.data_ptr(), m.data_ptr(), v.data_ptr(),
                                         step, ctl.lr, p_drop, seed,
-                                        hidden=_linear_shape(net)[0], layers=_linear_shape(net)[1], shuffle_key=(seed ^ (0x9E3779B97F4A7C15 * (epoch + 1))) % (1 << 64) or 1)
+                                        hidden=_linear_shape(net)[0], layers=_linear_shape(net)[1], shuffle_key=_epoch_key(seed, epoch))
         t_kernels += time.perf_counter() - t1
         keep, stop = ctl.step(avg)
         if keep:
@@ -484,7 +489,7 @@ def pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, path_chunk=
     return cf, exercised
 
 
-def pass2_fused(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, want_state=False):
+def pass2_fused(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, want_state=False, seed=None):
     """:615-651 by the library's kernel (omc_lsm_apply_mlp): the same sticky sweep, the network
     evaluated by float32 MFMA per 32-path tile, dropout bits from Philox-seeded streams."""
     torch = _torch()
@@ -493,7 +498,8 @@ def pass2_fused(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=True, want_
     ctx = _ctx_on_torch_stream(dev.index or 0)
     H, L = _linear_shape(net)
     params = flatten_params(net)
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     torch.cuda.current_stream(dev).synchronize()
     out = ctx.lsm_apply_mlp(S.data_ptr(), S.stride(0), M, N, K, r, T, is_put, params.data_ptr(),
                             fm.cpu().numpy(), fs.cpu().numpy(), float(ym), float(ysd),
@@ -560,6 +566,87 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
                 Y_mean=float(ym), Y_std=float(ysd), seconds_collect=t_c - t0, seconds_normalise=t1 - t_c,
                 seconds_train=t2 - t1, seconds_pass2=t3 - t2, net=net, feat_mean=fm, feat_std=fs)
     return info
+
+
+def price_curve_nn(pricer, jobs, chunk=256):
+    """Many pricings of AdvancedOptionPricer(regressor='nn') -- the points of a value-vs-expiry curve
+    (compute_curve_for_S0, options_model_3.py:697-713) -- with their networks TRAINED SIDE BY SIDE: training is
+    97 % of such a pricing and one network at the reference's minibatch of 256 rows occupies 8 of the chip's 256 CUs,
+    so every optimizer step of up to `chunk` points goes in one launch pair (omc_mlp_train_epoch_batch).  Paths, rows,
+    network initialisation and pass 2 run per point as in price_two_pass_nn; each point draws from torch's generator
+    exactly what its own call draws (manual_seed -> net init -> two seeds), keeps its own learning-rate schedule and
+    early stopping (EpochControl) -- the result of every point equals its single call, bit for bit.
+    jobs: [(S0, T, M, N, path_seed, torch_seed)] -> [result dict]."""
+    torch = _torch()
+    dev = torch.device("cuda", pricer.device)
+    is_put = pricer.option_type == "put"
+    K, r = pricer.K, pricer.r
+    results = [None] * len(jobs)
+    with torch.cuda.device(dev):
+        ctx = _ctx_on_torch_stream(pricer.device)
+        for lo in range(0, len(jobs), chunk):
+            probs = []
+            for idx in range(lo, min(lo + chunk, len(jobs))):
+                S0, T, M, N, path_seed, torch_seed = jobs[idx]
+                S = torch.empty((N + 1, M), dtype=torch.float32, device=dev)
+                generate_paths(ctx, S, pricer._model_kw(), S0, r, pricer.sigma or 0.0, T, path_seed)
+                torch.manual_seed(int(torch_seed))  # :455
+                net = make_net(7, pricer.nn_hidden, pricer.nn_layers, pricer.nn_dropout).to(dev)
+                built = build_rows_fused(S, K, r, T, is_put)
+                bs = pick_batch(built[0].shape[0], None) if built is not None else 0
+                H, L = _linear_shape(net)
+                if built is None or not fused_trainer_supports(net, bs) or not _batch_trainer_supports(H, L, bs):
+                    # nothing in the money, or a shape the side-by-side trainer does not cover: the single path
+                    del S, net, built
+                    out = price_two_pass_nn(pricer, S0, T, M, N, path_seed, torch_seed)
+                    results[idx] = out
+                    continue
+                data, fm, fs, ym, ysd = built
+                params = flatten_params(net)
+                p = dict(idx=idx, S=S, T=T, N=N, M=M, net=net, data=data, fm=fm, fs=fs, ym=ym, ysd=ysd, bs=bs,
+                         params=params, m=torch.zeros_like(params), v=torch.zeros_like(params), step=0,
+                         seed=int(torch.randint(0, 2 ** 62, (1,)).item()),        # _train_fused's draw
+                         seed2=int(torch.randint(0, 2 ** 62, (1,)).item()),       # pass2_fused's draw
+                         ctl=EpochControl(pricer.nn_lr), best=None, done=False, epochs_run=0)
+                probs.append(p)
+            if not probs:
+                continue
+            H, L = _linear_shape(probs[0]["net"])
+            p_drop = _dropout_of(probs[0]["net"])
+            torch.cuda.current_stream(dev).synchronize()  # every training matrix is complete
+            for epoch in range(pricer.nn_epochs):
+                act = [p for p in probs if not p["done"]]
+                if not act:
+                    break
+                outs = ctx.mlp_train_epoch_batch(
+                    [dict(data_ptr=p["data"].data_ptr(), n_rows=p["data"].shape[0], batch=p["bs"],
+                          params_ptr=p["params"].data_ptr(), m_ptr=p["m"].data_ptr(), v_ptr=p["v"].data_ptr(),
+                          step=p["step"], lr=p["ctl"].lr, seed=p["seed"], shuffle_key=_epoch_key(p["seed"], epoch))
+                     for p in act], H, L, p_drop)
+                for p, (avg, step) in zip(act, outs):
+                    p["step"], p["epochs_run"] = step, epoch + 1
+                    keep, stop = p["ctl"].step(avg)
+                    if keep:
+                        p["best"] = p["params"].clone()
+                    elif stop:
+                        p["done"] = True
+            for p in probs:
+                unflatten_params(p["net"], p["best"] if p["best"] is not None else p["params"])
+                res = pass2_fused(p["S"], K, r, p["T"], is_put, p["net"], p["fm"], p["fs"], p["ym"], p["ysd"],
+                                  dropout_on=True, seed=p["seed2"])
+                R = p["data"].shape[0]
+                res.update(stderr=res["std"] / math.sqrt(p["M"]), R=R, n_paths=p["M"], Y_mean=float(p["ym"]),
+                           Y_std=float(p["ysd"]), batch=p["bs"], optimizer_steps=p["step"], epochs_run=p["epochs_run"],
+                           best_loss=p["ctl"].best_loss, best_epoch=p["ctl"].best_epoch, final_lr=p["ctl"].lr,
+                           graphed=False, trainer="hip", rows="hip", batched_with=len(probs))
+                results[p["idx"]] = res
+            del probs
+    return results
+
+
+def _batch_trainer_supports(H, L, bs):
+    """The side-by-side trainer is the one-tile-per-workgroup kernel: which (shape, minibatch) it covers."""
+    return bool(_ffi.load_library().omc_mlp_train_batch_supported(int(H), int(L), int(bs)))
 
 
 def price_two_pass_nn(pricer, S0, T, M, N, path_seed, torch_seed):

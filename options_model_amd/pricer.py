@@ -266,15 +266,16 @@ class AdvancedOptionPricer:
     def compute_curve_for_S0(self, S0: float, intervals_per_day: int, total_points: int,
                              num_simulations: int, plot_paths: bool) -> List[Dict[str, Any]]:
         """options_model_3.py:697-713.  The points of a curve are independent pricings, so they
-        run as ONE batched set of launches (omc_price_american_batch); child seeds are drawn in
-        exactly the order the sequential loop would draw them, so the result equals calling
-        price_american_option point by point."""
+        run as ONE batched set of launches (polynomial regressor: omc_price_american_batch; network
+        regressor, the default: one net per point, trained side by side -- omc_mlp_train_epoch_batch);
+        child seeds are drawn in exactly the order the sequential loop would draw them, so the result
+        equals calling price_american_option point by point."""
         points = []
         for i in range(total_points, 0, -1):
             d = i / intervals_per_day
             points.append((d, d / 365, max(10, min(130, int(math.ceil(d))))))
-        batchable = (self.regressor == "poly" and self.iv_model is None
-                     and not (self.use_streaming and self.european_approximation))
+        batchable = (self.iv_model is None and not (self.use_streaming and self.european_approximation)
+                     and (self.regressor == "poly" or os.environ.get("OMC_NN_CURVE_BATCH", "1") != "0"))
         if not batchable:
             return [{"S0": S0, "Days to Expiry": d,
                      "Option Value": self.price_american_option(S0, T, num_simulations, steps, plot_paths)}
@@ -291,10 +292,11 @@ class AdvancedOptionPricer:
         if M == 0:
             raise ValueError("num_simulations and num_time_steps must be positive integers.")
         n_chunks = max(1, -(-int(num_simulations) // int(self.chunk_size)))
-        lsm_params, eur_params = [], []
+        lsm_params, eur_params, nn_seeds = [], [], []
         for d, T, steps in points:
             path_seed = self.rng_manager.get_child_seed()
-            self.rng_manager.get_child_seed()  # the reference's torch.manual_seed draw
+            torch_seed = self.rng_manager.get_child_seed()  # the reference's torch.manual_seed draw
+            nn_seeds.append((path_seed, torch_seed))
             lsm_params.append(self._params(S0, T, M, steps, path_seed, self.semantics))
             if with_cv:
                 eseed = [self.rng_manager.get_child_seed() for _ in range(n_chunks)][0]
@@ -302,7 +304,14 @@ class AdvancedOptionPricer:
                                                    n_steps=steps, S0=S0, K=self.K, r=self.r,
                                                    sigma=self.sigma or 0.0, T=T, seed=eseed, stream=1, **kw))
         ctx = self._ctx()
-        lsm = ctx.price_american_batch(lsm_params)
+        if self.regressor == "nn":
+            # the default regressor: one SingleLSMNet per point, all of them trained side by side
+            # (nn_regressor.price_curve_nn); every point equals its own price_american_enhanced_lsm call
+            from . import nn_regressor
+            lsm = nn_regressor.price_curve_nn(self, [(S0, T, M, steps, ps, ts) for (d, T, steps), (ps, ts)
+                                                     in zip(points, nn_seeds)])
+        else:
+            lsm = ctx.price_american_batch(lsm_params)
         eur = ctx.price_european_batch(eur_params) if with_cv else None
         self._calls += len(points)
         records = []
