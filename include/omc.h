@@ -367,6 +367,13 @@ int omc_seq_step_width(omc_ctx* ctx, const omc_params* p, int n);
  * Whole-batch kernel times are reported in res[0]. */
 int omc_price_american_batch(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
 int omc_price_european_batch(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
+/* The same for the regressor the v1 / v2 pricers really run (omc_price_american_contnet: a fresh ContNet per time
+ * step): n pricings, problem index on the grid for the whole chain (regression set -> rows -> fresh net -> nn_epochs
+ * full-batch Adam steps -> continuation values -> decision), the set sizes never leave the device, no host
+ * read-back between the first and the last launch.  nn_seeds[i] keys problem i's nets.  res[i] equals
+ * omc_price_american_contnet(p[i], ..., nn_seeds[i]) bit for bit. */
+int omc_price_american_contnet_batch(omc_ctx* ctx, const omc_params* p, int n, int nn_hidden, int nn_epochs,
+                                     double nn_lr, const uint64_t* nn_seeds, omc_result* res);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,8 @@ SIGNATURES = {
     "omc_seq_step_width": (C.c_int, [_P, C.POINTER(Params), _I]),
     "omc_price_american_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_price_european_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
+    "omc_price_american_contnet_batch": (C.c_int, [_P, C.POINTER(Params), _I, _I, _I, _D, C.POINTER(C.c_uint64),
+                                                   C.POINTER(Result)]),
     "omc_mlp_param_count": (C.c_int, [_I, _I]),
     "omc_mlp_train_supported": (C.c_int, [_I, _I, _I64]),
     "omc_mlp_train_epoch": (C.c_int, [_P, _P, _I64, _I64, _I, _I, _P, _P, _P, C.POINTER(C.c_int64)]
@@ -575,6 +577,25 @@ class Context:
 
     def price_american_batch(self, params_list):
         return self._batch(self.lib.omc_price_american_batch, list(params_list))
+
+    def price_american_contnet_batch(self, params_list, nn_hidden=32, nn_epochs=10, nn_lr=1e-3, nn_seeds=0):
+        """Many pricings with the v1 / v2 regressor (fresh ContNet per step) as one set of launches.
+        nn_seeds: one seed for all, or one per problem."""
+        plist = list(params_list)
+        n = len(plist)
+        seeds = [int(nn_seeds)] * n if isinstance(nn_seeds, (int, np.integer)) else [int(x) for x in nn_seeds]
+        assert len(seeds) == n
+        out = []
+        for lo in range(0, n, self.MAX_BATCH):
+            chunk = plist[lo:lo + self.MAX_BATCH]
+            k = len(chunk)
+            arr = (Params * k)(*chunk)
+            sd = (C.c_uint64 * k)(*[x & (2**64 - 1) for x in seeds[lo:lo + k]])
+            res = (Result * k)()
+            _check(self.lib, self.lib.omc_price_american_contnet_batch(self.handle, arr, k, int(nn_hidden), int(nn_epochs),
+                                                                       float(nn_lr), sd, res))
+            out.extend(r.as_dict() for r in res)
+        return out
 
     def price_european_batch(self, params_list):
         return self._batch(self.lib.omc_price_european_batch, list(params_list))

@@ -47,8 +47,8 @@ def price_american_option(S0, K, T, r, sigma, num_simulations=10000, num_time_st
 def compute_curve_for_S0(S0, K, r, sigma, num_simulations, intervals_per_day, total_points,
                          option_type, lsm_poly_degree, plot_paths, seed, *, regressor=None):
     """Options_model.py:190-211.  All points share `seed` (the reference reseeds per pricing) and are
-    independent: with the polynomial regressor they run as one batched set of launches, with the per-step
-    network as concurrent pricings on a small pool of contexts (_ffi.map_contexts)."""
+    independent: they run as one batched set of launches (omc_price_american_batch for the polynomial regressor,
+    omc_price_american_contnet_batch for the per-step network); every point equals its own pricing call."""
     regressor = resolve(regressor)
     points = []
     for i in range(total_points, 0, -1):
@@ -74,8 +74,8 @@ def compute_curve_for_S0(S0, K, r, sigma, num_simulations, intervals_per_day, to
                                n_paths=M, n_steps=steps, S0=S0, K=K, r=r, sigma=sigma, T=T,
                                seed=int(seed), stream=0) for _, T, steps in points]
     if regressor == "nn":
-        outs = _ffi.map_contexts(lambda ctx, q: ctx.price_american_contnet(q, NN_HIDDEN, NN_EPOCHS, NN_LR, int(seed)),
-                                 params)
+        # one batched set of launches for all points: problem index on the grid, set sizes stay on the device
+        outs = _ffi.default_context().price_american_contnet_batch(params, NN_HIDDEN, NN_EPOCHS, NN_LR, int(seed))
     else:
         outs = _ffi.default_context().price_american_batch(params)
     return [{"S0": S0, "Days to Expiry": d, "Option Value": o["price"], "Std Dev": o["std"],

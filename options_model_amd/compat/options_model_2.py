@@ -82,8 +82,8 @@ class OptionPricer:
 
     def compute_curve_for_S0(self, S0: float, intervals_per_day: int, total_points: int,
                              num_simulations: int, plot_paths: bool) -> List[Dict[str, Any]]:
-        """options_model_2.py:336-355: independent points, every one reseeded with self.seed -> with the
-        polynomial regressor one batched set of launches instead of a loop of pricings."""
+        """options_model_2.py:336-355: independent points, every one reseeded with self.seed -> one batched
+        set of launches instead of a loop of pricings (polynomial regressor and per-step network alike)."""
         points = []
         for i in range(total_points, 0, -1):
             d = i / intervals_per_day
@@ -105,7 +105,10 @@ class OptionPricer:
             raise ValueError("num_simulations and num_time_steps must be positive integers.")
         params = [self._params(S0, T, M, st) for _, T, st in points]
         if self.regressor == "nn":
-            outs = _ffi.map_contexts(lambda ctx, q: self._price(q, ctx), params)
+            if not (1 <= int(self.nn_hidden) <= 128):
+                raise ValueError("nn_hidden must be in 1 .. 128.")
+            outs = _ffi.default_context().price_american_contnet_batch(
+                params, int(self.nn_hidden), int(self.nn_epochs), float(self.nn_lr), int(self.seed))
         else:
             outs = _ffi.default_context().price_american_batch(params)
         self.last_result = outs[-1]

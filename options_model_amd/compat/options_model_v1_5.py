@@ -84,7 +84,8 @@ class OptionPricer:
         if not jobs:
             return []
         if self.regressor == "nn":
-            outs = _ffi.map_contexts(self._run, jobs)
+            outs = _ffi.default_context().price_american_contnet_batch([p for p, _ in jobs], NN_HIDDEN, NN_EPOCHS, NN_LR,
+                                                                       [s for _, s in jobs])
         else:
             outs = _ffi.default_context().price_american_batch([p for p, _ in jobs])
         self.last_result = outs[-1]

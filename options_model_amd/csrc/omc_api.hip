@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -1578,7 +1579,7 @@ static int generator_id(const omc_params* p)
     return 2 + p->heston_scheme;  // 2 reference clamp, 3 full truncation, 4 calibrator scheme
 }
 
-static int run_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res, bool american)
+static int run_batch_group(omc_ctx* c, const omc_params* p, int n, omc_result* res, bool american)
 {
     int rc;
     if ((rc = bind(c))) return rc;
@@ -1634,6 +1635,50 @@ static int run_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res, bo
     return 0;
 }
 
+// A batch launches ONE instantiation of every kernel: 16-byte accesses only if every problem admits them.  A
+// problem's sums depend on that width (it sets the order in which a thread meets its paths), so -- for every
+// problem to return the bits of its own single call whatever else is in the batch -- a mixed batch runs as two
+// groups: the problems that admit 16-byte accesses, and the rest.
+static bool item_vec4(const omc_params& q)
+{
+    const int64_t M = q.n_paths, P = (q.model == OMC_MODEL_GBM && !q.antithetic) ? M : M / 2;
+    return (P % 4) == 0 && (M % 4) == 0;
+}
+
+using GroupRun = std::function<int(const omc_params*, int, omc_result*, const int*)>;
+static int run_grouped(const omc_params* p, int n, omc_result* res, const GroupRun& run)
+{
+    int n4 = 0;
+    for (int i = 0; i < n; ++i) n4 += item_vec4(p[i]) ? 1 : 0;
+    if (n4 == 0 || n4 == n) return run(p, n, res, nullptr);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<omc_params> q;
+        std::vector<int> idx;
+        for (int i = 0; i < n; ++i)
+            if (item_vec4(p[i]) == (pass == 0)) {
+                q.push_back(p[i]);
+                idx.push_back(i);
+            }
+        std::vector<omc_result> r(q.size());
+        const int rc = run(q.data(), (int)q.size(), r.data(), idx.data());
+        if (rc) return rc;
+        for (size_t k = 0; k < idx.size(); ++k) res[idx[k]] = r[k];
+    }
+    // whole-batch times are reported on the first entry of a batch: add the two groups'
+    return 0;
+}
+
+static int run_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res, bool american)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_batch(p, n))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    return run_grouped(p, n, res, [&](const omc_params* q, int m, omc_result* r, const int*) {
+        return run_batch_group(c, q, m, r, american);
+    });
+}
+
 int omc_price_american_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res)
 {
     return run_batch(c, p, n, res, true);
@@ -1642,6 +1687,98 @@ int omc_price_american_batch(omc_ctx* c, const omc_params* p, int n, omc_result*
 int omc_price_european_batch(omc_ctx* c, const omc_params* p, int n, omc_result* res)
 {
     return run_batch(c, p, n, res, false);
+}
+
+static int contnet_batch_group(omc_ctx* c, const omc_params* p, int n, int nn_hidden, int nn_epochs, double nn_lr,
+                               const uint64_t* nn_seeds, omc_result* res)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_batch(p, n))) return rc;
+    if (!res || !nn_seeds) return fail(-7, "null pointer.");
+    if (p[0].semantics != OMC_SEM_REFERENCE)
+        return fail(-4, "the per-step network is the regressor of the reference flow (semantics 0).");
+    if ((rc = check_contnet(c, nn_hidden, nn_epochs, nn_lr))) return rc;
+    const int H = omc::cn_padded_width(nn_hidden);
+    const size_t slab = omc::batch_slab_bytes(p, n, true, false);
+    const size_t slab2 = omc::batch_cn_slab_bytes(p, n, nn_hidden);
+    const size_t nd = omc::batch_discount_doubles(p, n);
+    if ((rc = c->bslab.ensure(slab))) return rc;
+    if ((rc = c->cn_data.ensure(slab2))) return rc;
+    if ((rc = c->btable.ensure(omc::batch_table_bytes(n)))) return rc;
+    if ((rc = c->cn_scratch.ensure(omc::batch_cn_table_bytes(n)))) return rc;
+    if ((rc = c->mb_table.ensure(omc::mlp_batch_table_bytes(n)))) return rc;
+    if ((rc = c->cn_cont.ensure(sizeof(int) * ((size_t)n + 2)))) return rc;  // the trainer's tile prefix sums
+    if ((rc = c->bres.ensure(sizeof(double) * 8 * (size_t)n))) return rc;
+    if ((rc = c->bdisc.ensure(sizeof(double) * (nd ? nd : 1)))) return rc;
+    // Adam's bias corrections 1 - beta^step for the `nn_epochs` steps every net takes (optim.Adam defaults)
+    const double beta1 = 0.9, beta2 = 0.999;
+    if (c->mb_beta1 != beta1 || c->mb_beta2 != beta2 || c->mb_bc_cap < (size_t)nn_epochs + 2) {
+        const size_t cap = (size_t)nn_epochs + 1024;
+        c->mb_bc_host.assign(2 * cap, 0.0);
+        for (size_t k = 0; k < cap; ++k) {
+            c->mb_bc_host[k] = 1.0 - std::pow(beta1, (double)k);
+            c->mb_bc_host[cap + k] = 1.0 - std::pow(beta2, (double)k);
+        }
+        if ((rc = c->mb_bc.ensure(sizeof(double) * 2 * cap))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->mb_bc.p, c->mb_bc_host.data(), sizeof(double) * 2 * cap, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->mb_bc_cap = cap; c->mb_beta1 = beta1; c->mb_beta2 = beta2;
+    }
+    c->h_table.resize(omc::batch_table_bytes(n));
+    c->h_disc.resize(nd ? nd : 1);
+    c->h_bres.resize(8 * (size_t)n);
+    std::vector<char> cn_table(omc::batch_cn_table_bytes(n)), mlp_table(omc::mlp_batch_table_bytes(n));
+    std::vector<omc::MlpBatchJob> jobs((size_t)n);
+    omc::BatchExtents e;
+    omc::batch_build(p, n, true, false, (char*)c->bslab.p, (double*)c->bres.p, (double*)c->bdisc.p, c->h_table.data(),
+                     c->h_disc.data(), &e);
+    int max_cn_blocks = 0;
+    int64_t max_paths = 0;
+    omc::batch_cn_build(p, n, nn_hidden, nn_seeds, nn_lr, (char*)c->cn_data.p, c->h_table.data(), cn_table.data(),
+                        jobs.data(), &max_cn_blocks, &max_paths);
+    omc::mlp_batch_table_image(jobs.data(), n, H, 2, beta1, beta2, 1e-8, 0.0, 0.0, mlp_table.data());
+    HIP_TRY(hipMemcpyAsync(c->btable.p, c->h_table.data(), c->h_table.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->cn_scratch.p, cn_table.data(), cn_table.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->mb_table.p, mlp_table.data(), mlp_table.size(), hipMemcpyHostToDevice, c->stream));
+    if (nd)
+        HIP_TRY(hipMemcpyAsync(c->bdisc.p, c->h_disc.data(), sizeof(double) * nd, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->cn_data.p, 0, sizeof(double) * 8 * (size_t)n, c->stream));  // the problems' headers
+    HIP_TRY(hipStreamSynchronize(c->stream));  // cn_table / mlp_table are local pageable vectors
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(omc::batch_paths(c->stream, c->btable.p, n, e, generator_id(&p[0])));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(omc::batch_contnet(c->stream, c->btable.p, c->cn_scratch.p, c->mb_table.p, n, e, nn_hidden, nn_epochs,
+                               max_cn_blocks, max_paths, (const double*)c->mb_bc.p,
+                               (const double*)c->mb_bc.p + c->mb_bc_cap, (int*)c->cn_cont.p));
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_bres.data(), c->bres.p, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms_a = 0, ms_b = 0;
+    HIP_TRY(hipEventElapsedTime(&ms_a, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms_b, c->ev[1], c->ev[2]));
+    for (int i = 0; i < n; ++i) {
+        memset(&res[i], 0, sizeof res[i]);
+        fill_result(&res[i], c->h_bres.data() + 8 * (size_t)i, p[i].n_paths);
+    }
+    res[0].ms_paths = ms_a;  // whole-batch times on the first entry
+    res[0].ms_lsm = ms_b;
+    res[0].ms_total = ms_a + ms_b;
+    return 0;
+}
+
+int omc_price_american_contnet_batch(omc_ctx* c, const omc_params* p, int n, int nn_hidden, int nn_epochs, double nn_lr,
+                                     const uint64_t* nn_seeds, omc_result* res)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_batch(p, n))) return rc;
+    if (!res || !nn_seeds) return fail(-7, "null pointer.");
+    return run_grouped(p, n, res, [&](const omc_params* q, int m, omc_result* r, const int* idx) {
+        std::vector<uint64_t> sd((size_t)m);
+        for (int k = 0; k < m; ++k) sd[(size_t)k] = nn_seeds[idx ? idx[k] : k];
+        return contnet_batch_group(c, q, m, nn_hidden, nn_epochs, nn_lr, sd.data(), r);
+    });
 }
 
 int omc_mlp_param_count(int hidden, int layers) { return omc::mlp_apply_param_count(hidden, layers); }

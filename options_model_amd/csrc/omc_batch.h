@@ -31,4 +31,14 @@ hipError_t batch_paths(hipStream_t st, const void* table_dev, int n, const Batch
 hipError_t batch_lsm(hipStream_t st, const void* table_dev, int n, const BatchExtents& e, int semantics);
 hipError_t batch_terminal(hipStream_t st, const void* table_dev, int n, const BatchExtents& e, int gen);
 
+// ---- the per-step ContNet flow (the v1 / v2 pricers' regressor) for a whole batch: second slab + two more tables
+struct MlpBatchJob;
+size_t batch_cn_table_bytes(int n);
+size_t batch_cn_slab_bytes(const BatchItem* items, int n, int hidden);
+void batch_cn_build(const BatchItem* items, int n, int hidden, const uint64_t* seeds, double lr, char* slab2,
+                    void* table_host, void* cn_table_host, MlpBatchJob* jobs, int* max_cn_blocks, int64_t* max_paths);
+hipError_t batch_contnet(hipStream_t st, const void* table_dev, const void* cn_table_dev, const void* mlp_table_dev,
+                         int n, const BatchExtents& e, int hidden, int epochs, int max_cn_blocks, int64_t max_paths,
+                         const double* bc1_dev, const double* bc2_dev, int* tile_prefix_dev /* n + 1 ints */);
+
 }  // namespace omc

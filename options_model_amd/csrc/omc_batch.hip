@@ -13,6 +13,7 @@
 
 #include <algorithm>
 
+#include "omc_contnet_dev.h"
 #include "omc_lsm_dev.h"
 #include "omc_paths_dev.h"
 
@@ -102,6 +103,104 @@ __global__ __launch_bounds__(kBlock) void lsm_finalize_batch_kernel(const BatchP
     const BatchProb& p = pr[blockIdx.z];
     lsm_finalize_body(p.fin.part, p.step.gmom, p.result, p.fin_nblk, with_moments ? p.step.N : 0,
                       p.fin.pstride);
+}
+
+// ------------------------------------------------------------------ batched per-step ContNet flow
+// The regressor the reference's v1 / v2 pricers really use (a fresh ContNet per time step, omc_contnet.hip) for
+// MANY pricings at once: what their curve entry points run (Options_model.py:190-211, options_model_2.py:336-355:
+// 1,620 pricings of 10k paths for the UI's default job).  Problem index on the grid for every kernel of the chain;
+// the size of a step's regression set never leaves the device (the trainer's launches are sized for the largest
+// problem and its workgroups read the set size from the step's header; surplus workgroups exit), so a whole batch
+// runs without a single host read-back between its first and its last launch.  Bodies are the single-pricing ones:
+// every problem ends with the bits of its own omc_price_american_contnet call.
+struct CnProb {
+    int32_t* cnt;
+    double* s1;
+    double* s2;
+    int64_t* offs;
+    double* hdr;   // n, mean, 1/std, std of the current step's set; [4] = running sum of the set sizes
+    float* data;   // [M][8] trainer rows (capacity: every path)
+    float* cont;   // [M]
+    float* params; // padded net: params | m | v
+    float* m;
+    float* v;
+    float* wt;     // the hidden-to-hidden connection transposed (the trainer's forward product reads it)
+    int nblk, h, H, np;
+    uint32_t k0, k1;
+};
+
+// false: problem `z` has no work at loop step t (its sweep is shorter, or t is its maturity)
+__device__ __forceinline__ bool cn_args_at(const BatchProb& pr, const CnProb& c, int t, CnArgs* a)
+{
+    const StepArgs& s = pr.step;
+    if (t < 1 || t >= s.N) return false;
+    a->St = s.S + (int64_t)t * s.ld;
+    a->SN = s.S + (int64_t)s.N * s.ld;
+    a->ex = s.ex;
+    a->M = s.M;
+    a->K = s.K;
+    a->Dt = s.D[s.N - t];
+    a->is_put = s.is_put;
+    a->nblk = c.nblk;
+    a->cnt = c.cnt; a->s1 = c.s1; a->s2 = c.s2; a->offs = c.offs; a->hdr = c.hdr; a->data = c.data; a->cont = c.cont;
+    return true;
+}
+
+__global__ __launch_bounds__(kCnBlock) void cn_count_batch_kernel(const BatchProb* __restrict__ pr,
+                                                                 const CnProb* __restrict__ cp, int t)
+{
+    CnArgs a;
+    if (!cn_args_at(pr[blockIdx.y], cp[blockIdx.y], t, &a) || (int)blockIdx.x >= a.nblk) return;
+    cn_count_body(a);
+}
+
+// one workgroup per problem: scan of the counts -> row offsets and the set's header; then the step's FRESH net
+// (cn_init_one; Adam moments zeroed) together with the transposed copy of its hidden-to-hidden connection
+__global__ __launch_bounds__(1024) void cn_scan_init_batch_kernel(const BatchProb* __restrict__ pr,
+                                                                  const CnProb* __restrict__ cp, int t)
+{
+    const CnProb& c = cp[blockIdx.y];
+    CnArgs a;
+    if (!cn_args_at(pr[blockIdx.y], c, t, &a)) return;
+    cn_scan_body(a);
+    if (threadIdx.x == 0) c.hdr[4] += c.hdr[0];
+    CnInitArgs ia;
+    ia.params = c.params; ia.m = c.m; ia.v = c.v;
+    ia.H = c.H; ia.h = c.h; ia.np = c.np;
+    ia.k0 = c.k0; ia.k1 = c.k1; ia.t = (uint32_t)t;
+    const int H = c.H;
+    for (int i = threadIdx.x; i < c.np; i += 1024) {
+        cn_init_one(ia, i);
+        const int e = i - H * 8;
+        if (e >= 0 && e < H * H) c.wt[(size_t)(e % H) * H + e / H] = c.params[i];
+    }
+}
+
+__global__ __launch_bounds__(kCnBlock) void cn_rows_batch_kernel(const BatchProb* __restrict__ pr,
+                                                                const CnProb* __restrict__ cp, int t)
+{
+    CnArgs a;
+    if (!cn_args_at(pr[blockIdx.y], cp[blockIdx.y], t, &a) || (int)blockIdx.x >= a.nblk) return;
+    cn_rows_body(a);
+}
+
+template <int H>
+__global__ __launch_bounds__(kCnBlock) void cn_forward_batch_kernel(const BatchProb* __restrict__ pr,
+                                                                   const CnProb* __restrict__ cp, int t)
+{
+    const CnProb& c = cp[blockIdx.y];
+    CnFwdArgs fa;
+    if (!cn_args_at(pr[blockIdx.y], c, t, &fa.c) || (int64_t)blockIdx.x * kCnBlock >= fa.c.M) return;
+    fa.params = c.params;
+    fa.h = c.h;
+    cn_forward_body<H>(fa);
+}
+
+// result slot 4 = sum over the steps of the regression-set sizes (the rows the nets were trained on)
+__global__ void cn_total_batch_kernel(const BatchProb* __restrict__ pr, const CnProb* __restrict__ cp, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pr[i].result[4] = cp[i].hdr[4];
 }
 
 // ------------------------------------------------------------------ host side
@@ -316,6 +415,154 @@ hipError_t batch_terminal(hipStream_t st, const void* table_dev, int n, const Ba
     else if (gen == 3) hipLaunchKernelGGL((terminal_batch_kernel<3>), grid, dim3(kBlock), 0, st, pr);
     else hipLaunchKernelGGL((terminal_batch_kernel<4>), grid, dim3(kBlock), 0, st, pr);
     hipLaunchKernelGGL(lsm_finalize_batch_kernel, dim3(1, 1, (unsigned)n), dim3(kBlock), 0, st, pr, 0);
+    return hipGetLastError();
+}
+
+// ---- batched per-step ContNet flow: host side
+size_t batch_cn_table_bytes(int n) { return sizeof(CnProb) * (size_t)n; }
+
+static size_t cn_plan(const BatchItem& it, int H, size_t base, size_t* off /*[11]*/)
+{
+    const int64_t M = it.n_paths;
+    const size_t nb = (size_t)((M + kCnSpan - 1) / kCnSpan);
+    const int np = H * 8 + H * H + H + H + 1;
+    const size_t tiles = (size_t)((M + 31) / 32);
+    const size_t pstride = (size_t)((np + 1 + 63) / 64 * 64);  // the tile trainer's partial stride (omc_mlp.hip)
+    size_t o = align_up(base, 256);
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    off[0] = take(4 * (nb + 2));            // cnt
+    off[1] = take(8 * nb);                  // s1
+    off[2] = take(8 * nb);                  // s2
+    off[3] = take(8 * (nb + 1));            // offs
+    off[4] = take(sizeof(float) * 8 * (size_t)M);  // data
+    off[5] = take(sizeof(float) * (size_t)M);      // cont
+    off[6] = take(sizeof(float) * 3 * (size_t)np); // params | m | v
+    off[7] = take(sizeof(float) * (size_t)H * H);  // wt
+    off[8] = take(sizeof(float) * tiles * pstride); // gradient partials, one per tile
+    return o;
+}
+
+// bytes of the second slab: [n][8] doubles of headers first (cleared before every batch), then per-problem buffers
+size_t batch_cn_slab_bytes(const BatchItem* items, int n, int hidden)
+{
+    const int H = cn_padded_width(hidden);
+    size_t o = align_up(sizeof(double) * 8 * (size_t)n, 256);
+    size_t off[11];
+    for (int i = 0; i < n; ++i) o = cn_plan(items[i], H, o, off);
+    return o;
+}
+
+// Fills the ContNet table and the trainer's job list; patches the problems' step arguments to "values" mode
+// (continuation values come from the problem's `cont` row).  `table_host` is the BatchProb table batch_build made.
+void batch_cn_build(const BatchItem* items, int n, int hidden, const uint64_t* seeds, double lr, char* slab2,
+                    void* table_host, void* cn_table_host, MlpBatchJob* jobs, int* max_cn_blocks, int64_t* max_paths)
+{
+    BatchProb* tab = (BatchProb*)table_host;
+    CnProb* cn = (CnProb*)cn_table_host;
+    const int H = cn_padded_width(hidden);
+    const int np = H * 8 + H * H + H + H + 1;
+    size_t o = align_up(sizeof(double) * 8 * (size_t)n, 256);
+    size_t off[11];
+    *max_cn_blocks = 0;
+    *max_paths = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t end = cn_plan(items[i], H, o, off);
+        CnProb& c = cn[i];
+        c.cnt = (int32_t*)(slab2 + off[0]); c.s1 = (double*)(slab2 + off[1]); c.s2 = (double*)(slab2 + off[2]);
+        c.offs = (int64_t*)(slab2 + off[3]);
+        c.hdr = (double*)slab2 + 8 * (size_t)i;
+        c.data = (float*)(slab2 + off[4]); c.cont = (float*)(slab2 + off[5]);
+        c.params = (float*)(slab2 + off[6]); c.m = c.params + np; c.v = c.params + 2 * (size_t)np;
+        c.wt = (float*)(slab2 + off[7]);
+        c.nblk = (int)((items[i].n_paths + kCnSpan - 1) / kCnSpan);
+        c.h = hidden; c.H = H; c.np = np;
+        c.k0 = (uint32_t)seeds[i]; c.k1 = (uint32_t)(seeds[i] >> 32);
+        tab[i].step.cont = c.cont;
+        tab[i].step.ldc = 0;  // one row, rewritten every step
+        MlpBatchJob& j = jobs[i];
+        j = MlpBatchJob{};
+        j.data = c.data; j.nrows = 0; j.batch = 0; j.first_step = 0;
+        j.params = c.params; j.adam_m = c.m; j.adam_v = c.v;
+        j.partial = (float*)(slab2 + off[8]); j.wt = c.wt;
+        j.loss_acc = c.hdr + 5;  // (unused sum of the steps' losses)
+        j.lr = lr; j.seed = 0; j.shuffle_key = 0;
+        j.nrows_dev = c.hdr;
+        *max_cn_blocks = std::max(*max_cn_blocks, c.nblk);
+        *max_paths = std::max<int64_t>(*max_paths, items[i].n_paths);
+        o = end;
+    }
+}
+
+template <int H>
+static hipError_t cn_forward_batch(hipStream_t st, const BatchProb* pr, const CnProb* cp, int n, int64_t max_paths, int t)
+{
+    constexpr size_t lds = sizeof(float) * (size_t)(H * 8 + H * H + H + H + 1);
+    static std::atomic<uint64_t> attr_mask{0};
+    if (lds > 48 * 1024) {
+        hipError_t e = set_max_dynamic_lds(attr_mask, reinterpret_cast<const void*>(cn_forward_batch_kernel<H>), lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((cn_forward_batch_kernel<H>), dim3((unsigned)((max_paths + kCnBlock - 1) / kCnBlock), (unsigned)n),
+                       dim3(kCnBlock), lds, st, pr, cp, t);
+    return hipGetLastError();
+}
+
+// the whole backward induction of the batch: for every time step the chain count -> scan + fresh net -> rows ->
+// `epochs` full-batch steps -> continuation values -> decision, each ONE launch for all problems
+hipError_t batch_contnet(hipStream_t st, const void* table_dev, const void* cn_table_dev, const void* mlp_table_dev,
+                         int n, const BatchExtents& e, int hidden, int epochs, int max_cn_blocks, int64_t max_paths,
+                         const double* bc1_dev, const double* bc2_dev, int* tile_prefix_dev)
+{
+    const BatchProb* pr = (const BatchProb*)table_dev;
+    const CnProb* cp = (const CnProb*)cn_table_dev;
+    const int H = cn_padded_width(hidden);
+    const unsigned z = (unsigned)n;
+    const int Nmax = e.max_steps;
+    const bool big = lsm_step_block_threads() == 1024;
+    const dim3 gs((unsigned)e.sweep_blocks, 1, z), bs(big ? 1024 : 512);
+    // workgroups per problem in the trainer's launches: enough to fill the chip when the batch is small, few when
+    // the batch itself does (a regression set is mostly a small fraction of the paths: surplus workgroups only exit)
+    // trainer launches: a lone problem gets one workgroup per possible tile; a batch shares a fixed pool of
+    // workgroups over the tiles all its problems really have (work list: sizes differ wildly between problems)
+    const int tiles_max = (int)((max_paths + 31) / 32);
+    const bool listed = n > 1 && tile_prefix_dev != nullptr && H <= 64;  // (the 128-unit instance of the list kernel spills)
+    const int gx = listed ? 4096 : tiles_max;
+    auto step = [&](int t) {
+        if (big) {
+            if (e.vec4) hipLaunchKernelGGL((lsm_step_batch_kernel<0, 4, 1024>), gs, bs, 0, st, pr, t);
+            else hipLaunchKernelGGL((lsm_step_batch_kernel<0, 1, 1024>), gs, bs, 0, st, pr, t);
+        } else {
+            if (e.vec4) hipLaunchKernelGGL((lsm_step_batch_kernel<0, 4, 512>), gs, bs, 0, st, pr, t);
+            else hipLaunchKernelGGL((lsm_step_batch_kernel<0, 1, 512>), gs, bs, 0, st, pr, t);
+        }
+    };
+    for (int t = Nmax; t >= 1; --t) {
+        if (t < Nmax) {  // (at t = Nmax no problem has a regression step: t == N is the initialising launch)
+            const dim3 gc((unsigned)max_cn_blocks, z);
+            hipLaunchKernelGGL(cn_count_batch_kernel, gc, dim3(kCnBlock), 0, st, pr, cp, t);
+            hipLaunchKernelGGL(cn_scan_init_batch_kernel, dim3(1, z), dim3(1024), 0, st, pr, cp, t);
+            hipLaunchKernelGGL(cn_rows_batch_kernel, gc, dim3(kCnBlock), 0, st, pr, cp, t);
+            if (listed) {
+                hipError_t err = mlp_tile_prefix(st, mlp_table_dev, n, tile_prefix_dev);
+                if (err != hipSuccess) return err;
+            }
+            for (int ep = 0; ep < epochs; ++ep) {
+                hipError_t err = mlp_train_step_batch(st, mlp_table_dev, n, H, gx, ep, bc1_dev, bc2_dev,
+                                                      listed ? tile_prefix_dev : nullptr);
+                if (err != hipSuccess) return err;
+            }
+            hipError_t err = H == 32 ? cn_forward_batch<32>(st, pr, cp, n, max_paths, t)
+                           : H == 64 ? cn_forward_batch<64>(st, pr, cp, n, max_paths, t)
+                                     : cn_forward_batch<128>(st, pr, cp, n, max_paths, t);
+            if (err != hipSuccess) return err;
+        }
+        step(t);
+    }
+    const dim3 gf((unsigned)e.block_blocks, 1, z);
+    if (e.vec4) hipLaunchKernelGGL((lsm_final_batch_kernel<4>), gf, dim3(kBlock), 0, st, pr);
+    else hipLaunchKernelGGL((lsm_final_batch_kernel<1>), gf, dim3(kBlock), 0, st, pr);
+    hipLaunchKernelGGL(lsm_finalize_batch_kernel, dim3(1, 1, z), dim3(kBlock), 0, st, pr, 0);
+    hipLaunchKernelGGL(cn_total_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pr, cp, n);
     return hipGetLastError();
 }
 

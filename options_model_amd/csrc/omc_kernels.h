@@ -170,6 +170,7 @@ struct MlpBatchJob {
     double* loss_acc;
     double lr;
     uint64_t seed, shuffle_key;
+    const double* nrows_dev = nullptr;  // non-null: nrows = batch = the double stored there (set size counted on the device)
 };
 size_t mlp_batch_table_bytes(int n);
 bool mlp_batch_supported(int hidden, int layers, int64_t batch);
@@ -177,6 +178,13 @@ void mlp_batch_table_image(const MlpBatchJob* jobs, int n, int hidden, int layer
                            double weight_decay, double dropout, void* out);
 hipError_t mlp_train_epoch_batch(hipStream_t st, const void* table_dev, int n, int hidden, int layers, int64_t max_steps,
                                  int max_tiles, const double* bc1_dev, const double* bc2_dev);
+// one full-batch step for every problem of the table (two hidden layers; the per-step ContNet flow), grid_tiles
+// workgroups per problem walking its tiles
+// tile_prefix_dev != null: work-list launch -- grid_tiles workgroups IN TOTAL share all problems' tiles evenly
+// (prefix sums of the problems' tile counts from mlp_tile_prefix, n + 1 ints, refreshed whenever set sizes change)
+hipError_t mlp_train_step_batch(hipStream_t st, const void* table_dev, int n, int hidden, int grid_tiles, int step_base,
+                                const double* bc1_dev, const double* bc2_dev, const int* tile_prefix_dev = nullptr);
+hipError_t mlp_tile_prefix(hipStream_t st, const void* table_dev, int n, int* prefix_dev);
 size_t mlp_partial_bytes(int hidden, int layers, int64_t batch);
 size_t mlp_wt_bytes(int hidden, int layers);
 int mlp_train_param_count(int hidden, int layers);               // -1: shape not covered by a trainer

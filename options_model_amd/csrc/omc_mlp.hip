@@ -991,7 +991,7 @@ __device__ __forceinline__ void relu_dropout_1(v16f& z, uint32_t row, uint32_t s
 }
 
 template <int H, int L>
-__device__ __forceinline__ void mlp_train_quad_body(const MlpQuadArgs& a)
+__device__ __forceinline__ void mlp_train_quad_body(const MlpQuadArgs& a, const int tile)
 {
     constexpr int W = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H;
     __shared__ float sAct[L][H * 32];  // H_j, swizzled [unit][32 rows]
@@ -1001,7 +1001,6 @@ __device__ __forceinline__ void mlp_train_quad_body(const MlpQuadArgs& a)
     __shared__ float sD[32];           // d(loss)/d(out) per row
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     auto rho = [&](int r) { return (r >> 2) * 8 + 4 * h + (r & 3); };  // tile row of accumulator register r
-    const int tile = blockIdx.x;
     if (tile >= a.ntiles) return;
     float* out = a.partial + (size_t)tile * a.pstride;
     const float* Wo = a.params + H * 8 + (L - 1) * CONN;
@@ -1215,7 +1214,7 @@ __device__ __forceinline__ void mlp_train_quad_body(const MlpQuadArgs& a)
 template <int H, int L>
 __global__ __launch_bounds__(H * 2) void mlp_train_quad_kernel(MlpQuadArgs a)
 {
-    mlp_train_quad_body<H, L>(a);
+    mlp_train_quad_body<H, L>(a, blockIdx.x);
 }
 
 // ---- many small networks trained side by side (the curve entry points: one net per curve point) ----------------
@@ -1238,15 +1237,31 @@ struct MlpBatchProb {
     uint32_t keep16, k0, k1;
     float inv_keep;
     int pstride, pad;
+    // non-null: the set size lives in device memory (the per-step ContNet flow: the regression set of the step,
+    // counted by the kernels right before): nrows = batch = (int64_t)*nrows_dev, read when the kernel runs
+    const double* nrows_dev;
 };
 
+__device__ __forceinline__ void batch_rows(const MlpBatchProb& p, int64_t* nrows, int64_t* batch)
+{
+    if (p.nrows_dev) {
+        *nrows = *batch = (int64_t)*p.nrows_dev;
+    } else {
+        *nrows = p.nrows;
+        *batch = p.batch;
+    }
+}
+
 template <int H, int L>
-__global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBatchProb* __restrict__ tab, int s)
+__global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBatchProb* __restrict__ tab, int s,
+                                                                     int step_base)
 {
     const MlpBatchProb& p = tab[blockIdx.y];
-    const int64_t o = (int64_t)s * p.batch;
-    if (o >= p.nrows) return;
-    const int64_t nb = (p.nrows - o < p.batch) ? p.nrows - o : p.batch;
+    int64_t nrows, batch;
+    batch_rows(p, &nrows, &batch);
+    const int64_t o = (int64_t)s * batch;
+    if (o >= nrows) return;
+    const int64_t nb = (nrows - o < batch) ? nrows - o : batch;
     MlpQuadArgs a;
     a.data = p.data;
     a.params = p.params;
@@ -1260,21 +1275,107 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBa
     a.two_over_b = (float)(2.0 / (double)nb);
     a.keep16 = p.keep16;
     a.inv_keep = p.inv_keep;
-    a.step = (uint32_t)(p.first_step + s + 1);
+    a.step = (uint32_t)(p.first_step + step_base + s + 1);
     a.k0 = p.k0;
     a.k1 = p.k1;
-    mlp_train_quad_body<H, L>(a);
+    mlp_train_quad_body<H, L>(a, blockIdx.x);  // (the grid covers the largest problem's tiles)
+}
+
+// Work-list form of the same launch for batches whose problems differ wildly in size (the per-step ContNet flow of
+// a curve: at any loop step a few problems are at their first regression step with thousands of rows while the rest
+// have a few dozen): `prefix[p]` = tiles of problems 0 .. p-1 (mlp_tile_prefix_kernel, once per time step), the
+// grid's workgroups share the total evenly, each walking a contiguous run of (problem, tile) items.  One partial per
+// tile as before, so nothing changes for the sums.
+__global__ __launch_bounds__(1024) void mlp_tile_prefix_kernel(const MlpBatchProb* __restrict__ tab, int n,
+                                                              int* __restrict__ prefix)
+{
+    __shared__ int seg[1024];
+    const int tid = threadIdx.x;
+    const int len = (n + 1023) / 1024, lo = tid * len, hi = lo + len < n ? lo + len : n;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) {
+        int64_t nrows, batch;
+        batch_rows(tab[i], &nrows, &batch);
+        const int64_t nb = nrows < batch ? nrows : batch;
+        s += (int)((nb + 31) / 32);
+    }
+    seg[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = tid >= d ? seg[tid - d] : 0;
+        __syncthreads();
+        seg[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? seg[tid - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        prefix[i] = run;
+        int64_t nrows, batch;
+        batch_rows(tab[i], &nrows, &batch);
+        const int64_t nb = nrows < batch ? nrows : batch;
+        run += (int)((nb + 31) / 32);
+    }
+    if (tid == 1023) prefix[n] = seg[1023];
+}
+
+template <int H, int L>
+__global__ __launch_bounds__(H * 2) void mlp_train_quad_list_kernel(const MlpBatchProb* __restrict__ tab,
+                                                                    const int* __restrict__ prefix, int n, int step_base)
+{
+    const int total = prefix[n];
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    int item = (int)blockIdx.x * per;
+    const int end = item + per < total ? item + per : total;
+    if (item >= end) return;
+    int lo = 0, hi = n;  // the problem that owns `item`: the last p with prefix[p] <= item
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= item) lo = mid; else hi = mid;
+    }
+    int p = lo;
+    while (item < end) {
+        while (prefix[p + 1] <= item) ++p;  // (problems without tiles are skipped)
+        const MlpBatchProb& pb = tab[p];
+        int64_t nrows, batch;
+        batch_rows(pb, &nrows, &batch);
+        const int64_t nb = nrows < batch ? nrows : batch;
+        MlpQuadArgs a;
+        a.data = pb.data;
+        a.params = pb.params;
+        a.wt = pb.wt;
+        a.partial = pb.partial;
+        a.row0 = 0;
+        a.nrows = nb;
+        a.shuf = pb.shuf;
+        a.ntiles = (int)((nb + 31) / 32);
+        a.pstride = pb.pstride;
+        a.two_over_b = (float)(2.0 / (double)nb);
+        a.keep16 = pb.keep16;
+        a.inv_keep = pb.inv_keep;
+        a.step = (uint32_t)(pb.first_step + step_base + 1);
+        a.k0 = pb.k0;
+        a.k1 = pb.k1;
+        const int first = prefix[p];
+        const int last = prefix[p + 1] < end ? prefix[p + 1] : end;
+        for (; item < last; ++item) {
+            mlp_train_quad_body<H, L>(a, item - first);
+            __syncthreads();
+        }
+    }
 }
 
 // bc1 / bc2: 1 - beta^step for step = 0 .. (host-computed tables: libm pow, as quad_steps uses)
-__global__ __launch_bounds__(256) void mlp_adam_batch_kernel(const MlpBatchProb* __restrict__ tab, int s, int H, int L,
-                                                            const double* __restrict__ bc1, const double* __restrict__ bc2)
+__global__ __launch_bounds__(256) void mlp_adam_batch_kernel(const MlpBatchProb* __restrict__ tab, int s, int step_base,
+                                                            int H, int L, const double* __restrict__ bc1,
+                                                            const double* __restrict__ bc2)
 {
     const MlpBatchProb& p = tab[blockIdx.y];
-    const int64_t o = (int64_t)s * p.batch;
-    if (o >= p.nrows) return;
-    const int64_t nb = (p.nrows - o < p.batch) ? p.nrows - o : p.batch;
-    const int64_t step = p.first_step + s + 1;
+    int64_t nrows, batch;
+    batch_rows(p, &nrows, &batch);
+    const int64_t o = (int64_t)s * batch;
+    if (o >= nrows) return;
+    const int64_t nb = (nrows - o < batch) ? nrows - o : batch;
+    const int64_t step = p.first_step + step_base + s + 1;
     MlpAdamArgs b;
     b.params = p.params;
     b.m = p.m;
@@ -1842,6 +1943,7 @@ void mlp_batch_table_image(const MlpBatchJob* jobs, int n, int hidden, int layer
         p.k0 = (uint32_t)j.seed;
         p.k1 = (uint32_t)(j.seed >> 32);
         p.pstride = hidden == 32 ? tile_pstride(32, 2) : (hidden == 64 ? tile_pstride(64, layers) : tile_pstride(128, layers));
+        p.nrows_dev = j.nrows_dev;
     }
 }
 
@@ -1852,9 +1954,39 @@ static hipError_t batch_epoch(hipStream_t st, const MlpBatchProb* tab, int n, in
     hipLaunchKernelGGL(mlp_transpose_batch_kernel, dim3(16, n), dim3(256), 0, st, tab, H, L);
     const dim3 gq((unsigned)max_tiles, (unsigned)n), ga((unsigned)((mlp_params_of(H, L) + 16) / 16), (unsigned)n);
     for (int64_t s = 0; s < max_steps; ++s) {
-        hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L>), gq, dim3(H * 2), 0, st, tab, (int)s);
-        hipLaunchKernelGGL(mlp_adam_batch_kernel, ga, dim3(256), 0, st, tab, (int)s, H, L, bc1, bc2);
+        hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L>), gq, dim3(H * 2), 0, st, tab, (int)s, 0);
+        hipLaunchKernelGGL(mlp_adam_batch_kernel, ga, dim3(256), 0, st, tab, (int)s, 0, H, L, bc1, bc2);
     }
+    return hipGetLastError();
+}
+
+// ONE full-batch optimizer step (forward / backward + Adam) for every problem of the table: the per-step ContNet
+// flow's "epoch".  `step_base` = optimizer steps the nets have taken so far (Adam's bias correction); the transposed
+// connection copies must be current (the flow's init kernel writes them, Adam keeps them so).
+template <int H, int L>
+static hipError_t batch_one_step(hipStream_t st, const MlpBatchProb* tab, int n, int grid_tiles, int step_base,
+                                 const double* bc1, const double* bc2, const int* prefix)
+{
+    const dim3 gq((unsigned)grid_tiles, (unsigned)n), ga((unsigned)((mlp_params_of(H, L) + 16) / 16), (unsigned)n);
+    if (prefix) hipLaunchKernelGGL((mlp_train_quad_list_kernel<H, L>), dim3((unsigned)grid_tiles), dim3(H * 2), 0, st, tab, prefix, n, step_base);
+    else hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L>), gq, dim3(H * 2), 0, st, tab, 0, step_base);
+    hipLaunchKernelGGL(mlp_adam_batch_kernel, ga, dim3(256), 0, st, tab, 0, step_base, H, L, bc1, bc2);
+    return hipGetLastError();
+}
+
+hipError_t mlp_train_step_batch(hipStream_t st, const void* table_dev, int n, int hidden, int grid_tiles, int step_base,
+                                const double* bc1_dev, const double* bc2_dev, const int* tile_prefix_dev)
+{
+    const MlpBatchProb* tab = (const MlpBatchProb*)table_dev;
+    if (hidden == 32) return batch_one_step<32, 2>(st, tab, n, grid_tiles, step_base, bc1_dev, bc2_dev, tile_prefix_dev);
+    if (hidden == 64) return batch_one_step<64, 2>(st, tab, n, grid_tiles, step_base, bc1_dev, bc2_dev, tile_prefix_dev);
+    if (hidden == 128) return batch_one_step<128, 2>(st, tab, n, grid_tiles, step_base, bc1_dev, bc2_dev, tile_prefix_dev);
+    return hipErrorInvalidValue;
+}
+
+hipError_t mlp_tile_prefix(hipStream_t st, const void* table_dev, int n, int* prefix_dev)
+{
+    hipLaunchKernelGGL(mlp_tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const MlpBatchProb*)table_dev, n, prefix_dev);
     return hipGetLastError();
 }
 

@@ -1,0 +1,93 @@
+"""The v1 / v2 pricers' own regressor (fresh ContNet per time step) for MANY pricings at once
+(omc_price_american_contnet_batch): what Options_model.compute_curve_for_S0 / options_model_2's curve workers run.
+Every pricing of a batch must return the bits of its own omc_price_american_contnet call."""
+import math
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("price", "sum", "sumsq", "n_exercised", "n_zero", "sum_nitm", "n_paths", "std", "zero_prob")
+
+
+def _problems():
+    from options_model_amd import _ffi
+    ps = []
+    for i, (M, N, S0, T, put) in enumerate([(10_000, 50, 100.0, 1.0, True), (10_000, 10, 90.0, 0.03, True),
+                                            (4_000, 37, 110.0, 0.4, False), (20_000, 25, 100.0, 0.5, True),
+                                            (2_048, 130, 95.0, 0.36, True), (10_002, 12, 140.0, 0.1, True),  # never in the money late
+                                            (512, 5, 100.0, 0.02, False)]):
+        ps.append(_ffi.make_params(semantics="reference", n_paths=M, n_steps=N, S0=S0, T=T, is_put=put, seed=42 + i, stream=i))
+    return ps
+
+
+@pytest.mark.parametrize("hidden,epochs", [(32, 10), (16, 3), (64, 4)])
+def test_batch_equals_single_calls_bitwise(ctx, hidden, epochs):
+    ps = _problems()
+    seeds = [7 + 3 * i for i in range(len(ps))]
+    batch = ctx.price_american_contnet_batch(ps, hidden, epochs, 1e-3, seeds)
+    for p, s, b in zip(ps, seeds, batch):
+        one = ctx.price_american_contnet(p, hidden, epochs, 1e-3, s)
+        for k in KEYS:
+            assert b[k] == one[k], (k, b[k], one[k])
+    assert batch[0]["sum_nitm"] > 0 and batch[0]["ms_total"] > 0
+
+
+def test_heston_batch_and_one_seed_for_all(ctx):
+    from options_model_amd import _ffi
+    ps = [_ffi.make_params(model="heston", semantics="reference", n_paths=6000, n_steps=20 + i, S0=100.0 + i, seed=5,
+                           heston_scheme="reference") for i in range(5)]
+    batch = ctx.price_american_contnet_batch(ps, 32, 10, 1e-3, 99)
+    for p, b in zip(ps, batch):
+        one = ctx.price_american_contnet(p, 32, 10, 1e-3, 99)
+        assert (b["price"], b["n_exercised"], b["sum_nitm"]) == (one["price"], one["n_exercised"], one["sum_nitm"])
+
+
+def test_curve_surfaces_use_the_batch_and_keep_their_numbers(ctx, monkeypatch):
+    """compat.Options_model / options_model_2 curves with the default regressor: one batched call, same records as
+    the point-by-point loop."""
+    from options_model_amd.compat import Options_model as v1
+    monkeypatch.delenv("OMC_REGRESSOR", raising=False)
+    recs = v1.compute_curve_for_S0(100.0, 100.0, 0.05, 0.2, 4000, 2, 9, "put", 2, False, 42)
+    assert [r["Days to Expiry"] for r in recs] == [4.5, 4.0, 3.5, 3.0, 2.5, 2.0, 1.5, 1.0, 0.5]
+    for r in recs[:3] + recs[-2:]:
+        d = r["Days to Expiry"]
+        steps = max(10, min(130, int(math.ceil(d))))   # Options_model.py:203
+        mean, std, zp = v1.price_american_option(100.0, 100.0, d / 365.0, 0.05, 0.2, 4000, steps, "put", 2, False, 42)
+        assert (r["Option Value"], r["Std Dev"], r["Zero Prob"]) == (mean, std, zp)
+    from options_model_amd.compat import options_model_2 as v2
+    pr = v2.OptionPricer(100.0, 0.05, 0.2, "put", 2, 42, nn_hidden=16, nn_epochs=5)
+    recs2 = pr.compute_curve_for_S0(100.0, 2, 6, 4000, False)
+    pr2 = v2.OptionPricer(100.0, 0.05, 0.2, "put", 2, 42, nn_hidden=16, nn_epochs=5)
+    for r in recs2:
+        d = r["Days to Expiry"]
+        assert r["Option Value"] == pr2.price_american_option(100.0, d / 365.0, 4000, max(10, min(130, int(math.ceil(d)))))
+
+
+def test_timings_of_the_ui_jobs(ctx):
+    """the UI's single pricing (10k x 50) and its 1,620-point job (9 spots x 180 expiries,
+    10k paths, 10..130 steps) with the default ContNet regressor."""
+    from options_model_amd import _ffi
+    one = [_ffi.make_params(semantics="reference", n_paths=10_000, n_steps=50, seed=42)]
+    ctx.price_american_contnet_batch(one, 32, 10, 1e-3, 42)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.price_american_contnet_batch(one, 32, 10, 1e-3, 42)
+    ms1 = (time.perf_counter() - t0) / 5 * 1e3
+    ps = []
+    for s0 in (80, 85, 90, 95, 100, 105, 110, 115, 120):
+        for i in range(180, 0, -1):
+            d = i / 2.0
+            ps.append(_ffi.make_params(semantics="reference", n_paths=10_000, n_steps=max(10, min(130, int(math.ceil(d)))),
+                                       S0=float(s0), T=d / 365.0, seed=42))
+    ctx.price_american_contnet_batch(ps[:64], 32, 10, 1e-3, 42)
+    t0 = time.perf_counter()
+    out = ctx.price_american_contnet_batch(ps, 32, 10, 1e-3, 42)
+    t_job = time.perf_counter() - t0
+    print(f"ContNet flow: 10k x 50 single pricing {ms1:.2f} ms; 1,620-point UI job {t_job:.3f} s "
+          f"(GPU {out[0]['ms_total']:.1f} ms)")
+    assert len(out) == 1620 and all(o["price"] > 0 for o in out[:180])
+    assert ms1 <= 8.0          # (round 2: 8.4 ms with a host read-back per step; the chain is ~25 dependent launches per time step)
+    assert t_job <= 0.3        # (round 2: ~4 s on 8 host threads)
