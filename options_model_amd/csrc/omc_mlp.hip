@@ -505,6 +505,45 @@ __device__ __forceinline__ void mlp_adam_body(const MlpAdamArgs& a)
     }
 }
 
+// The same update with ONE THREAD per parameter (256 parameters per workgroup): for the batched launches, where a
+// workgroup of mlp_adam_body per 16 parameters and problem means tens of thousands of nearly empty workgroups.  The
+// float additions are those of mlp_adam_body in the same order -- slice sums g_s = partial[s] + partial[s + 16] + ...
+// (from 0), then g_0 + g_1 + ... + g_15 (from 0) -- so the parameters come out bit for bit the same.
+__device__ __forceinline__ void mlp_adam_body_flat(const MlpAdamArgs& a, const int p)
+{
+    if (p > a.nparams) return;
+    float g = 0.0f;
+#pragma unroll 1
+    for (int s0 = 0; s0 < 16; ++s0) {
+        float gs = 0.0f;
+        for (int w = s0; w < a.nparts; w += 16) gs += a.partial[(size_t)w * a.stride + p];
+        g += gs;
+    }
+    if (p == a.nparams) {  // the loss slot
+        *a.loss_acc += (double)g * (double)a.inv_b;
+        return;
+    }
+    const float w0 = a.params[p];
+    g = __builtin_fmaf(a.wd, w0, g);
+    const float m = __builtin_fmaf(a.beta1, a.m[p], (1.0f - a.beta1) * g);
+    const float v = __builtin_fmaf(a.beta2, a.v[p], (1.0f - a.beta2) * g * g);
+    a.m[p] = m;
+    a.v[p] = v;
+    const float denom = __builtin_amdgcn_sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    const float w1 = w0 - a.lr_t * (m / denom);
+    a.params[p] = w1;
+    if (a.wt) {
+        const int conn = a.H * a.H + a.H, q = p - a.H * 8;
+        if (q >= 0 && q < (a.L - 1) * conn) {
+            const int jc = q / conn, rem = q - jc * conn;
+            if (rem < a.H * a.H) {
+                const int i = rem / a.H, k = rem - i * a.H;
+                a.wt[(size_t)jc * a.H * a.H + (size_t)k * a.H + i] = w1;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a) { mlp_adam_body(a); }
 
 // ------------------------------------------------------------------ feature statistics
@@ -1365,6 +1404,7 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_list_kernel(const MlpBat
 }
 
 // bc1 / bc2: 1 - beta^step for step = 0 .. (host-computed tables: libm pow, as quad_steps uses)
+template <bool FLAT>
 __global__ __launch_bounds__(256) void mlp_adam_batch_kernel(const MlpBatchProb* __restrict__ tab, int s, int step_base,
                                                             int H, int L, const double* __restrict__ bc1,
                                                             const double* __restrict__ bc2)
@@ -1393,7 +1433,10 @@ __global__ __launch_bounds__(256) void mlp_adam_batch_kernel(const MlpBatchProb*
     b.beta2 = (float)p.beta2;
     b.eps = (float)p.eps;
     b.wd = (float)p.wd;
-    mlp_adam_body(b);
+    // FLAT: one thread per parameter (few, full workgroups: many problems per launch); else 16 threads per parameter
+    // (the single-problem kernel's shape: shortest latency for a lone problem).  Same bits either way.
+    if constexpr (FLAT) mlp_adam_body_flat(b, (int)(blockIdx.x * 256 + threadIdx.x));
+    else mlp_adam_body(b);
 }
 
 __global__ __launch_bounds__(256) void mlp_transpose_batch_kernel(const MlpBatchProb* __restrict__ tab, int H, int L)
@@ -1952,10 +1995,13 @@ static hipError_t batch_epoch(hipStream_t st, const MlpBatchProb* tab, int n, in
                               const double* bc1, const double* bc2)
 {
     hipLaunchKernelGGL(mlp_transpose_batch_kernel, dim3(16, n), dim3(256), 0, st, tab, H, L);
-    const dim3 gq((unsigned)max_tiles, (unsigned)n), ga((unsigned)((mlp_params_of(H, L) + 16) / 16), (unsigned)n);
+    const bool flat = n >= 8;
+    const dim3 gq((unsigned)max_tiles, (unsigned)n),
+        ga((unsigned)(flat ? (mlp_params_of(H, L) + 256) / 256 : (mlp_params_of(H, L) + 16) / 16), (unsigned)n);
     for (int64_t s = 0; s < max_steps; ++s) {
         hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L>), gq, dim3(H * 2), 0, st, tab, (int)s, 0);
-        hipLaunchKernelGGL(mlp_adam_batch_kernel, ga, dim3(256), 0, st, tab, (int)s, 0, H, L, bc1, bc2);
+        if (flat) hipLaunchKernelGGL(mlp_adam_batch_kernel<true>, ga, dim3(256), 0, st, tab, (int)s, 0, H, L, bc1, bc2);
+        else hipLaunchKernelGGL(mlp_adam_batch_kernel<false>, ga, dim3(256), 0, st, tab, (int)s, 0, H, L, bc1, bc2);
     }
     return hipGetLastError();
 }
@@ -1967,10 +2013,13 @@ template <int H, int L>
 static hipError_t batch_one_step(hipStream_t st, const MlpBatchProb* tab, int n, int grid_tiles, int step_base,
                                  const double* bc1, const double* bc2, const int* prefix)
 {
-    const dim3 gq((unsigned)grid_tiles, (unsigned)n), ga((unsigned)((mlp_params_of(H, L) + 16) / 16), (unsigned)n);
+    const bool flat = n >= 8;
+    const dim3 gq((unsigned)grid_tiles, (unsigned)n),
+        ga((unsigned)(flat ? (mlp_params_of(H, L) + 256) / 256 : (mlp_params_of(H, L) + 16) / 16), (unsigned)n);
     if (prefix) hipLaunchKernelGGL((mlp_train_quad_list_kernel<H, L>), dim3((unsigned)grid_tiles), dim3(H * 2), 0, st, tab, prefix, n, step_base);
     else hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L>), gq, dim3(H * 2), 0, st, tab, 0, step_base);
-    hipLaunchKernelGGL(mlp_adam_batch_kernel, ga, dim3(256), 0, st, tab, 0, step_base, H, L, bc1, bc2);
+    if (flat) hipLaunchKernelGGL(mlp_adam_batch_kernel<true>, ga, dim3(256), 0, st, tab, 0, step_base, H, L, bc1, bc2);
+    else hipLaunchKernelGGL(mlp_adam_batch_kernel<false>, ga, dim3(256), 0, st, tab, 0, step_base, H, L, bc1, bc2);
     return hipGetLastError();
 }
 
