@@ -474,7 +474,11 @@ def main():
         kernels.append(rf("lsm_pass1_kernel", 4.0 * M * N, ms_p1))  # rows 1..N-1 + terminal row
         kernels.append(rf("lsm_pass2_kernel", 4.0 * M * N, ms_p2))  # rows N..1 (upper bound)
     else:
-        kernels.append(rf("lsm_step_kernel", step_bytes_per_path(a.semantics) * M, ms_lsm / N, launches=N))
+        # per-step flows: the pricings of a group share their launches (K per launch; ms_lsm is per pricing)
+        k_eff = 1 if a.sync_every_step else ctx.seq_step_width([params(a.semantics, i) for i in range(min(a.group, a.steps))])
+        kernels.append(rf("lsm_step_kernel" if k_eff == 1 else "lsm_step_multi_kernel",
+                          step_bytes_per_path(a.semantics) * M * k_eff, ms_lsm * k_eff / N, launches=N))
+        kernels[-1]["pricings_per_launch"] = k_eff
     # HBM bytes per launch are PMC counters: they exist only in a rocprofv3 --pmc pass (two separate
     # passes, FETCH_SIZE doubled per the gfx950 note), so an ordinary run quotes the committed summary
     prof = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.config}.json")
@@ -486,7 +490,8 @@ def main():
             for k in kernels:
                 stem = k["kernel"].replace("gbm_", "").replace("heston_", "")
                 for name, v in pk.items():
-                    if stem in name.replace("_ind_", "_") and same:
+                    if stem in name.replace("_ind_", "_") and same and \
+                            v.get("pricings_per_launch", 1) == k.get("pricings_per_launch", 1):
                         k["traffic"] = v["read_bytes"] + v["write_bytes"]
                         k["traffic_source"] = f"profiles/pmc_traffic_{a.config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
                                               f"passes, {pj.get('round', 'r01')}; not measured in this run)"
@@ -541,6 +546,17 @@ def main():
             if r["pricings_per_launch"] not in by_k:
                 by_k[r["pricings_per_launch"]] = r
         ctx.set_option("seq_step_k", -1)
+        if os.path.exists(prof):  # PMC bytes per launch of the per-step kernels from the committed summary (same config)
+            try:
+                pj = json.load(open(prof))
+                if pj.get("config", "c2") == a.config and pj.get("paths_per_gpu", 1_000_000) == M:
+                    for r in by_k.values():
+                        for name, v in pj.get("kernels", {}).items():
+                            if r["kernel"] + "<" in name and v.get("pricings_per_launch", 1) == r["pricings_per_launch"]:
+                                r["traffic"] = v["read_bytes"] + v["write_bytes"]
+                                r["traffic_source"] = f"profiles/pmc_traffic_{a.config}.json ({pj.get('round', '')}; not measured in this run)"
+            except Exception:
+                pass
         best = max(by_k.values(), key=lambda r: r["frac"])
         r = dict(best)
         r.update(flow="reference (per-step sticky flow: Options_model.py:108-157)",
@@ -549,6 +565,7 @@ def main():
                  single_pricing={"us_per_time_step": one["us_per_time_step_per_pricing"], "frac": one["frac"],
                                  "ms_per_pricing": one["ms_per_pricing"], "path_steps_per_s": one["path_steps_per_s"]},
                  by_pricings_per_launch={str(k): {"frac": v["frac"], "achieved": v["achieved"], "ms_per_launch": v["ms_per_launch"],
+                                                  "traffic": v.get("traffic"),
                                                   "ms_per_pricing": v["ms_per_pricing"], "path_steps_per_s": v["path_steps_per_s"]}
                                          for k, v in sorted(by_k.items())})
         line["roofline_per_step"] = r

@@ -126,6 +126,38 @@ def test_config4_size_heston_put_real_decisions_and_idempotence(ctx):
     S.free()
 
 
+def test_config4_as_baseline_words_it_heston_call_full_truncation_4m_x_252(ctx):
+    """BASELINE configs[3] verbatim: Heston American CALL, full-truncation Euler, 4M paths x 252 steps, one GPU.
+    (1) against the CPU oracle on the same Philox stream for the first 200k paths of the SAME global pair indices
+    (1e-3 relative, north_star's tolerance; the oracle is float64 downstream of the same float32 paths);
+    (2) at full size: exact homogeneity in (S0, K), the American call on a non-dividend asset worth at least the
+    European one on the same paths, a sequence of three such pricings equal to three calls bit for bit, and the
+    per-step flow's K-per-launch form (K = 4 at this size) equal to its single launches."""
+    from options_model_amd import _ffi
+    from oracle import cpu as orc
+    M, N = 4_000_000, 252
+    kw = dict(model="heston", is_put=False, n_steps=N, seed=42, heston_scheme="full_truncation", **HP)
+    a = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=M, stream=9, **kw))
+    b = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=M, stream=9, S0=200.0, K=200.0, **kw))
+    assert b["price"] == 2.0 * a["price"] and b["n_exercised"] == a["n_exercised"] and b["sum_nitm"] == a["sum_nitm"]
+    eur = ctx.price_european(_ffi.make_params(n_paths=M, stream=9, **kw))
+    assert a["price"] >= eur["price"] - 3 * a["std"] / math.sqrt(M) and 9.5 < a["price"] < 11.5
+    Mc = 200_000
+    g = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=Mc, stream=9, **kw))
+    So = orc.heston_paths(Mc, N, 100.0, 0.05, 1.0, HP["v0"], HP["kappa"], HP["theta"], HP["xi"], HP["rho"], 42, 9, 0, 1)
+    ref = orc.lsm_poly(So, 100.0, 0.05, 1.0, False, "two_pass")
+    assert g["price"] == pytest.approx(ref["price"], rel=1e-3)
+    ps = [_ffi.make_params(semantics="two_pass", n_paths=M, stream=20 + i, **kw) for i in range(3)]
+    for p, s in zip(ps, ctx.price_american_seq(ps)):
+        one = ctx.price_american(p)
+        assert (s["price"], s["sumsq"], s["n_exercised"], s["sum_nitm"]) == (one["price"], one["sumsq"], one["n_exercised"], one["sum_nitm"])
+    ps = [_ffi.make_params(semantics="reference", n_paths=M, stream=30 + i, **kw) for i in range(4)]
+    assert ctx.seq_step_width(ps) == 4
+    for p, s in zip(ps, ctx.price_american_seq(ps)):
+        one = ctx.price_american(p)
+        assert (s["price"], s["sumsq"], s["n_exercised"], s["sum_nitm"]) == (one["price"], one["sumsq"], one["n_exercised"], one["sum_nitm"])
+
+
 @pytest.mark.parametrize("model,M,sems", [("gbm", 1_000_000, ("two_pass", "reference", "textbook")),
                                           ("heston", 4_000_000, ("two_pass",))])
 def test_full_size_pricing_is_exactly_homogeneous_in_spot_and_strike(ctx, model, M, sems):

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round-3 measurement steps, one per gpurun call:
+#   bash tools/gpu_r03.sh bench TAG   the driver's exact bench command + rocprofv3 kernel stats (two_pass, reference) + c3 / c4 lines
+#   bash tools/gpu_r03.sh pmc TAG     PMC passes: HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes)
+set -u
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+WHAT=${1:-bench}
+TAG=${2:-r03}
+R="$GRAFT_REPO_ROOT"
+ok() { [ "$1" -ne 124 ] && [ "$1" -ne 137 ]; }
+case "$WHAT" in
+bench)
+  timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_driver.json 2> gpurun_out/bench_${TAG}_driver.err; rc=$?
+  echo "bench (driver's command) exit=$rc"; ok $rc || exit 1
+  timeout -k 10 500 python bench.py > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err; rc=$?
+  echo "bench (defaults) exit=$rc"; ok $rc || exit 1
+  cd /tmp && export TMPDIR=/tmp
+  for SEM in two_pass reference; do
+    OUT="$R/gpurun_out/prof_${TAG}_$SEM"
+    EXTRA=""; [ $SEM = reference ] && EXTRA="--group 16 --steps 32"
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- \
+        python3 "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --semantics $SEM $EXTRA --no-cpu-baseline --no-variants --no-sustained \
+        > "$R/gpurun_out/bench_prof_${TAG}_$SEM.json" 2> "$R/gpurun_out/prof_${TAG}_$SEM.err"; rc=$?
+    echo "rocprof $SEM exit=$rc"; ok $rc || exit 1
+    f=$(find "$OUT" -name "*kernel_stats.csv" | head -1); cp "$f" "$R/gpurun_out/${TAG}_${SEM}_kernel_stats.csv"; head -9 "$f" | cut -c1-150
+    rm -rf "$OUT"
+  done
+  cd "$R"
+  timeout -k 10 400 python bench.py --config c3 --steps 10 --warmup 5 --no-variants > gpurun_out/bench_${TAG}_c3.json 2> gpurun_out/bench_${TAG}_c3.err; rc=$?
+  echo "bench c3 exit=$rc"; ok $rc || exit 1
+  timeout -k 10 400 python bench.py --config c4 --steps 20 --warmup 5 --no-variants > gpurun_out/bench_${TAG}_c4.json 2> gpurun_out/bench_${TAG}_c4.err; rc=$?
+  echo "bench c4 exit=$rc"
+  ;;
+pmc)
+  cd /tmp && export TMPDIR=/tmp
+  for SEM in two_pass reference; do
+    EXTRA=""; [ $SEM = reference ] && EXTRA="--group 16 --steps 16"
+    for CTR in FETCH_SIZE WRITE_SIZE; do
+      OUT="$R/gpurun_out/pmc_${TAG}${SEM}_$CTR"
+      timeout -k 10 300 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$OUT" -- \
+          python3 "$R/bench.py" --steps 3 --warmup 1 --min-warmup-seconds 0.02 --semantics $SEM $EXTRA --only-timed > /dev/null 2> "$OUT.err"; rc=$?
+      echo "pmc $SEM $CTR exit=$rc"; ok $rc || exit 1
+    done
+    python3 "$R/tools/summarize_pmc.py" "$R/gpurun_out" "${TAG}${SEM}" c2 1000000 "$TAG" | tee "$R/gpurun_out/pmc_summary_${TAG}${SEM}.txt"
+    rm -rf "$R/gpurun_out/pmc_${TAG}${SEM}_FETCH_SIZE" "$R/gpurun_out/pmc_${TAG}${SEM}_WRITE_SIZE"
+  done
+  ;;
+esac
