@@ -220,6 +220,10 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="go through the communicator even with one rank (rehearsal of the N>1 path)")
+    ap.add_argument("--p2p-exchange", action="store_true",
+                    help="several ranks, native communicator: exchange the per-step flows' moments by direct writes into "
+                         "every peer's mailbox (omc_p2p_*, SURVEY 5.8(b)) instead of an all-reduce per time step; checked "
+                         "against the collective before use, on every rank")
     ap.add_argument("--rank-timeout", type=float, default=300.0,
                     help="multi-rank runs: overall deadline in seconds; ranks still running then are ended and the job "
                          "exits non-zero (launcher and, inside every rank, a watchdog)")
@@ -515,6 +519,27 @@ def main():
     if a.only_timed:
         line["roofline_per_step"] = kernels[1] if a.semantics == "reference" else None
     elif a.semantics != "reference":
+        exchange = "n/a (one rank)" if not dist_mode else "collective (all-reduce of 8K doubles per time step)"
+        if dist_mode and comm.startswith("rccl-native") and (a.p2p_exchange or os.environ.get("OMC_BENCH_P2P") == "1"):
+            # direct peer writes instead of a collective per step: connect (collective decision), then every rank
+            # prices one small sequence both ways; only if all ranks see the same price (1e-12: the collective may
+            # add the ranks' contributions in another order) and no exchange timed out does the section use it
+            good = False
+            if pricer.enable_p2p():
+                try:
+                    ids = [3000, 3001, 3002, 3003]
+                    ctx.set_option("p2p_exchange", 1)
+                    on = [o["sum"] for o in price_group(ids, "reference")[1]]
+                    ctx.set_option("p2p_exchange", 0)
+                    off = [o["sum"] for o in price_group(ids, "reference")[1]]
+                    good = all(abs(x - y) <= 1e-12 * abs(y) for x, y in zip(on, off))
+                except Exception as e:  # a timed-out exchange surfaces as an error of the call
+                    print(f"bench.py rank {rank}: direct exchange failed its self-check: {e}", file=sys.stderr)
+                    good = False
+            good = pricer.allreduce_max(0.0 if good else 1.0) == 0.0
+            ctx.set_option("p2p_exchange", 1 if good else 0)
+            exchange = ("direct writes into every peer's mailbox (omc_p2p_*), one launch per time step" if good
+                        else exchange + "; the direct exchange did not pass its self-check")
         # (a) ONE pricing per launch: the latency of a single pricing's time step; (b) K pricings of the sequence
         # per launch (omc_price_american_seq, option "seq_step_k"): the throughput of the same kernel when the
         # chip is filled.  Same kernel body, same bits per pricing (tests/test_gpu_step_multi.py).
@@ -559,7 +584,7 @@ def main():
                 pass
         best = max(by_k.values(), key=lambda r: r["frac"])
         r = dict(best)
-        r.update(flow="reference (per-step sticky flow: Options_model.py:108-157)",
+        r.update(flow="reference (per-step sticky flow: Options_model.py:108-157)", exchange_across_ranks=exchange,
                  note="ms_per_launch = HIP-event time of the whole N-launch sweep / N (kernel boundaries included); a launch "
                       "advances `pricings_per_launch` independent pricings of the sequence by one time step",
                  single_pricing={"us_per_time_step": one["us_per_time_step_per_pricing"], "frac": one["frac"],

@@ -109,6 +109,22 @@ int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
  * [n_steps + 1][256][8] uint64 with launch index n_steps - t.  Not part of the pricing path. */
 int omc_debug_read(omc_ctx* ctx, void* host, size_t bytes);
 
+/* ---- per-step flows across GPUs without a collective per step ------------------------------ */
+/* The per-step flows exchange 8 doubles per pricing after every time step.  Instead of an all-reduce per step, every
+ * rank can WRITE its contribution into every peer's memory (xGMI) and sum what arrives itself: omc_p2p_export
+ * allocates this rank's mailbox (fine-grained device memory) and returns its 64-byte IPC handle; hand all ranks'
+ * handles, in rank order, to omc_p2p_connect on every rank (one node; at most 16 ranks).  From then on a context
+ * that is distributed (communicator or hook) runs the per-step exchange as ONE small launch per step -- reduce the
+ * rank's partials, publish to all peers, poll the own mailbox (bounded), add the contributions in rank order -- and
+ * keeps the collective for everything else (the two-pass flow's moment table, the result sums).  Every rank gets
+ * the same bits; a contribution that does not arrive within the deadline makes the pricing call fail (error 3100,
+ * sticky: omc_p2p_status reports it) -- it never hangs.  Option "p2p_exchange" = 0 switches back to the collective
+ * without disconnecting. */
+int omc_p2p_export(omc_ctx* ctx, void* handle_out, size_t bytes /* >= 64 */);
+int omc_p2p_connect(omc_ctx* ctx, int rank, int world, const void* handles, size_t bytes /* >= world * 64 */);
+int omc_p2p_disconnect(omc_ctx* ctx);
+int omc_p2p_status(omc_ctx* ctx, int* connected, int* world, uint64_t* error_word);
+
 /* ---- path generation ------------------------------------------------------------------- */
 /* replaces the inline GBM block options_model_3.py:473-480 (== Options_model.py:79-88,
  * options_model_2.py:257-264) and the torch loops option_model_3_gpu.py:117-185 */

@@ -89,6 +89,10 @@ SIGNATURES = {
     "omc_comm_destroy": (C.c_int, [_P]),
     "omc_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "omc_comm_allreduce_f64": (C.c_int, [_P, _P, _I, _I]),
+    "omc_p2p_export": (C.c_int, [_P, _P, _SZ]),
+    "omc_p2p_connect": (C.c_int, [_P, _I, _I, _P, _SZ]),
+    "omc_p2p_disconnect": (C.c_int, [_P]),
+    "omc_p2p_status": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "omc_price_american": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result), _P, _I64]),
     "omc_price_european": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result)]),
     "omc_heston_price_strikes": (C.c_int, [_P, _I64, _I] + [_D] * 8 + [_U64, _U64, _I, _P, _I, _I, _P, _P]),
@@ -452,6 +456,25 @@ class Context:
         a = np.ascontiguousarray(values, np.float64).copy()
         _check(self.lib, self.lib.omc_comm_allreduce_f64(self.handle, a.ctypes.data, a.size, 1 if op == "max" else 0))
         return a
+
+    # -- direct peer exchange of the per-step moments (include/omc.h)
+    def p2p_export(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        _check(self.lib, self.lib.omc_p2p_export(self.handle, buf, 64))
+        return buf.raw
+
+    def p2p_connect(self, rank: int, world: int, handles: bytes):
+        buf = C.create_string_buffer(bytes(handles), 64 * int(world))
+        _check(self.lib, self.lib.omc_p2p_connect(self.handle, int(rank), int(world), buf, 64 * int(world)))
+
+    def p2p_disconnect(self):
+        _check(self.lib, self.lib.omc_p2p_disconnect(self.handle))
+
+    def p2p_status(self):
+        """-> (connected, world, sticky error word)"""
+        a, b, e = C.c_int(0), C.c_int(0), C.c_uint64(0)
+        _check(self.lib, self.lib.omc_p2p_status(self.handle, C.byref(a), C.byref(b), C.byref(e)))
+        return bool(a.value), b.value, e.value
 
     # -- fused pricing
     def price_american(self, params: Params, keep_paths: DeviceArray | None = None):

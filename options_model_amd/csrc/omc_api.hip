@@ -14,6 +14,7 @@
 
 #include "omc_batch.h"
 #include "omc_comm.h"
+#include "omc_p2p.h"
 #include "omc_kernels.h"
 
 namespace {
@@ -111,6 +112,10 @@ struct omc_ctx {
     omc_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
     omc::Comm* comm = nullptr;  // native RCCL communicator (omc_comm_init); takes precedence over the hook
+    // direct write-to-all-peers exchange of the per-step moments (omc_p2p_connect): replaces the per-step all-reduce
+    omc::P2P* p2p = nullptr;
+    int p2p_use = 1;            // option "p2p_exchange": 0 = keep the collective even when connected
+    bool p2p_used = false;      // an exchange was enqueued since the last wait
     // omc_price_american_seq across GPUs: the moment all-reduce of pricing k runs on its own stream while the
     // main stream generates the paths of pricing k+1 into the second path buffer
     hipStream_t comm_stream = nullptr;
@@ -262,6 +267,13 @@ int allreduce(omc_ctx* c, double* dptr, int count)
     return 0;
 }
 
+// the per-step moments travel by direct peer writes instead of a collective: connected, switched on, and the same
+// world as the communicator / hook the rest of the exchange uses
+bool p2p_active(const omc_ctx* c)
+{
+    return c->p2p && c->p2p_use && omc::p2p_connected(c->p2p) && c->distributed() && omc::p2p_world(c->p2p) == c->world;
+}
+
 bool step_persistent_enabled(const omc_ctx* c)
 {
     if (c->persist_failed) return false;
@@ -381,8 +393,13 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
             for (int t = p.N; t >= 1; --t) {
                 HIP_TRY(omc::lsm_step(st, p, w, semantics, t, ext));
                 if (ext && t >= 2) {
-                    HIP_TRY(omc::lsm_reduce_step_moments(st, w, t - 1, nblk));
-                    if ((rc = allreduce(c, w.gmom + (size_t)(t - 1) * 8, 8))) return rc;
+                    if (p2p_active(c)) {  // reduce + publish to all peers + gather + rank-ordered sum: one launch
+                        HIP_TRY(omc::p2p_exchange_step(c->p2p, st, w, t - 1, nblk));
+                        c->p2p_used = true;
+                    } else {
+                        HIP_TRY(omc::lsm_reduce_step_moments(st, w, t - 1, nblk));
+                        if ((rc = allreduce(c, w.gmom + (size_t)(t - 1) * 8, 8))) return rc;
+                    }
                 }
             }
             HIP_TRY(omc::lsm_final_reduce(st, p, w, semantics == OMC_SEM_TEXTBOOK ? 0 : 1, flags, write_state));
@@ -401,6 +418,18 @@ bool persistent_gave_up(omc_ctx* c, const double* h)
     if (!c->persist_used || h[7] == 0.0) return false;
     c->persist_failed = 1;
     return true;
+}
+
+// after a wait: did a direct exchange give up (its bounded poll ran out)?  The sums are NaN then.
+int check_p2p(omc_ctx* c)
+{
+    if (!c->p2p_used) return 0;
+    c->p2p_used = false;
+    unsigned long long w = 0;
+    HIP_TRY(omc::p2p_error_word(c->p2p, c->stream, &w));
+    if (w) return fail(3100, "direct peer exchange of the per-step moments timed out (a peer's contribution never arrived); "
+                             "omc_p2p_disconnect and use the collective");
+    return 0;
 }
 
 void fill_result(omc_result* res, const double* h, int64_t M, int world = 1)
@@ -508,6 +537,8 @@ int omc_ctx_destroy(omc_ctx* c)
     drop_sweep_graph(c);
     if (c->comm) omc::comm_destroy(c->comm);
     c->comm = nullptr;
+    if (c->p2p) omc::p2p_destroy(c->p2p);
+    c->p2p = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->persist_scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc,
                       &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
@@ -592,6 +623,7 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     else if (!strcmp(key, "seq_event_stride")) c->seq_event_stride = value > 0 ? (int)value : 0;
     else if (!strcmp(key, "seq_step_k")) c->seq_step_k = value < 0 ? -1 : (int)(value > 32 ? 32 : value);
     else if (!strcmp(key, "seq_step_wgs")) c->seq_step_wgs = value > 0 ? (int)value : 0;
+    else if (!strcmp(key, "p2p_exchange")) c->p2p_use = value ? 1 : 0;
     else if (!strcmp(key, "step_persistent")) {
         c->step_persistent = value < 0 ? -1 : (value ? 1 : 0);
         if (value > 0) c->persist_failed = 0;  // explicit request: try again
@@ -680,6 +712,63 @@ int omc_comm_allreduce_f64(omc_ctx* c, double* host_inout, int count, int op)
     if (rc) return fail(rc, err.c_str());
     HIP_TRY(hipMemcpyAsync(host_inout, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ direct peer exchange (per-step flows)
+int omc_p2p_export(omc_ctx* c, void* handle_out, size_t bytes)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!handle_out || bytes < (size_t)omc::kP2PHandleBytes) return fail(-7, "handle buffer must hold 64 bytes.");
+    if (c->p2p) return fail(-4, "this context already has a mailbox (omc_p2p_disconnect first).");
+    std::string err;
+    omc::P2P* p = nullptr;
+    rc = omc::p2p_export(&p, handle_out, &err);
+    if (rc) return fail(rc, err.c_str());
+    c->p2p = p;
+    return 0;
+}
+
+int omc_p2p_connect(omc_ctx* c, int rank, int world, const void* handles, size_t bytes)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!c->p2p) return fail(-4, "no mailbox on this context (omc_p2p_export first).");
+    if (!handles || world < 1 || bytes < (size_t)world * omc::kP2PHandleBytes)
+        return fail(-7, "handles must hold world x 64 bytes, in rank order.");
+    std::string err;
+    rc = omc::p2p_connect(c->p2p, rank, world, handles, &err);
+    if (rc) return fail(rc, err.c_str());
+    return 0;
+}
+
+int omc_p2p_disconnect(omc_ctx* c)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!c->p2p) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    omc::p2p_destroy(c->p2p);
+    c->p2p = nullptr;
+    c->p2p_used = false;
+    return 0;
+}
+
+int omc_p2p_status(omc_ctx* c, int* connected, int* world, uint64_t* error_word)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (connected) *connected = (c->p2p && omc::p2p_connected(c->p2p)) ? 1 : 0;
+    if (world) *world = c->p2p ? omc::p2p_world(c->p2p) : 0;
+    if (error_word) {
+        *error_word = 0;
+        if (c->p2p && omc::p2p_connected(c->p2p)) {
+            unsigned long long w = 0;
+            HIP_TRY(omc::p2p_error_word(c->p2p, c->stream, &w));
+            *error_word = w;
+        }
+    }
     return 0;
 }
 
@@ -809,6 +898,7 @@ int omc_lsm_poly(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
         HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
         if ((rc = copy_outputs(c, w, n_paths, n_steps, betas_out, sx_out, tex_out))) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if ((rc = check_p2p(c))) return rc;
         if (attempt == 0 && persistent_gave_up(c, c->hres)) continue;
         break;
     }
@@ -1011,6 +1101,7 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
         if (!zero_copy)
             HIP_TRY(hipMemcpyAsync(hres, result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
         if ((rc = wait_stream(c))) return rc;
+        if ((rc = check_p2p(c))) return rc;
         if (attempt == 0 && persistent_gave_up(c, hres)) continue;
         break;
     }
@@ -1380,6 +1471,19 @@ static int enqueue_seq_step_multi(omc_ctx* c, const omc_params* p, int n, int K,
             omc::lsm_sweep_args_image(prob, w, sem, false, img + eb * (size_t)k, ext);
         }
         HIP_TRY(hipMemcpyAsync(c->mtable.p, img, eb * (size_t)Kb, hipMemcpyHostToDevice, c->stream));
+        const bool p2p = ext && p2p_active(c) && Kb <= omc::kP2PMaxPricings;
+        if (p2p) {  // where each pricing's partials are and where its global moments go
+            const double* parts[omc::kP2PMaxPricings];
+            double* gm[omc::kP2PMaxPricings];
+            int nb[omc::kP2PMaxPricings], gs[omc::kP2PMaxPricings];
+            for (int k = 0; k < Kb; ++k) {
+                parts[k] = (const double*)(state + gbytes + per * (size_t)k + o_part);
+                gm[k] = gmomK + 8 * (size_t)k;
+                nb[k] = omc::lsm_sweep_blocks(M);
+                gs[k] = 8 * Kb;
+            }
+            HIP_TRY(omc::p2p_set_jobs(c->p2p, c->stream, parts, gm, nb, gs, Kb));
+        }
         if (i0 == 0) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         for (int k = 0; k < Kb; ++k)
             if ((rc = enqueue_paths(c, &p[i0 + k], (float*)((char*)c->mS.p + sbytes * (size_t)k), ld))) return rc;
@@ -1387,8 +1491,13 @@ static int enqueue_seq_step_multi(omc_ctx* c, const omc_params* p, int n, int K,
         for (int t = N; t >= 1; --t) {
             HIP_TRY(omc::lsm_step_multi(c->stream, c->mtable.p, Kb, G, sem, vec4, N, t));
             if (ext && t >= 2) {
-                HIP_TRY(omc::lsm_reduce_step_moments_multi(c->stream, c->mtable.p, Kb, t - 1));
-                if ((rc = allreduce(c, gmomK + (size_t)(t - 1) * 8 * (size_t)Kb, 8 * Kb))) return rc;  // K fits' moments, one collective
+                if (p2p) {
+                    HIP_TRY(omc::p2p_exchange_step_multi(c->p2p, c->stream, Kb, t - 1));
+                    c->p2p_used = true;
+                } else {
+                    HIP_TRY(omc::lsm_reduce_step_moments_multi(c->stream, c->mtable.p, Kb, t - 1));
+                    if ((rc = allreduce(c, gmomK + (size_t)(t - 1) * 8 * (size_t)Kb, 8 * Kb))) return rc;  // K fits' moments, one collective
+                }
             }
         }
         HIP_TRY(omc::lsm_final_multi(c->stream, c->mtable.p, Kb, M));
@@ -1460,6 +1569,7 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
         }
         HIP_TRY(hipEventRecord(ev_end, c->stream));
         if ((rc = wait_stream(c))) return rc;
+        if ((rc = check_p2p(c))) return rc;
         bool redo = false;
         for (int i = 0; i < n && attempt == 0; ++i) redo = redo || persistent_gave_up(c, c->seq_pin + 8 * (size_t)i);
         if (!redo) break;

@@ -198,9 +198,45 @@ class RcclPricer(_ShardedBase):
     def allreduce_max(self, x: float) -> float:
         return float(self.ctx.comm_allreduce([x], "max")[0])
 
+    def enable_p2p(self, tag: str | None = None, timeout_s: float = 60.0) -> bool:
+        """The per-step flows' moment exchange by direct writes into every peer's mailbox (omc_p2p_*; SURVEY.md
+        5.8(b)) instead of an all-reduce per time step.  Collective: every rank exports its mailbox handle, all
+        handles travel through the rendezvous directory, every rank maps every peer; the ranks vote after each
+        stage and either ALL end up connected (True) or all stay with the collective (False).  The communicator
+        keeps doing everything else."""
+        from . import rendezvous
+        base = (rendezvous.default_tag() if tag is None else tag) + "_p2p"
+        handle, ok = b"\0" * 64, True
+        try:
+            handle = self.ctx.p2p_export()
+        except Exception:
+            ok = False
+        path = rendezvous.publish(handle, f"{base}_h{self.rank}")
+        try:
+            if not rendezvous.agree(self.rank, self.world, ok, "p2p_export", tag, timeout_s):
+                if ok:
+                    self.ctx.p2p_disconnect()
+                return False
+            handles = b"".join(rendezvous.fetch(64, f"{base}_h{r}", timeout_s) for r in range(self.world))
+            try:
+                self.ctx.p2p_connect(self.rank, self.world, handles)
+            except Exception:
+                ok = False
+            if not rendezvous.agree(self.rank, self.world, ok, "p2p_connect", tag, timeout_s):
+                self.ctx.p2p_disconnect()
+                return False
+            return True
+        finally:
+            rendezvous._retire_at_exit([path])
+
     def close(self):
         try:
-            self.ctx.comm_destroy()
+            try:
+                if self.ctx.p2p_status()[0]:
+                    self.barrier()  # no rank unmaps its mailbox while a peer could still be writing into it
+                self.ctx.p2p_disconnect()
+            finally:
+                self.ctx.comm_destroy()
         finally:
             self.ctx.close()
 

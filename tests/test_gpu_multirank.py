@@ -140,3 +140,68 @@ def test_facade_n_gpus_2_shards_through_the_native_communicator(ctx, standin, tm
     one = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 200_000, 40, model="Heston", option_type="call",
                                 heston_scheme="full_truncation", seed=5, ctx=ctx)
     assert got[0]["heston"][0] == pytest.approx(one.price, rel=1e-12)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_peer_exchange_equals_the_collective_path(ctx, standin, world):
+    """SURVEY 5.8(b) / VERDICT r2 item 8: the per-step flows' moments by direct writes into every peer's mailbox
+    (hipIpc-mapped fine-grained memory, system-scope stores and polls, bounded) instead of an all-reduce per step.
+    Ranks share this GPU; both paths add the ranks' contributions in rank order, so the results are the same BITS:
+    compared against the unsharded pricing exactly as the collective path is, for one pricing per launch and for K."""
+    from options_model_amd import _ffi
+    out, _ = _bench(["--gpus", str(world), "--single-device", "--backend", "rccl", "--steps", "4", "--warmup", "2",
+                     "--paths-per-gpu", str(M_PER_GPU), "--n-steps", str(N), "--group", "4", "--p2p-exchange",
+                     "--min-warmup-seconds", "0.05", "--no-variants", "--no-cpu-baseline", "--no-sustained"], standin)
+    d = _line(out)
+    ps = d["roofline_per_step"]
+    assert ps["exchange_across_ranks"].startswith("direct writes"), ps["exchange_across_ranks"]
+    ref = ctx.price_american(_ffi.make_params(semantics="reference", n_paths=world * M_PER_GPU, n_steps=N, seed=42,
+                                              stream=ps["price_stream"]))
+    assert ps["price"] == pytest.approx(ref["price"], rel=1e-12) and ps["pricings_per_launch"] >= 4
+    assert ps["last_pricing"]["sum_nitm"] == ref["sum_nitm"] and ps["last_pricing"]["n_exercised"] == ref["n_exercised"]
+
+
+_P2P = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+from options_model_amd import _ffi
+from options_model_amd.dist import RcclPricer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+sp = RcclPricer(0, rank, world)
+kw = dict(semantics="reference", n_steps=30, seed=9)
+coll1 = sp.price_american(120_000 * world, stream=1, **kw)
+collK = sp.price_american_seq(120_000 * world, [2, 3, 4, 5, 6], **kw)
+assert sp.enable_p2p()
+assert sp.ctx.p2p_status() == (True, world, 0)
+p2p1 = sp.price_american(120_000 * world, stream=1, **kw)
+p2pK = sp.price_american_seq(120_000 * world, [2, 3, 4, 5, 6], **kw)
+tb = sp.price_american(120_000 * world, stream=1, **dict(kw, semantics="textbook"))
+sp.ctx.set_option("p2p_exchange", 0)
+tb0 = sp.price_american(120_000 * world, stream=1, **dict(kw, semantics="textbook"))
+keys = ("price", "sumsq", "n_exercised", "sum_nitm")
+same = all(p2p1[k] == coll1[k] for k in keys) and all(a[k] == b[k] for a, b in zip(p2pK, collK) for k in keys) \
+    and all(tb[k] == tb0[k] for k in keys)
+print("RESULT" + str(rank) + " " + json.dumps(dict(same=same, price=p2p1["price"], status=list(sp.ctx.p2p_status()))))
+sp.close()
+"""
+
+
+def test_direct_exchange_bitwise_equals_collective_in_process(standin, tmp_path):
+    """The same comparison without bench.py: two rank processes price through the collective and through the direct
+    exchange (single pricing, a sequence of five sharing their launches, the textbook flow) -- identical bits."""
+    script = tmp_path / "p2p2.py"
+    script.write_text(_P2P % ROOT)
+    port = 29900 + os.getpid() % 90
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMC_RCCL_LIB=standin, OMC_RDZV_NONCE=f"p2p{os.getpid()}")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    got = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2500:]
+        got.append(json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT")][0].split(" ", 1)[1]))
+    assert got[0]["same"] and got[1]["same"] and got[0]["price"] == got[1]["price"]
+    assert got[0]["status"] == [True, 2, 0]
