@@ -205,3 +205,23 @@ def test_direct_exchange_bitwise_equals_collective_in_process(standin, tmp_path)
         got.append(json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT")][0].split(" ", 1)[1]))
     assert got[0]["same"] and got[1]["same"] and got[0]["price"] == got[1]["price"]
     assert got[0]["status"] == [True, 2, 0]
+
+
+def test_the_drivers_launch_form_torchrun_native_communicator(ctx, standin):
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`: the ranks are torchrun's children (common parent = its agent, which names
+    the rendezvous files together with MASTER_PORT and TORCHELASTIC_RUN_ID), bench.py must NOT start ranks of its own,
+    and the default transport is the native communicator."""
+    from options_model_amd import _ffi
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMC_RCCL_LIB=standin, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29650 + os.getpid() % 40), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "4", "--warmup", "2", "--paths-per-gpu", str(M_PER_GPU), "--n-steps", str(N), "--single-device",
+           "--backend", "rccl", "--group", "4", "--min-warmup-seconds", "0.05", "--no-variants", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["comm"].startswith("rccl-native") and d["seq_overlap"] == "on"
+    ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=2 * M_PER_GPU, n_steps=N, seed=42, stream=3))
+    assert d["price"] == pytest.approx(ref["price"], rel=1e-12)
+    assert d["sustained"]["pricings"] > 0 and d["clock_settled"] in (True, False)
