@@ -54,8 +54,9 @@ HESTON = dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7)
 
 def step_bytes_per_path(semantics: str) -> float:
     """what one launch of lsm_step_kernel must move per path."""
-    # reference: S_t, S_t-1, S_N (4 each) + 1 flag byte; textbook: S_t, S_t-1, sx, tex
-    return 13.0 if semantics == "reference" else 16.0
+    # reference: S_t, S_t-1 and the path's `live` value (S_N, or negative once exercised): 4 bytes each;
+    # textbook: S_t, S_t-1, sx, tex
+    return 12.0 if semantics == "reference" else 16.0
 
 
 def lsm_algorithmic_bytes(semantics: str, M: int, N: int) -> float:

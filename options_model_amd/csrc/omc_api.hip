@@ -204,7 +204,7 @@ int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
     int rc;
     if ((rc = c->sx.ensure(sizeof(float) * (size_t)M))) return rc;
     if ((rc = c->tex.ensure(sizeof(int32_t) * (size_t)M))) return rc;
-    if ((rc = c->ex.ensure((size_t)M + 16))) return rc;
+    if ((rc = c->ex.ensure(sizeof(float) * (size_t)M + 16))) return rc;
     if ((rc = c->D.ensure(sizeof(double) * (size_t)(N + 1)))) return rc;
     if ((rc = c->part.ensure(sizeof(double) * 2 * 8 * omc::kMaxLsmBlocks))) return rc;
     if ((rc = c->gmom.ensure(sizeof(double) * 8 * (size_t)(N + 1)))) return rc;
@@ -220,7 +220,7 @@ int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
     }
     w->sx = (float*)c->sx.p;
     w->tex = (int32_t*)c->tex.p;
-    w->ex = (uint8_t*)c->ex.p;
+    w->live = (float*)c->ex.p;
     if (c->step_stamps) {
         if ((rc = c->dbg.ensure(sizeof(unsigned long long) * 8 * 256 * (size_t)(N + 1)))) return rc;
         w->dbg = (unsigned long long*)c->dbg.p;
@@ -1400,7 +1400,7 @@ static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
         // re-reads S_t, S_N and the flags its predecessor touched: measured at 1M paths, 16 pricings per launch
         // 0.66 of the HBM roofline, 32 -- 416 MB per launch -- 0.53), at most 16; problems so large that fewer
         // than 4 fit are bandwidth-bound one at a time already (8M paths: 0.62 alone, 0.61 with 4 per launch)
-        const double per = (p[0].semantics == OMC_SEM_REFERENCE ? 13.0 : 16.0) * (double)p[0].n_paths;
+        const double per = (p[0].semantics == OMC_SEM_REFERENCE ? 12.0 : 16.0) * (double)p[0].n_paths;
         k = (int)(2.2e8 / per);
         if (k > 16) k = 16;
         if (k < 4) k = 1;
@@ -1433,7 +1433,7 @@ static int enqueue_seq_step_multi(omc_ctx* c, const omc_params* p, int n, int K,
     const size_t sbytes = sizeof(float) * (size_t)ld * (size_t)(N + 1);
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t o_sx = 0, o_tex = o_sx + up(sizeof(float) * (size_t)M), o_ex = o_tex + up(sizeof(int32_t) * (size_t)M),
-                 o_part = o_ex + up((size_t)M + 16), o_betas = o_part + up(sizeof(double) * 2 * 8 * omc::kMaxLsmBlocks),
+                 o_part = o_ex + up(sizeof(float) * (size_t)M + 16), o_betas = o_part + up(sizeof(double) * 2 * 8 * omc::kMaxLsmBlocks),
                  per = o_betas + up(sizeof(double) * 4 * (size_t)(N + 1));
     const size_t gbytes = up(sizeof(double) * 8 * (size_t)K * (size_t)(N + 1));
     if ((rc = c->mS.ensure(sbytes * (size_t)K))) return rc;
@@ -1463,7 +1463,7 @@ static int enqueue_seq_step_multi(omc_ctx* c, const omc_params* p, int n, int K,
             const omc_params& q = p[i0 + k];
             char* st = state + gbytes + per * (size_t)k;
             omc::LsmWorkspace w = w0;
-            w.sx = (float*)(st + o_sx); w.tex = (int32_t*)(st + o_tex); w.ex = (uint8_t*)(st + o_ex);
+            w.sx = (float*)(st + o_sx); w.tex = (int32_t*)(st + o_tex); w.live = (float*)(st + o_ex);
             w.part = (double*)(st + o_part); w.betas = (double*)(st + o_betas);
             w.gmom = gmomK + 8 * (size_t)k; w.gstride = 8 * Kb;
             w.result = dst + 8 * (size_t)(i0 + k);

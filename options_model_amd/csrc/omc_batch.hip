@@ -136,7 +136,7 @@ __device__ __forceinline__ bool cn_args_at(const BatchProb& pr, const CnProb& c,
     if (t < 1 || t >= s.N) return false;
     a->St = s.S + (int64_t)t * s.ld;
     a->SN = s.S + (int64_t)s.N * s.ld;
-    a->ex = s.ex;
+    a->live = s.live;
     a->M = s.M;
     a->K = s.K;
     a->Dt = s.D[s.N - t];
@@ -243,7 +243,7 @@ static Layout plan(const BatchItem& it, size_t base, bool american, bool two_pas
         L.S = take(sizeof(float) * (size_t)L.ld * (size_t)(N + 1));
         L.sx = take(sizeof(float) * (size_t)M);
         L.tex = take(sizeof(int32_t) * (size_t)M);
-        L.ex = take((size_t)M);
+        L.ex = take(sizeof(float) * (size_t)M);  // the per-step reference flow's `live` row
         L.gmom = take(sizeof(double) * 8 * (size_t)(N + 1));
         L.betas = take(sizeof(double) * 4 * (size_t)(N + 1));
         if (two_pass) L.part1 = take(sizeof(double) * 8 * (size_t)(N + 1) * (size_t)L.ntiles);
@@ -321,7 +321,7 @@ void batch_build(const BatchItem* items, int n, bool american, bool two_pass, ch
         dk += (size_t)N + 1;
         StepArgs& s = p.step;
         s.S = p.path.S; s.ld = L.ld; s.M = M; s.N = N; s.is_put = it.is_put; s.K = it.K; s.invK = 1.0 / it.K;
-        s.sx = (float*)(slab + L.sx); s.tex = (int32_t*)(slab + L.tex); s.ex = (uint8_t*)(slab + L.ex); s.D = D;
+        s.sx = (float*)(slab + L.sx); s.tex = (int32_t*)(slab + L.tex); s.live = (float*)(slab + L.ex); s.D = D;
         s.part = part;
         s.gmom = (double*)(slab + L.gmom); s.betas = (double*)(slab + L.betas);
         s.t = 0; s.nblk = L.nblk_sweep; s.external = 0; s.pstride = L.pstride; s.gstride = 8; s.cont = nullptr; s.ldc = 0; s.dbg = nullptr;
@@ -334,7 +334,7 @@ void batch_build(const BatchItem* items, int n, bool american, bool two_pass, ch
         a2.nblk = L.nblk_blocks; a2.pstride = L.pstride;
         FinalArgs& f = p.fin;
         f.sx = s.sx; f.tex = s.tex; f.M = M; f.N = N; f.is_put = it.is_put; f.tval = it.semantics == 1 ? 0 : 1;
-        f.ex = it.semantics == 0 ? s.ex : nullptr; f.SN = s.S + (int64_t)N * L.ld; f.fill_state = 0;
+        f.live = it.semantics == 0 ? s.live : nullptr; f.fill_state = 0;
         f.K = it.K; f.D = D; f.part = part; f.nblk = L.nblk_blocks; f.pstride = L.pstride;
         p.fin_nblk = L.nblk_blocks;
         e.max_steps = std::max(e.max_steps, N);

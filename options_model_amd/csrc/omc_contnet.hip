@@ -57,7 +57,7 @@ static void carve(const LsmProblem& p, const LsmWorkspace& w, void* scratch, int
     a->hdr = (double*)q;
     a->St = p.S + (size_t)t * p.ld;
     a->SN = p.S + (size_t)p.N * p.ld;
-    a->ex = w.ex;
+    a->live = w.live;
     a->M = p.M;
     a->K = p.K;
     a->Dt = Dt;

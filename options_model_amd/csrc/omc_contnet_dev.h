@@ -15,7 +15,7 @@ constexpr int kCnSpan = kCnBlock * kCnChunks;      // paths per workgroup
 struct CnArgs {
     const float* St;    // row t of the path matrix
     const float* SN;    // row N
-    const uint8_t* ex;  // sticky "has exercised" flags
+    const float* live;  // sticky state of the per-step sweep: negative = has exercised
     int64_t M;
     double K, Dt;       // Dt = exp(-r dt (N - t)): terminal payoff valued at t
     int is_put, nblk;
@@ -30,7 +30,7 @@ struct CnArgs {
 
 __device__ __forceinline__ bool member(const CnArgs& a, int64_t j, float s)
 {
-    return payoff_d(s, a.K, a.is_put) > 0.0 && a.ex[j] == 0;
+    return payoff_d(s, a.K, a.is_put) > 0.0 && !(a.live[j] < 0.0f);
 }
 
 // fixed-order sum of one double per thread over the workgroup (valid in thread 0)

@@ -72,7 +72,8 @@ struct LsmProblem {
 struct LsmWorkspace {
     float* sx;        // [M]   spot at the (current) exercise time of each path
     int32_t* tex;     // [M]   step index of that exercise (N = maturity / never exercised)
-    uint8_t* ex;      // [M]   per-step reference flow: sticky "has exercised" flag (sx / tex valid where set)
+    float* live;      // [M]   per-step reference flow: S_N while the path is in play, negative once it has exercised
+                      //       (sticky; sx / tex valid where negative)
     double* D;        // [N+1] discount table exp(-r dt k)
     double* part;     // [2][8][kMaxLsmBlocks] per-block partial moments, ping-pong by step parity
     double* gmom;     // [N+1][8] reduced moments per step (row stride `gstride` doubles)
@@ -136,7 +137,7 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
                            bool write_state, bool solve_from_moments = false);
 
 // valuation of (sx,tex): sums into w.result ; tval = 1 (reference flows) or 0 (textbook);
-// use_flags: state of the per-step reference sweep (w.ex: unexercised paths take (S_N, N)),
+// use_flags: state of the per-step reference sweep (w.live: unexercised paths take (S_N, N)),
 // fill_state: also write that into sx / tex
 hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int tval,
                             bool use_flags = false, bool fill_state = false);

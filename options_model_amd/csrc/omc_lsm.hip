@@ -180,7 +180,7 @@ static void fill_step_args(StepArgs& a, const LsmProblem& p, const LsmWorkspace&
 {
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
     a.K = p.K; a.invK = 1.0 / p.K;
-    a.sx = w.sx; a.tex = w.tex; a.ex = w.ex; a.D = w.D; a.part = w.part; a.gmom = w.gmom; a.betas = w.betas;
+    a.sx = w.sx; a.tex = w.tex; a.live = w.live; a.D = w.D; a.part = w.part; a.gmom = w.gmom; a.betas = w.betas;
     a.t = t; a.nblk = lsm_sweep_blocks(p.M); a.external = external_moments ? 1 : 0;
     a.pstride = kPStride;
     a.gstride = w.gstride;
@@ -234,7 +234,7 @@ size_t lsm_sweep_args_bytes() { return sizeof(SweepArgs); }
 static void fill_final_args(FinalArgs& a, const LsmProblem& p, const LsmWorkspace& w, int tval, bool use_flags,
                             bool fill_state)
 {
-    a.sx = w.sx; a.tex = w.tex; a.ex = use_flags ? w.ex : nullptr; a.SN = p.S + (int64_t)p.N * p.ld;
+    a.sx = w.sx; a.tex = w.tex; a.live = use_flags ? w.live : nullptr;
     a.M = p.M; a.N = p.N; a.is_put = p.is_put; a.tval = tval; a.fill_state = fill_state ? 1 : 0;
     a.K = p.K; a.D = w.D; a.part = w.part;
     a.nblk = lsm_step_blocks(p.M); a.pstride = kPStride;

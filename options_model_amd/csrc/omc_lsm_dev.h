@@ -66,7 +66,8 @@ struct StepArgs {
     double K, invK;
     float* sx;
     int32_t* tex;
-    uint8_t* ex;  // SEM 0: sticky "exercised" flag per path (sx / tex are then only WRITTEN, at exercise)
+    float* live;  // SEM 0: the path's TERMINAL spot S_N while it has not exercised, a negative value once it has
+                  // (sticky; sx / tex are then only WRITTEN, at exercise): state and regression target in one row
     const double* D;
     double* part;
     double* gmom;
@@ -92,8 +93,9 @@ struct StepArgs {
 //   epilogue  per-workgroup partial moments of step t-1 -> part[(t-1)&1]
 // SEM 0: sticky "exercised" mask (reference per-step flow, Options_model.py:108-150).  A path in the
 //        regression set has by construction never exercised, so its cash-flow is the discounted
-//        TERMINAL payoff: the loop reads S_t, S_{t-1}, S_N and a one-byte flag (13 bytes per path and
-//        step) and writes (sx, tex, flag) only when a path exercises -- at most once per path.
+//        TERMINAL payoff: the loop reads S_t, S_{t-1} and the path's `live` value -- S_N while it is in
+//        play, negative once it has exercised -- i.e. 12 bytes per path and step (round 2 read S_N from the
+//        matrix plus a flag byte: 13), and writes (sx, tex, live) only when a path exercises -- once per path.
 // SEM 1: textbook LSM: the cash-flow of every in-the-money path is payoff(sx) D[tex - t]: state
 //        (sx, tex) is read every step (16 bytes per path and step).
 //
@@ -172,12 +174,11 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int
     // at ~6.2 TB/s of the 13 bytes per path once several pricings share a launch; the second buffer costs 13 VGPRs.
     const float* St = a.S + (int64_t)t * a.ld;
     const float* Sm = St - a.ld;
-    const float* Sn = a.S + (int64_t)N * a.ld;
     const int64_t stride = (int64_t)a.nblk * BLOCK * VEC;
     struct Chunk {
-        float st[VEC], sm[VEC], sx[VEC];  // sx: SEM 0 terminal spot S_N, SEM 1 spot at the current exercise time
+        float st[VEC], sm[VEC], sx[VEC];  // sx: SEM 0 the `live` values (S_N, or < 0: exercised), SEM 1 spot at the exercise time
         int32_t tex[VEC];                 // SEM 1 only
-        uint32_t exw;                     // SEM 0: VEC flag bytes
+        uint32_t exw;                     // SEM 0: bit 8v set = path v of the chunk has exercised
         int64_t j;                        // first column of the chunk; >= M: nothing there for this lane
     };
     auto load_chunk = [&](Chunk& c) {
@@ -185,9 +186,7 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int
         if (do_mom) loadf<VEC>(Sm + c.j, c.sm);
         if (!init) {
             if (SEM == 0) {
-                loadf<VEC>(Sn + c.j, c.sx);
-                if constexpr (VEC == 4) c.exw = *reinterpret_cast<const uint32_t*>(a.ex + c.j);
-                else c.exw = a.ex[c.j];
+                loadf<VEC>(a.live + c.j, c.sx);
             } else {
                 loadf<VEC>(a.sx + c.j, c.sx);
                 loadi<VEC>(a.tex + c.j, c.tex);
@@ -287,13 +286,14 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int
         const int64_t j = c.j;
         if (j < a.M) {
             if (SEM == 0) {
-                if (init) {
-                    c.exw = 0;
+                if (init) {  // t == N: every path is in play, its live value is its terminal spot
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) c.sx[v] = c.st[v];
-                    if constexpr (VEC == 4) *reinterpret_cast<uint32_t*>(a.ex + j) = 0u;
-                    else a.ex[j] = 0;
+                    storef<VEC>(a.live + j, c.sx);
                 }
+                c.exw = 0;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) c.exw |= c.sx[v] < 0.0f ? 1u << (8 * v) : 0u;
                 if (fit_ok) {
                     uint32_t neww = c.exw;
 #pragma unroll
@@ -306,14 +306,11 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int
                                 neww |= 1u << (8 * v);
                                 a.sx[j + v] = c.st[v];
                                 a.tex[j + v] = t;
+                                a.live[j + v] = -1.0f;
                             }
                         }
                     }
-                    if (neww != c.exw) {
-                        c.exw = neww;
-                        if constexpr (VEC == 4) *reinterpret_cast<uint32_t*>(a.ex + j) = neww;
-                        else a.ex[j] = (uint8_t)neww;
-                    }
+                    c.exw = neww;
                 }
                 if (do_mom) {
 #pragma unroll
@@ -802,8 +799,7 @@ __device__ __forceinline__ void lsm_pass2_body(Pass2Args a)
 struct FinalArgs {
     float* sx;
     int32_t* tex;
-    const uint8_t* ex;  // per-step reference flow: flag 0 = never exercised -> (S_N, N); else null
-    const float* SN;    // terminal row (used with `ex`)
+    const float* live;  // per-step reference flow: >= 0 = never exercised, the value is S_N -> (S_N, N); else null
     int64_t M;
     int N, is_put, tval, fill_state;  // fill_state: write (S_N, N) into sx / tex of unexercised paths
     double K;
@@ -827,16 +823,13 @@ __device__ __forceinline__ void lsm_final_body(FinalArgs a)
         int32_t tex[VEC];
         loadf<VEC>(a.sx + j, sx);
         loadi<VEC>(a.tex + j, tex);
-        if (a.ex) {
+        if (a.live) {
             float sn[VEC];
-            loadf<VEC>(a.SN + j, sn);
-            uint32_t exw;
-            if constexpr (VEC == 4) exw = *reinterpret_cast<const uint32_t*>(a.ex + j);
-            else exw = a.ex[j];
+            loadf<VEC>(a.live + j, sn);
             bool any = false;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                if (((exw >> (8 * v)) & 0xffu) == 0u) { sx[v] = sn[v]; tex[v] = a.N; any = true; }
+                if (!(sn[v] < 0.0f)) { sx[v] = sn[v]; tex[v] = a.N; any = true; }
             }
             if (a.fill_state && any) {
                 storef<VEC>(a.sx + j, sx);

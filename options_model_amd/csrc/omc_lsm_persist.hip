@@ -50,7 +50,7 @@ struct PersistArgs {
     double K, invK;
     float* sx;
     int32_t* tex;
-    uint8_t* ex;
+    float* live;  // state the valuation kernel reads: S_N for a path that never exercised, negative otherwise
     const double* D;
     double* gmom;
     double* betas;
@@ -382,7 +382,12 @@ __global__ __launch_bounds__(kPersistBlock) void lsm_sweep_persist_kernel(Persis
                 }
             }
             if (a.write_state) {
-                *reinterpret_cast<uint32_t*>(a.ex + j0 + c * cstride) = flags;
+                {
+                    float lv[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) lv[v] = ((flags >> (8 * v)) & 0xffu) ? -1.0f : sn4[v];
+                    *reinterpret_cast<float4*>(a.live + j0 + c * cstride) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+                }
                 if (any) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
@@ -440,7 +445,7 @@ hipError_t lsm_sweep_persistent(hipStream_t st, const LsmProblem& p, const LsmWo
 {
     PersistArgs a;
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put; a.K = p.K; a.invK = 1.0 / p.K;
-    a.sx = w.sx; a.tex = w.tex; a.ex = w.ex; a.D = w.D; a.gmom = w.gmom; a.betas = w.betas; a.part = w.part;
+    a.sx = w.sx; a.tex = w.tex; a.live = w.live; a.D = w.D; a.gmom = w.gmom; a.betas = w.betas; a.part = w.part;
     a.gran = (unsigned long long*)scratch;
     a.bgran = a.gran + 2 * kStepMaxBlocks * 16;
     a.err = (unsigned int*)(a.bgran + 2 * 16);
