@@ -59,3 +59,69 @@ def test_fused_pricing_matches_oracle(ctx, case):
     assert abs(res["price"] - ref["price"]) <= 1e-9 * max(abs(ref["price"]), 1e-12) + 1e-15
     assert (res["n_exercised"], res["n_zero"], res["sum_nitm"]) == (ref["n_exercised"], ref["n_zero"],
                                                                     ref["sum_nitm"])
+
+
+def _seq_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        model = "heston" if rng.random() < 0.25 else "gbm"
+        anti = True if model == "heston" else bool(rng.integers(0, 2))
+        M = int(rng.choice([2, 6, 64, 254, 1000, 1026, 4096, 4100, 8192, 33_334, 262_144, 300_002]))
+        if not anti and rng.random() < 0.5:
+            M += 1
+        out.append(dict(model=model, antithetic=anti, M=M, N=int(rng.choice([1, 2, 3, 5, 9, 16, 33])),
+                        sem=str(rng.choice(["reference", "textbook"])), n=int(rng.choice([2, 3, 5, 8, 17])),
+                        k=int(rng.choice([-1, 2, 3, 7, 32])), seed=int(rng.integers(1, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("case", _seq_cases(24, 20261004), ids=lambda c: f"{c['model']}-{c['sem']}-{c['M']}x{c['N']}-n{c['n']}-k{c['k']}")
+def test_sequences_sharing_their_launches_match_single_calls(ctx, case):
+    """Round 3: K pricings per launch of the per-timestep kernel.  Random geometry, sequence length and batch width:
+    every pricing of the sequence returns the bits of its own call (which the test above ties to the oracle)."""
+    from options_model_amd import _ffi
+    c = case
+    rng = np.random.default_rng(c["seed"])
+    ps = [_ffi.make_params(model=c["model"], antithetic=c["antithetic"], semantics=c["sem"], n_paths=c["M"], n_steps=c["N"],
+                           seed=c["seed"], stream=i, is_put=bool(rng.integers(0, 2)), K=float(rng.choice([95.0, 100.0, 100.5])),
+                           S0=float(rng.choice([90.0, 100.0, 115.0])), sigma=float(rng.choice([0.15, 0.3])), xi=0.4, theta=0.05)
+          for i in range(c["n"])]
+    ctx.set_option("seq_step_k", c["k"])
+    try:
+        seq = ctx.price_american_seq(ps)
+    finally:
+        ctx.set_option("seq_step_k", -1)
+    for p, s in zip(ps, seq):
+        one = ctx.price_american(p)
+        for k in ("price", "sum", "sumsq", "n_exercised", "n_zero", "sum_nitm", "n_paths"):
+            assert s[k] == one[k], (k, s[k], one[k])
+
+
+def _cn_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        probs = []
+        for _ in range(int(rng.integers(1, 9))):
+            probs.append(dict(M=int(rng.choice([64, 510, 1000, 1026, 4096, 10_000, 10_002])), N=int(rng.choice([2, 3, 5, 10, 17, 40])),
+                              S0=float(rng.choice([70.0, 95.0, 100.0, 130.0])), T=float(rng.choice([0.02, 0.25, 1.0])),
+                              is_put=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 2 ** 31)),
+                              nn_seed=int(rng.integers(0, 2 ** 40))))
+        out.append(dict(probs=probs, hidden=int(rng.choice([5, 32, 33, 64])), epochs=int(rng.choice([0, 1, 3, 10]))))
+    return out
+
+
+@pytest.mark.parametrize("case", _cn_cases(10, 77), ids=lambda c: f"h{c['hidden']}-e{c['epochs']}-n{len(c['probs'])}")
+def test_contnet_batches_match_single_calls(ctx, case):
+    """Round 3: the v1 / v2 regressor for many pricings at once; random mixes of sizes (incl. ones without 16-byte
+    access), widths and epoch counts (0 epochs: the fresh net decides): batch == single calls, bit for bit."""
+    from options_model_amd import _ffi
+    ps = [_ffi.make_params(semantics="reference", n_paths=q["M"], n_steps=q["N"], S0=q["S0"], T=q["T"], is_put=q["is_put"],
+                           seed=q["seed"]) for q in case["probs"]]
+    seeds = [q["nn_seed"] for q in case["probs"]]
+    batch = ctx.price_american_contnet_batch(ps, case["hidden"], case["epochs"], 1e-3, seeds)
+    for p, s, b in zip(ps, seeds, batch):
+        one = ctx.price_american_contnet(p, case["hidden"], case["epochs"], 1e-3, s)
+        for k in ("price", "sum", "sumsq", "n_exercised", "n_zero", "sum_nitm", "n_paths"):
+            assert b[k] == one[k], (k, b[k], one[k])
