@@ -565,10 +565,12 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
             for (int v = 0; v < VEC; ++v) u2[v] = u[v] * u[v];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
+#ifndef OMC_EXP_USUMS  // (experiment build: the four target-free sums are the generator's job, see omc_paths_dev.h)
                 acc[1] += u[v];
                 acc[2] += u2[v];
                 acc[3] = fma(u2[v], u[v], acc[3]);
                 acc[4] = fma(u2[v], u2[v], acc[4]);
+#endif
                 acc[5] = fma(pN[k][v], m[v], acc[5]);
                 acc[6] = fma(u[v], pN[k][v], acc[6]);
                 acc[7] = fma(u2[v], pN[k][v], acc[7]);

@@ -49,6 +49,14 @@ struct PathArgs {
     uint64_t pair_offset;
 };
 
+#ifdef OMC_EXP_USUMS
+// EXPERIMENT BUILD ONLY (-DOMC_EXP_USUMS, tools/exp_usums.sh): what would it cost the store-bound generator to also
+// form the four regression sums that need no target (sum u .. sum u^4 over the in-the-money paths, u = S/K - 1) per
+// time step, so that pass 1 could drop them?  K = 100, put, hard-wired; per step a wave reduction and one store of
+// the wave's partials into a scratch array.  Results of the pricing are unaffected (nothing reads the scratch).
+__device__ double g_exp_usums[256 * 2048 * 8];
+#endif
+
 template <int VEC, bool ANTI>
 __device__ __forceinline__ void gbm_paths_body(const PathArgs& g)
 {
@@ -87,6 +95,30 @@ __device__ __forceinline__ void gbm_paths_body(const PathArgs& g)
                     sa[v] = sa[v] * fast_exp2(__builtin_fmaf(-b, z[v][i], a));
                 store_vec<VEC>(row + P, sa);
             }
+#ifdef OMC_EXP_USUMS
+            {
+                __shared__ double wl_exp[kBlock / 64][kWaveRedDoubles];
+                double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                auto add = [&](float sv) {
+                    const double m = sv < 100.0f ? 1.0 : 0.0;
+                    const double u = fma((double)sv, 0.01, -1.0) * m;
+                    const double u2 = u * u;
+                    acc[1] += u;
+                    acc[2] += u2;
+                    acc[3] = fma(u2, u, acc[3]);
+                    acc[4] = fma(u2, u2, acc[4]);
+                };
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    add(s[v]);
+                    if (ANTI) add(sa[v]);
+                }
+                const double sred = wave_reduce8(acc, wl_exp[threadIdx.x >> 6]);
+                const int wave_id = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+                if ((threadIdx.x & 7) == 0 && t < 256 && wave_id < 2048)
+                    g_exp_usums[((size_t)t * 2048 + wave_id) * 8 + ((threadIdx.x & 63) >> 3)] = sred;
+            }
+#endif
         }
     }
 }
