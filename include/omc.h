@@ -368,8 +368,8 @@ int omc_price_american_seq(omc_ctx* ctx, const omc_params* p, int n, omc_result*
  * matrices resident, one launch boundary per time step for all K, and across GPUs the K moment vectors of a step in
  * ONE all-reduce of 8K doubles.  One pricing alone is latency-bound (13 MB and ~6 us per launch at 1M paths); K of
  * them fill the chip.  res[i] still carries the bits of omc_price_american(p[i]): the summation tree of a pricing
- * does not depend on K.  Option "seq_step_k": -1 = default (as many as keep one launch's rows inside the 256 MB
- * Infinity Cache, at most 16: 16 at 1M paths), 1 = off, k <= 32; K is further limited by a byte
+ * does not depend on K.  Option "seq_step_k": -1 = default (as many as keep one launch within ~200 MB, at most 32:
+ * 16 at 1M paths, 32 at 250k), 1 = off, k <= 32; K is further limited by a byte
  * budget for the resident matrices (OMC_SEQ_STEP_BYTES, default 64e9).  This returns the K a sequence would use
  * (1 = one pricing at a time, 0 = invalid arguments). */
 int omc_seq_step_width(omc_ctx* ctx, const omc_params* p, int n);

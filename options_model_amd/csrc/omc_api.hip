@@ -1396,13 +1396,13 @@ static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
     static const int env_k = getenv("OMC_SEQ_STEP_K") ? atoi(getenv("OMC_SEQ_STEP_K")) : -1;
     int k = c->seq_step_k >= 0 ? c->seq_step_k : env_k;
     if (k < 0) {
-        // default: as many pricings as keep one launch's rows and state inside the 256 MB Infinity Cache (a launch
-        // re-reads S_t, S_N and the flags its predecessor touched: measured at 1M paths, 16 pricings per launch
-        // 0.66 of the HBM roofline, 32 -- 416 MB per launch -- 0.53), at most 16; problems so large that fewer
-        // than 4 fit are bandwidth-bound one at a time already (8M paths: 0.62 alone, 0.61 with 4 per launch)
+        // default: as many pricings as keep one launch's rows and state within ~200 MB (measured, tools/exp_step_k.py:
+        // at 1M paths the pricing rate rises up to 16-20 pricings per launch -- 0.66 of the HBM roofline -- and falls
+        // beyond 240 MB per launch; 250k-path pricings still gain at 32), at most 32; problems so large that fewer
+        // than 4 fit are bandwidth-bound one at a time already (8M paths: 0.62 alone, 0.59 with 4 per launch)
         const double per = (p[0].semantics == OMC_SEM_REFERENCE ? 12.0 : 16.0) * (double)p[0].n_paths;
-        k = (int)(2.2e8 / per);
-        if (k > 16) k = 16;
+        k = (int)(2.0e8 / per);
+        if (k > 32) k = 32;
         if (k < 4) k = 1;
     }
     if (k < 2) return 1;
