@@ -138,12 +138,16 @@ class RcclPricer(_ShardedBase):
     raise.  A rank that never votes makes the others raise TimeoutError after `timeout_s`."""
 
     transport = "rccl-native"
+    _generation = 0  # communicators brought up by this process so far (every rank counts the same way): the votes
+                     # of one bring-up can never be taken for those of another
 
     def __init__(self, local_rank: int, rank: int, world: int, tag: str | None = None, timeout_s: float = 120.0,
                  init_timeout_s: float = 300.0):
         from . import _ffi, rendezvous
 
         self._ffi = _ffi
+        RcclPricer._generation += 1
+        self._gen = gen = RcclPricer._generation
         self.rank, self.world = int(rank), int(world)
         self.ctx = _ffi.Context(local_rank)
         marker = b"OMC_RCCL_UNAVAILABLE"
@@ -156,12 +160,13 @@ class RcclPricer(_ShardedBase):
                 why.append(f"rank 0 has no unique id: {e}")
                 return marker.ljust(128, b"\0")
 
-        uid, path = rendezvous.exchange(self.rank, make_uid, 128, tag, timeout_s)
+        uid_tag = (rendezvous.default_tag() if tag is None else tag) + f"_g{gen}"
+        uid, path = rendezvous.exchange(self.rank, make_uid, 128, uid_tag, timeout_s)
         ok = not uid.startswith(marker)
         if not ok and not why:
             why.append("rank 0 has no unique id (see its log)")
         try:
-            all_ok = rendezvous.agree(self.rank, self.world, ok, "uid", tag, timeout_s)
+            all_ok = rendezvous.agree(self.rank, self.world, ok, f"uid{gen}", tag, timeout_s)
         finally:
             if path:
                 rendezvous.retire(path)  # every rank has voted, i.e. has read the id
@@ -180,7 +185,7 @@ class RcclPricer(_ShardedBase):
             why.append(f"omc_comm_init failed on rank {self.rank}: {e}")
         finally:
             dog.cancel()
-        all_ok = rendezvous.agree(self.rank, self.world, ok, "init", tag, max(timeout_s, init_timeout_s))
+        all_ok = rendezvous.agree(self.rank, self.world, ok, f"init{gen}", tag, max(timeout_s, init_timeout_s))
         if not all_ok:
             try:
                 if ok:
@@ -205,7 +210,7 @@ class RcclPricer(_ShardedBase):
         stage and either ALL end up connected (True) or all stay with the collective (False).  The communicator
         keeps doing everything else."""
         from . import rendezvous
-        base = (rendezvous.default_tag() if tag is None else tag) + "_p2p"
+        base = (rendezvous.default_tag() if tag is None else tag) + f"_p2p{self._gen}"
         handle, ok = b"\0" * 64, True
         try:
             handle = self.ctx.p2p_export()
@@ -213,7 +218,7 @@ class RcclPricer(_ShardedBase):
             ok = False
         path = rendezvous.publish(handle, f"{base}_h{self.rank}")
         try:
-            if not rendezvous.agree(self.rank, self.world, ok, "p2p_export", tag, timeout_s):
+            if not rendezvous.agree(self.rank, self.world, ok, f"p2p_export{self._gen}", tag, timeout_s):
                 if ok:
                     self.ctx.p2p_disconnect()
                 return False
@@ -222,7 +227,7 @@ class RcclPricer(_ShardedBase):
                 self.ctx.p2p_connect(self.rank, self.world, handles)
             except Exception:
                 ok = False
-            if not rendezvous.agree(self.rank, self.world, ok, "p2p_connect", tag, timeout_s):
+            if not rendezvous.agree(self.rank, self.world, ok, f"p2p_connect{self._gen}", tag, timeout_s):
                 self.ctx.p2p_disconnect()
                 return False
             return True
