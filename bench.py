@@ -211,8 +211,9 @@ def main():
     ap.add_argument("--only-timed", action="store_true",
                     help="warm-up + timed region only (for rocprofv3 --pmc passes: every dispatch of a kernel is then "
                          "the same workload): no per-step extra, sustained loop, price check, variants, CPU baseline")
-    ap.add_argument("--group", type=int, default=10,
-                    help="pricings enqueued per omc_price_american_seq call (one host wait per group)")
+    ap.add_argument("--group", type=int, default=None,
+                    help="pricings enqueued per omc_price_american_seq call (one host wait -- and, across GPUs, one result "
+                         "collective -- per group); default: all --steps in one group, at most 50")
     ap.add_argument("--sync-every-step", action="store_true",
                     help="one synchronous omc_price_american call per step instead")
     ap.add_argument("--backend", default=None, choices=["rccl", "nccl", "gloo"],
@@ -234,6 +235,8 @@ def main():
     ap.add_argument("--kernel-samples", type=int, default=8,
                     help="at least this many pricings of the timed region carry their own HIP events")
     a = ap.parse_args()
+    if a.group is None:
+        a.group = max(1, min(a.steps, 50))
     if a.only_timed:
         a.no_cpu_baseline = a.no_variants = a.no_sustained = True
     if a.gpus < 1:
