@@ -225,3 +225,53 @@ def test_the_drivers_launch_form_torchrun_native_communicator(ctx, standin):
     ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=2 * M_PER_GPU, n_steps=N, seed=42, stream=3))
     assert d["price"] == pytest.approx(ref["price"], rel=1e-12)
     assert d["sustained"]["pricings"] > 0 and d["clock_settled"] in (True, False)
+
+
+_P2P_LOST = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+from options_model_amd import _ffi
+from options_model_amd.dist import RcclPricer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+sp = RcclPricer(0, rank, world)
+assert sp.enable_p2p()
+kw = dict(semantics="reference", n_steps=12, seed=9)
+sp.price_american(40_000 * world, stream=1, **kw)          # one good pricing: the mailboxes work
+if rank == 1:
+    time.sleep(20)                                           # rank 1 goes missing (it never sends another contribution)
+    os._exit(0)
+t0 = time.monotonic()
+try:
+    sp.price_american(40_000 * world, stream=2, **kw)
+    print("RESULT no error")
+except _ffi.OmcError as e:
+    print("RESULT error after %%.1f s: %%s" %% (time.monotonic() - t0, e))
+    print("STATUS", sp.ctx.p2p_status())
+os._exit(0)
+"""
+
+
+def test_a_lost_peer_ends_the_direct_exchange_with_an_error_not_a_hang(standin, tmp_path):
+    """Bounded waits: when a peer's contribution never arrives, the exchange kernel gives up at its deadline, marks the
+    mailbox (sticky: later exchanges of the call return at once) and the pricing call FAILS with error 3100 -- it does
+    not hang and it does not return a price built on missing data."""
+    script = tmp_path / "p2p_lost.py"
+    script.write_text(_P2P_LOST % ROOT)
+    port = 29950 + os.getpid() % 40
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMC_RCCL_LIB=standin, OMC_RDZV_NONCE=f"lost{os.getpid()}",
+                   OMC_STANDIN_TIMEOUT_S="4")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    t0 = time.monotonic()
+    so, se = procs[0].communicate(timeout=120)
+    took = time.monotonic() - t0
+    procs[1].communicate(timeout=120)
+    assert procs[0].returncode == 0, se[-2000:]
+    line = [ln for ln in so.splitlines() if ln.startswith("RESULT")][0]
+    assert "error after" in line and "direct peer exchange" in line, (line, se[-1500:])
+    status = [ln for ln in so.splitlines() if ln.startswith("STATUS")][0]
+    assert status.endswith(", 1)"), status       # the sticky error word
+    assert took < 60
