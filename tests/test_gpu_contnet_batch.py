@@ -91,3 +91,26 @@ def test_timings_of_the_ui_jobs(ctx):
     assert len(out) == 1620 and all(o["price"] > 0 for o in out[:180])
     assert ms1 <= 8.0          # (round 2: 8.4 ms with a host read-back per step; the chain is ~25 dependent launches per time step)
     assert t_job <= 0.3        # (round 2: ~4 s on 8 host threads)
+
+
+def test_edge_cases_one_step_two_paths_empty_sets(ctx):
+    """Edges of the batched ContNet flow: a one-step problem (no regression step at all), two paths, a deep
+    out-of-the-money call whose regression sets are empty at every step, a batch of one -- all equal to single calls."""
+    from options_model_amd import _ffi
+    ps = [_ffi.make_params(semantics="reference", n_paths=2, n_steps=1, seed=3),
+          _ffi.make_params(semantics="reference", n_paths=2, n_steps=7, seed=4),
+          _ffi.make_params(semantics="reference", n_paths=4096, n_steps=1, seed=5, is_put=False),
+          _ffi.make_params(semantics="reference", n_paths=4096, n_steps=9, seed=6, is_put=False, S0=20.0, K=100.0, T=0.05),
+          _ffi.make_params(semantics="reference", n_paths=10_000, n_steps=130, seed=7, S0=100.0, T=90.0 / 365)]
+    batch = ctx.price_american_contnet_batch(ps, 32, 10, 1e-3, [1, 2, 3, 4, 5])
+    for i, (p, b) in enumerate(zip(ps, batch)):
+        one = ctx.price_american_contnet(p, 32, 10, 1e-3, i + 1)
+        for k in KEYS:
+            assert b[k] == one[k] or (b[k] != b[k] and one[k] != one[k]), (i, k, b[k], one[k])
+    assert batch[3]["price"] == 0.0 and batch[3]["sum_nitm"] == 0          # never in the money: no net was ever trained
+    alone = ctx.price_american_contnet_batch([ps[4]], 32, 10, 1e-3, 5)[0]
+    assert alone["price"] == batch[4]["price"] and alone["sum_nitm"] == batch[4]["sum_nitm"]
+    with pytest.raises(ValueError):
+        ctx.price_american_contnet_batch([_ffi.make_params(semantics="two_pass", n_paths=64, n_steps=3)], 32, 10, 1e-3, 0)
+    with pytest.raises(ValueError):
+        ctx.price_american_contnet_batch(ps[:2], 200, 10, 1e-3, 0)      # nn_hidden beyond 128
