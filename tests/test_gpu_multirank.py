@@ -275,3 +275,21 @@ def test_a_lost_peer_ends_the_direct_exchange_with_an_error_not_a_hang(standin, 
     status = [ln for ln in so.splitlines() if ln.startswith("STATUS")][0]
     assert status.endswith(", 1)"), status       # the sticky error word
     assert took < 60
+
+
+def test_config3_shard_size_through_the_native_communicator(ctx, standin):
+    """BASELINE configs[2] is 64M paths over 8 GPUs = 8M-path shards.  Four such shards (the test box admits four rank
+    processes on its card; 65 GB of path matrices incl. the overlapped sequence's second buffers) priced through the
+    native-communicator path must equal the ONE-GPU pricing of the same 32M paths: global pair offsets, the
+    decision-independent moment all-reduce and the result collective at config 3's per-GPU size."""
+    from options_model_amd import _ffi
+    out, took = _bench(["--gpus", "4", "--single-device", "--backend", "rccl", "--config", "c3", "--steps", "2", "--warmup",
+                        "1", "--min-warmup-seconds", "0.05", "--no-variants", "--no-cpu-baseline", "--no-sustained"],
+                       standin, timeout=600)
+    d = _line(out)
+    assert d["rccl_ranks"] == 4 and d["config"]["paths_per_gpu"] == 8_000_000 and d["seq_overlap"] == "on"
+    ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=32_000_000, n_steps=252, seed=42, stream=1))
+    assert d["price"] == pytest.approx(ref["price"], rel=1e-12)
+    lp = d["last_pricing"]
+    assert (lp["n_paths"], lp["n_exercised"], lp["sum_nitm"]) == (32_000_000, ref["n_exercised"], ref["sum_nitm"])
+    assert d["price_check"]["rel_err"] < 1e-3
