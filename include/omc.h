@@ -80,7 +80,20 @@ int omc_abi_version(void);
 const char* omc_last_error(void);
 int omc_device_count(int* count);
 /* hip_stream == NULL: the context creates its own stream; else it borrows the caller's
- * (e.g. torch.cuda.current_stream().cuda_stream) and never destroys it. */
+ * (e.g. torch.cuda.current_stream().cuda_stream) and never destroys it.
+ *
+ * Stream ordering of borrowed device pointers (the entry/exit contract):
+ *   exit   every entry point returns after the context's stream has drained, so whatever the caller
+ *          enqueues afterwards, on any stream, sees the library's writes.
+ *   entry  a context that BORROWS a stream is ordered by that stream: the caller's pending work on it
+ *          precedes the library's.  A context that OWNS its stream (hip_stream == NULL; created with
+ *          hipStreamNonBlocking, so the null stream's implicit synchronisation does not apply to it) orders
+ *          itself, on entry of every call that takes a device pointer from the caller, after everything then
+ *          pending on the device's DEFAULT (null) stream -- the stream PyTorch queues on unless told otherwise
+ *          -- by an event wait; no host blocking.  Work the caller has pending on any OTHER stream (a torch
+ *          side stream, its own non-blocking streams) is not ordered: synchronise that stream first, or create
+ *          the context on it.  The options_model_amd modules that hand torch tensors to the library create their
+ *          contexts on torch's current stream (nn_regressor._ctx_on_torch_stream). */
 int omc_ctx_create(int device, void* hip_stream, omc_ctx** out);
 int omc_ctx_destroy(omc_ctx* ctx);
 int omc_sync(omc_ctx* ctx);

@@ -92,6 +92,7 @@ struct omc_ctx {
     double *seq_pin = nullptr, *seq_dev = nullptr;  // omc_price_american_seq: one 8-double slot per pricing
     int seq_cap = 0;
     hipEvent_t ev_seq = nullptr;
+    hipEvent_t ev_entry = nullptr;  // bind_in(): orders a context-owned stream after the device's default stream
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // omc_price_american_seq: further event sets (7 each) for the pricings of a sequence that carry their own
     // kernel timings ("seq_event_stride": every k-th pricing; 0 = the first one only)
@@ -171,6 +172,24 @@ int bind(omc_ctx* c)
 {
     if (!c) return fail(-7, "null context.");
     HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+// Entry of every call that takes BORROWED device pointers.  A context that owns its stream creates it with
+// hipStreamNonBlocking, so nothing orders it after work the caller still has in flight on the device's default
+// (null) stream -- which is where PyTorch queues the torch.full / torch.empty / copy that produced the pointer.
+// Record a marker on the null stream and make the context's stream wait for it: asynchronous, a few microseconds
+// of host time, and the caller's producer is then always ahead of the library's consumer.  A context that borrows
+// the caller's stream is ordered by that stream itself.  (Work on OTHER caller streams is the caller's to order:
+// include/omc.h, "stream ordering".)
+int bind_in(omc_ctx* c)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->own_stream) return 0;
+    if (!c->ev_entry) HIP_TRY(hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_entry, nullptr));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_entry, 0));
     return 0;
 }
 
@@ -558,6 +577,7 @@ int omc_ctx_destroy(omc_ctx* c)
     if (c->hres_pin) (void)hipHostFree(c->hres_pin);
     if (c->seq_pin) (void)hipHostFree(c->seq_pin);
     if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
+    if (c->ev_entry) (void)hipEventDestroy(c->ev_entry);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -582,7 +602,7 @@ int omc_alloc(omc_ctx* c, size_t bytes, void** dptr)
 
 int omc_free(omc_ctx* c, void* dptr)
 {
-    int rc = bind(c);
+    int rc = bind_in(c);
     if (rc) return rc;
     if (dptr) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -593,7 +613,7 @@ int omc_free(omc_ctx* c, void* dptr)
 
 int omc_memcpy_h2d(omc_ctx* c, void* dst, const void* src, size_t bytes)
 {
-    int rc = bind(c);
+    int rc = bind_in(c);
     if (rc) return rc;
     if (!bytes) return 0;
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -603,7 +623,7 @@ int omc_memcpy_h2d(omc_ctx* c, void* dst, const void* src, size_t bytes)
 
 int omc_memcpy_d2h(omc_ctx* c, void* dst, const void* src, size_t bytes)
 {
-    int rc = bind(c);
+    int rc = bind_in(c);
     if (rc) return rc;
     if (!bytes) return 0;
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -778,7 +798,7 @@ int omc_gbm_paths_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, int n_s
                       uint64_t pair_offset, int antithetic)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
     if (!(sigma > 0)) return fail(-5, "S0, K, T, and sigma must be positive.");
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
@@ -796,7 +816,7 @@ int omc_heston_paths_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, int 
                          int scheme)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
     if (!(rho >= -1.0 && rho <= 1.0) || !(v0 >= 0)) return fail(-5, "invalid Heston parameters.");
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
@@ -815,7 +835,7 @@ int omc_gbm_paths_from_normals_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_p
                                    int64_t ldz, int antithetic)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -834,7 +854,7 @@ int omc_heston_paths_from_normals_f32(omc_ctx* c, float* S, int64_t ld, int64_t 
                                       const float* Z1, const float* Z2, int64_t ldz, int scheme)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -851,7 +871,7 @@ int omc_heston_paths_from_normals_f32(omc_ctx* c, float* S, int64_t ld, int64_t 
 int omc_philox4x32_10(omc_ctx* c, const uint32_t* in, uint32_t* out, int n)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if (!in || !out || n <= 0) return fail(-7, "bad arguments.");
     if ((rc = c->scratch.ensure(sizeof(uint32_t) * 10 * (size_t)n))) return rc;
     uint32_t* din = (uint32_t*)c->scratch.p;
@@ -867,7 +887,7 @@ int omc_gbm_normals_f32(omc_ctx* c, float* Z, int64_t ldz, int64_t n_pairs, int 
                         uint64_t seed, uint64_t stream, uint64_t pair_offset)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if (!Z || n_pairs <= 0 || n_steps <= 0 || ldz < n_pairs) return fail(-7, "bad arguments.");
     HIP_TRY(omc::launch_gbm_normals(c->stream, Z, ldz, n_pairs, n_steps, seed, (uint32_t)stream,
                                     pair_offset));
@@ -881,7 +901,7 @@ int omc_lsm_poly(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
                  float* sx_out, int32_t* tex_out)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if ((rc = check_market(1.0, K, T, r))) return rc;
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -916,7 +936,7 @@ int omc_lsm_apply_frozen(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths
                          omc_result* res, float* sx_out, int32_t* tex_out)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if ((rc = check_market(1.0, K, T, r))) return rc;
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -945,7 +965,7 @@ int omc_lsm_apply_values(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths
                          omc_result* res, float* sx_out, int32_t* tex_out)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if ((rc = check_market(1.0, K, T, r))) return rc;
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -1085,7 +1105,7 @@ static inline int seq_sample_index(const omc_ctx* c, int i)
 int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* S_keep, int64_t ld)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = S_keep ? bind_in(c) : bind(c))) return rc;  // only a caller-provided path matrix is borrowed memory
     if ((rc = check_params(p))) return rc;
     if (!res) return fail(-7, "null result pointer.");
     // Single GPU: the finalize kernel stores its 8 sums straight into host-mapped pinned memory (no copy
@@ -1200,7 +1220,7 @@ int omc_lsm_contnet(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int
                     omc_result* res, float* sx_out, int32_t* tex_out)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if ((rc = check_market(1.0, K, T, r))) return rc;
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -1218,7 +1238,7 @@ int omc_lsm_contnet(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int
 int omc_contnet_init_params(omc_ctx* c, int nn_hidden, int t, uint64_t nn_seed, float* params_out, int n)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     const int H = omc::cn_padded_width(nn_hidden);
     if (nn_hidden < 1 || H < 0) return fail(-4, "nn_hidden must be in 1 .. 128.");
     const int np = omc::mlp_train_param_count(H, 2);
@@ -1638,7 +1658,7 @@ int omc_heston_price_strikes(omc_ctx* c, int64_t n_paths, int n_steps, double S0
                              int n_strikes, int is_put, double* prices, double* stderrs)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if (!(S0 > 0) || !(T > 0)) return fail(-1, "S0, K, T must be positive.");
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if (n_paths & 1) return fail(-3, "antithetic layout needs an even n_paths.");
@@ -1904,7 +1924,7 @@ int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
                       double dropout, uint64_t seed, omc_result* res, float* sx_out, int32_t* tex_out)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if ((rc = check_market(1.0, K, T, r))) return rc;
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -1935,7 +1955,7 @@ int omc_localvol_paths_f32(omc_ctx* c, float* S, int64_t ld, int64_t n_paths, in
                            double m_scale, double tau_scale, double epsilon, const float* Z)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if ((rc = check_market(S0, K, T, r))) return rc;
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -1954,7 +1974,7 @@ int omc_nn_build_rows(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
                       double T, int is_put, float* data, int64_t cap_rows, int64_t* n_rows, double* stats16)
 {
     int rc;
-    if ((rc = bind(c))) return rc;
+    if ((rc = bind_in(c))) return rc;
     if ((rc = check_market(1.0, K, T, r))) return rc;
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
@@ -1998,7 +2018,7 @@ int omc_nn_build_rows(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
 int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const double* y, int64_t n_rows,
                          double T, double dt, double* out16)
 {
-    int rc = bind(c);
+    int rc = bind_in(c);
     if (rc) return rc;
     if (!x || !t || !y || !out16) return fail(-7, "null pointer.");
     if (n_rows <= 0) return fail(-3, "n_rows must be positive.");
@@ -2013,7 +2033,7 @@ int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const do
 
 int omc_mlp_shuffle_indices(omc_ctx* c, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device)
 {
-    int rc = bind(c);
+    int rc = bind_in(c);
     if (rc) return rc;
     if (n_rows <= 0 || !out_device) return fail(-3, "n_rows must be positive, out non-null.");
     HIP_TRY(omc::mlp_shuffle_indices(c->stream, n_rows, shuffle_key, out_device));
@@ -2026,7 +2046,7 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
                         double lr, double beta1, double beta2, double eps, double weight_decay,
                         double dropout, uint64_t seed, uint64_t shuffle_key, double* mean_loss)
 {
-    int rc = bind(c);
+    int rc = bind_in(c);
     if (rc) return rc;
     if (omc::mlp_train_kernel_choice(hidden, layers, batch) == 0)
         return fail(-9, "the fused trainer supports hidden = 64 or 128 with 2 or 3 hidden layers (and 32 x 2).");
@@ -2063,7 +2083,7 @@ int omc_mlp_train_batch_supported(int hidden, int layers, int64_t batch)
 int omc_mlp_train_epoch_batch(omc_ctx* c, omc_mlp_job* jobs, int n, int hidden, int layers, double beta1, double beta2,
                               double eps, double weight_decay, double dropout)
 {
-    int rc = bind(c);
+    int rc = bind_in(c);
     if (rc) return rc;
     if (!jobs || n <= 0) return fail(-7, "empty batch.");
     if (n > 65535) return fail(-3, "batch too large (max 65535 networks per call).");

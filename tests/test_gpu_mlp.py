@@ -150,6 +150,10 @@ def test_ragged_last_batch(env, ctx):
 def test_shuffle_is_a_permutation(env, ctx, n):
     torch, nnr, dev = env
     out = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    # the fill is queued on torch's stream; the session context runs on its own.  The library orders an owned
+    # stream after the device's default stream on entry (include/omc.h, "stream ordering"), and the test does
+    # not lean on that alone: the fill must have landed before the shuffle writes the same buffer.
+    torch.cuda.synchronize()
     ctx.mlp_shuffle_indices(n, 12345, out.data_ptr())
     idx = out.cpu().numpy()
     assert np.array_equal(np.sort(idx), np.arange(n))
@@ -157,6 +161,7 @@ def test_shuffle_is_a_permutation(env, ctx, n):
     assert np.array_equal(out.cpu().numpy(), np.arange(n))  # key 0: storage order
     if n >= 1000:
         out2 = torch.empty_like(out)
+        torch.cuda.synchronize()
         ctx.mlp_shuffle_indices(n, 12346, out2.data_ptr())
         idx2 = out2.cpu().numpy()
         assert (idx != idx2).mean() > 0.99 and (idx != np.arange(n)).mean() > 0.99
@@ -184,6 +189,7 @@ def test_shuffled_epoch_visits_every_row_once(env, ctx):
     assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[0][1].abs().max())
     # minibatches: shuffled in-kernel == storage order on the gathered copy, bit for bit
     idx = torch.empty(rows, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
     ctx.mlp_shuffle_indices(rows, 77, idx.data_ptr())
     gathered = data[idx].contiguous()
     outs = []
