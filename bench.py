@@ -31,8 +31,6 @@ Prints ONE JSON line (rank 0).  Extra objects:
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -123,72 +121,14 @@ def cpu_baseline(model, M, N, semantics, is_put, seed, stream, budget_s=25.0):
 
 
 # ---------------------------------------------------------------------------------------------
-def free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def launch_ranks(n: int, deadline_s: float, argv=None) -> int:
     """Parent of a `--gpus N` run without a launcher: start N rank processes (this script again, with
-    the rank environment) and relay rank 0's JSON line.  No GPU call is made here; a child that fails
-    takes the job down with a non-zero exit code (children are never re-exec'd or retried), and so does
-    the overall deadline (`--rank-timeout`): the ranks still running then are terminated -- exactly the
-    processes started here -- and named on stderr, so that a rank stuck inside a communicator call ends
-    as an error, not as a job that never finishes."""
-    import tempfile
-    port = free_port()
-    nonce = os.urandom(8).hex()  # part of the rendezvous file names: no collision with any other launch
-    procs = []
-    out0 = tempfile.TemporaryFile()  # rank 0's stdout (a file, so that nobody blocks on a full pipe)
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMC_RDZV_NONCE=nonce)
-        # the host driver only supports dmabuf IPC: RCCL needs this (it is exported on the GPU boxes; set it for
-        # launches from a bare environment too, never override what the caller chose)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen(argv or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=out0 if r == 0 else sys.stderr.fileno()))
-    rc = 0
-    alive = set(range(n))
-    t0 = time.monotonic()
-
-    def stop(ranks):
-        for q in ranks:  # exactly the processes started above
-            procs[q].terminate()
-        t1 = time.monotonic()
-        for q in ranks:
-            try:
-                procs[q].wait(max(0.1, 10.0 - (time.monotonic() - t1)))
-            except subprocess.TimeoutExpired:
-                procs[q].kill()
-                procs[q].wait()
-
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
-                stop(sorted(alive))
-        if alive and rc == 0 and time.monotonic() - t0 > deadline_s:
-            rc = 124
-            print(f"bench.py: rank(s) {sorted(alive)} did not finish within --rank-timeout {deadline_s:.0f} s; "
-                  f"terminating them", file=sys.stderr)
-            stop(sorted(alive))
-        if alive:
-            time.sleep(0.05)
-    out0.seek(0)
-    out = out0.read().decode()
-    if rc == 0:
-        sys.stdout.write(out)
-        sys.stdout.flush()
-    else:
-        sys.stderr.write(out)
-    return rc
+    the rank environment) and relay rank 0's JSON line -- options_model_amd.launcher.launch_ranks, the machinery
+    the facade's `n_gpus = N` uses as well: no GPU call here, children are never re-exec'd or retried, a failing
+    child or the overall deadline (`--rank-timeout`) ends the job non-zero with the ranks named on stderr."""
+    from options_model_amd import launcher
+    return launcher.launch_ranks(n, deadline_s, argv or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                 who="bench.py", timeout_flag="--rank-timeout")
 
 
 # ---------------------------------------------------------------------------------------------

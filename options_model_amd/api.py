@@ -20,12 +20,19 @@ regressor:
               lsm_poly_degree and then ignores it: Options_model.py:53,69-70)
 n_gpus:
   1           this process, one GPU (`device`).
-  N > 1       the paths shard by antithetic pair over the N GPUs of one node, ONE PROCESS PER GPU: the call
-              must be made by every rank of an N-rank job (`python -m torch.distributed.run --nproc-per-node
-              N script.py`, or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT); each rank
-              prices its shard through the library's own RCCL communicator (dist.RcclPricer: regression
-              moments and result sums all-reduced over xGMI) and every rank returns the same global result.
-              Called from a lone process it refuses -- it never silently prices on one GPU.
+  N > 1       the paths shard by antithetic pair over N GPUs of one node, ONE PROCESS PER GPU; each rank prices its
+              shard through the library's own RCCL communicator (dist.RcclPricer: regression moments and result sums
+              all-reduced over xGMI) and the call returns the global result.  Two ways to get the ranks:
+              * called from a PLAIN process (a script, a notebook, the Streamlit UI -- the reference's callers are
+                single-process programs, options_model_2_ui.py:87-133): the ranks are started here as child
+                processes on first use (launcher.RankPool: fresh interpreters, the parent never re-execs and makes
+                no GPU call for them), keep their communicator across calls and are closed at exit.  `device` may
+                list one HIP device per rank (default: rank r -> device r);
+              * called by every rank of an N-rank job (`python -m torch.distributed.run --nproc-per-node N
+                script.py`, or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT): each rank is
+                its own process already and every rank returns the same global result.
+              It never silently prices on fewer GPUs: a rank that cannot start, or a job of another size, raises.
+              regressor="nn" shards as well (nn_dist: rows per rank, statistics and gradient partials all-reduced).
 """
 from __future__ import annotations
 
@@ -97,15 +104,34 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
         raise ValueError("model must be 'GBM' or 'Heston'.")
     if semantics not in _SEM:
         raise ValueError(f"semantics must be one of {sorted(set(_SEM))}.")
-    if regressor != "poly":
-        if regressor == "nn":
-            if n_gpus > 1:
-                raise ValueError("n_gpus > 1 shards the polynomial regressor's flows; regressor='nn' runs on one GPU.")
-            from . import nn_regressor
-            return nn_regressor.price_american_option_nn(
-                S0, K, r, sigma, T, n_paths, n_steps, model=model, option_type=option_type,
-                heston_params=heston_params, seed=seed, stream=stream, device=device)
+    if regressor not in ("poly", "nn"):
         raise ValueError("regressor must be 'poly' or 'nn'.")
+    if n_gpus > 1 and not _in_job(n_gpus):
+        # a plain process: validate here (the reference's messages), then let the rank pool do the collective call
+        if ctx is not None:
+            raise ValueError("n_gpus > 1 uses one context per rank process; do not pass ctx.")
+        _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
+        from . import launcher
+        devices = None if device is None else ([int(device)] * n_gpus if isinstance(device, int) else list(device))
+        kw = dict(S0=S0, K=K, r=r, sigma=sigma, T=T, n_paths=int(n_paths), n_steps=int(n_steps), model=model,
+                  option_type=option_type, heston_params=heston_params, seed=int(seed), stream=int(stream))
+        if regressor == "nn":
+            d = launcher.pool(n_gpus, devices).call("price_american_option_nn", kw)
+        else:
+            kw.update(regressor="poly", semantics=semantics, heston_scheme=heston_scheme, antithetic=bool(antithetic))
+            d = launcher.pool(n_gpus, devices).call("price_american_option", kw)
+        d["info"] = dict(d.get("info", {}), launched_ranks=n_gpus)
+        return PriceResult(**d)
+    if regressor == "nn":
+        if n_gpus > 1:
+            from . import nn_dist
+            return nn_dist.price_american_option_nn_sharded(
+                _job_pricer(n_gpus, device), S0, K, r, sigma, T, n_paths, n_steps, model=model,
+                option_type=option_type, heston_params=heston_params, seed=seed, stream=stream)
+        from . import nn_regressor
+        return nn_regressor.price_american_option_nn(
+            S0, K, r, sigma, T, n_paths, n_steps, model=model, option_type=option_type,
+            heston_params=heston_params, seed=seed, stream=stream, device=device)
     _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
     M = int(n_paths) // 2 * 2 if antithetic else int(n_paths)  # options_model_3.py:458
     if M <= 0:
@@ -141,15 +167,28 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
 _job = {}
 
 
+def _in_job(n_gpus: int) -> bool:
+    """Is this process one rank of an n_gpus-rank job (started by a launcher that set the rank environment)?
+    A job of ANOTHER size is an error, not a reason to start ranks from inside a rank."""
+    if "RANK" not in os.environ:
+        return False
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == n_gpus:
+        return True
+    if world > 1:
+        raise RuntimeError(
+            f"price_american_option(n_gpus={n_gpus}) was called inside a {world}-rank job (RANK="
+            f"{os.environ['RANK']}): n_gpus must equal the job's WORLD_SIZE.  It does not fall back to one GPU.")
+    return False
+
+
 def _job_pricer(n_gpus: int, device=None):
     """The per-process RcclPricer of an n_gpus-rank job (created on first use, closed at exit)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != n_gpus or "RANK" not in os.environ:
         raise RuntimeError(
-            f"price_american_option(n_gpus={n_gpus}) must be called by every rank of a {n_gpus}-rank job, one process "
-            f"per GPU (e.g. `python -m torch.distributed.run --nnodes=1 --nproc-per-node {n_gpus} script.py`); this "
-            f"process sees WORLD_SIZE={os.environ.get('WORLD_SIZE', 'unset')}, RANK={os.environ.get('RANK', 'unset')}. "
-            f"It does not fall back to one GPU.")
+            f"this process is not a rank of a {n_gpus}-rank job (WORLD_SIZE={os.environ.get('WORLD_SIZE', 'unset')}, "
+            f"RANK={os.environ.get('RANK', 'unset')}); it does not fall back to one GPU.")
     key = (os.getpid(), n_gpus)
     sp = _job.get(key)
     if sp is None:
