@@ -93,7 +93,9 @@ def heston_defaults(sigma, heston_params=None):
 def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", option_type="put",
                           regressor="poly", semantics="two_pass", heston_params=None,
                           heston_scheme="reference", antithetic=True, seed=42, stream=0,
-                          device=None, ctx=None, n_gpus=1) -> PriceResult:
+                          device=None, ctx=None, n_gpus=1, nn_options=None) -> PriceResult:
+    """nn_options (regressor="nn" only): dict with any of nn_hidden, nn_layers, nn_dropout, nn_epochs, nn_lr, nn_batch,
+    inference_dropout, torch_seed -- the network named by BASELINE config 5 (2 x 64) by default."""
     model_l = str(model).lower()
     n_gpus = int(n_gpus)
     if n_gpus < 1:
@@ -116,7 +118,8 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
         kw = dict(S0=S0, K=K, r=r, sigma=sigma, T=T, n_paths=int(n_paths), n_steps=int(n_steps), model=model,
                   option_type=option_type, heston_params=heston_params, seed=int(seed), stream=int(stream))
         if regressor == "nn":
-            d = launcher.pool(n_gpus, devices).call("price_american_option_nn", kw)
+            kw.update(nn_options or {})
+            d = launcher.pool(n_gpus, devices).call("price_american_option_nn", kw, timeout_s=3600.0)
         else:
             kw.update(regressor="poly", semantics=semantics, heston_scheme=heston_scheme, antithetic=bool(antithetic))
             d = launcher.pool(n_gpus, devices).call("price_american_option", kw)
@@ -127,11 +130,11 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
             from . import nn_dist
             return nn_dist.price_american_option_nn_sharded(
                 _job_pricer(n_gpus, device), S0, K, r, sigma, T, n_paths, n_steps, model=model,
-                option_type=option_type, heston_params=heston_params, seed=seed, stream=stream)
+                option_type=option_type, heston_params=heston_params, seed=seed, stream=stream, **(nn_options or {}))
         from . import nn_regressor
         return nn_regressor.price_american_option_nn(
             S0, K, r, sigma, T, n_paths, n_steps, model=model, option_type=option_type,
-            heston_params=heston_params, seed=seed, stream=stream, device=device)
+            heston_params=heston_params, seed=seed, stream=stream, device=device, **(nn_options or {}))
     _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
     M = int(n_paths) // 2 * 2 if antithetic else int(n_paths)  # options_model_3.py:458
     if M <= 0:

@@ -49,6 +49,14 @@ def rank_env(rank: int, world: int, port: int, nonce: str, base=None, local_rank
     return env
 
 
+def _stderr_fd():
+    """The parent's stderr for the children (None = inherit fd 2 when sys.stderr is not a real file, e.g. captured)."""
+    try:
+        return sys.stderr.fileno()
+    except (AttributeError, OSError, ValueError):
+        return None
+
+
 def _stop(procs, ranks, grace_s: float = 10.0):
     for q in ranks:  # exactly the processes started by this module
         if procs[q].poll() is None:
@@ -75,7 +83,7 @@ def launch_ranks(n: int, deadline_s: float, argv, who: str = "options_model_amd.
     out0 = tempfile.TemporaryFile()  # rank 0's stdout (a file, so that nobody blocks on a full pipe)
     for r in range(n):
         procs.append(subprocess.Popen(list(argv), env=rank_env(r, n, port, nonce),
-                                      stdout=out0 if r == 0 else sys.stderr.fileno()))
+                                      stdout=out0 if r == 0 else _stderr_fd()))
     rc = 0
     alive = set(range(n))
     t0 = time.monotonic()
@@ -115,9 +123,10 @@ class RankPool:
     (the multi-GPU entry points are collective), waits for every rank's answer and returns rank 0's.
 
     devices: the HIP device of each rank (default: rank r -> device r).  env: extra environment for the workers
-    (tests point OMC_RCCL_LIB at the shared-memory stand-in to run several ranks on one card)."""
+    (tests point OMC_RCCL_LIB at the shared-memory stand-in to run several ranks on one card).  worker_argv: the
+    worker command (default: this package's _rank_worker; the CPU tests run a protocol-only worker)."""
 
-    def __init__(self, n_gpus: int, devices=None, env=None, start_timeout_s: float = 300.0):
+    def __init__(self, n_gpus: int, devices=None, env=None, start_timeout_s: float = 300.0, worker_argv=None):
         n = int(n_gpus)
         if n < 2:
             raise ValueError("a rank pool needs at least two ranks")
@@ -136,14 +145,19 @@ class RankPool:
         try:
             for r in range(n):
                 self.procs.append(subprocess.Popen(
-                    [sys.executable, "-m", "options_model_amd._rank_worker", str(self.devices[r])],
+                    list(worker_argv or [sys.executable, "-m", "options_model_amd._rank_worker"]) + [str(self.devices[r])],
                     env=rank_env(r, n, port, nonce, base), stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                    stderr=sys.stderr.fileno(), cwd=_ROOT))
+                    stderr=_stderr_fd(), cwd=_ROOT))
             for p in self.procs:
                 os.set_blocking(p.stdout.fileno(), False)
             self._closed = False
             # first exchange: every worker has imported the package, created its context and communicator
-            self._roundtrip(dict(fn="__hello__", kwargs={}), start_timeout_s)
+            hello = self._roundtrip(dict(fn="__hello__", kwargs={}), start_timeout_s)
+            bad = [(r, a) for r, a in enumerate(hello) if not a.get("ok")]
+            if bad:
+                raise RankError("the ranks did not come up: " +
+                                "; ".join(f"rank {r}: {a.get('type')}: {a.get('error')}" for r, a in bad))
+            self.transport = hello[0]["result"].get("transport")
         except BaseException:
             self._closed = False
             self.close(kill=True)

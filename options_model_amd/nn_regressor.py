@@ -668,8 +668,9 @@ def price_two_pass_nn(pricer, S0, T, M, N, path_seed, torch_seed):
 def price_american_option_nn(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", option_type="put",
                              heston_params=None, seed=42, stream=0, device=0, nn_hidden=64,
                              nn_layers=2, nn_dropout=0.1, nn_epochs=25, nn_lr=1e-3, nn_batch=None,
-                             inference_dropout=True, nn_trainer="auto"):
-    """Facade backend for regressor='nn' (BASELINE config 5 names a 2x64 MLP)."""
+                             inference_dropout=True, nn_trainer="auto", torch_seed=None):
+    """Facade backend for regressor='nn' (BASELINE config 5 names a 2x64 MLP).  torch_seed: what the reference
+    hands to torch.manual_seed (options_model_3.py:455); default seed + 1."""
     from .api import PriceResult, _validate
     torch = _torch()
     model_l = str(model).lower()
@@ -681,7 +682,8 @@ def price_american_option_nn(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", 
         ctx = _ctx_on_torch_stream(device)
         S = torch.empty((int(n_steps) + 1, M), dtype=torch.float32, device=dev)
         generate_paths(ctx, S, kw, S0, r, sigma or 0.0, T, seed, stream)
-        out = price_with_paths(S, K, r, T, option_type == "put", seed + 1, nn_hidden, nn_layers,
+        out = price_with_paths(S, K, r, T, option_type == "put", seed + 1 if torch_seed is None else torch_seed,
+                               nn_hidden, nn_layers,
                                nn_dropout, nn_epochs, nn_lr, nn_batch, inference_dropout, trainer=nn_trainer)
     return PriceResult(price=out["price"], stderr=out.get("stderr", 0.0), std=out.get("std", 0.0),
                        zero_prob=out.get("zero_prob", 0.0), n_paths=M,

@@ -119,7 +119,8 @@ class AdvancedOptionPricer:
                  # -- extensions (keyword-only in spirit; the GPU file adds nn_layers/nn_dropout
                  #    the same way, option_model_3_gpu.py:557-561)
                  nn_layers: int = 3, nn_dropout: float = 0.10, regressor: Optional[str] = None,
-                 semantics: str = "two_pass", device: int = 0):
+                 semantics: str = "two_pass", device: int = 0, n_gpus: Optional[int] = None,
+                 devices: Optional[list] = None):
         """Called with the reference's own arguments only, this prices the way the reference does:
         ONE SingleLSMNet(7, nn_hidden, nn_layers) with dropout, trained on the pass-1 rows and applied
         in the sticky pass 2 (options_model_3.py:482-651) -- regressor "nn", the default -- on the GPU
@@ -127,7 +128,10 @@ class AdvancedOptionPricer:
         is the explicit fast option: OLS on [1,u,u^2] per time step in the same two-pass control flow
         (the reference accepts lsm_poly_degree and never uses it).  The environment
         variable OMC_REGRESSOR=poly|nn changes the default for callers that cannot pass the argument
-        (e.g. the Streamlit UI going through compute_curve_worker_enhanced)."""
+        (e.g. the Streamlit UI going through compute_curve_worker_enhanced).
+        n_gpus > 1 (or OMC_N_GPUS for the same callers): the American pricing shards its paths over that many
+        GPUs, one rank process per GPU -- started from here when this is a plain process (api.py, launcher.py);
+        `devices` lists one HIP device per rank (default: rank r -> device r; OMC_DEVICES="0,1,.." likewise)."""
         if regressor is None:
             regressor = os.environ.get("OMC_REGRESSOR", "nn").lower()
         if regressor not in ("poly", "nn"):
@@ -145,6 +149,12 @@ class AdvancedOptionPricer:
         self.european_approximation = european_approximation
         self.use_control_variate = use_control_variate
         self.regressor, self.semantics, self.device = regressor, semantics, device
+        self.n_gpus = int(n_gpus if n_gpus is not None else os.environ.get("OMC_N_GPUS", "1"))
+        if self.n_gpus < 1:
+            raise ValueError("n_gpus must be a positive integer.")
+        if devices is None and os.environ.get("OMC_DEVICES"):
+            devices = [int(d) for d in os.environ["OMC_DEVICES"].split(",")]
+        self.devices = devices
         self._calls = 0
         self.last_result: Optional[dict] = None
 
@@ -226,13 +236,26 @@ class AdvancedOptionPricer:
                                                         self.option_type == "put", self.semantics)
             self.last_result = res
             return res["price"]
+        if self.regressor not in ("poly", "nn"):
+            raise ValueError("regressor must be 'poly' or 'nn'.")
+        if self.n_gpus > 1:  # paths sharded over rank processes (api.price_american_option, n_gpus)
+            from . import api
+            kw = self._model_kw()
+            res = api.price_american_option(
+                S0, self.K, self.r, self.sigma, T, M, int(num_time_steps), model=kw.pop("model"),
+                option_type=self.option_type, regressor=self.regressor, semantics=self.semantics,
+                heston_params=kw or None, seed=path_seed, stream=0, n_gpus=self.n_gpus, device=self.devices,
+                nn_options=dict(nn_hidden=self.nn_hidden, nn_layers=self.nn_layers, nn_dropout=self.nn_dropout,
+                                nn_epochs=self.nn_epochs, nn_lr=self.nn_lr, torch_seed=torch_seed))
+            self.last_result = dict(price=res.price, std=res.std, stderr=res.stderr, n_paths=res.n_paths,
+                                    n_exercised=res.n_exercised, sum_nitm=res.sum_nitm, zero_prob=res.zero_prob,
+                                    R=res.sum_nitm, **res.info)
+            return res.price
         if self.regressor == "nn":
             from . import nn_regressor
             res = nn_regressor.price_two_pass_nn(self, S0, T, M, int(num_time_steps), path_seed, torch_seed)
             self.last_result = res
             return res["price"]
-        if self.regressor != "poly":
-            raise ValueError("regressor must be 'poly' or 'nn'.")
         out = self._ctx().price_american(self._params(S0, T, M, int(num_time_steps), path_seed,
                                                       self.semantics))
         self.last_result = out

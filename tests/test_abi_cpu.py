@@ -78,21 +78,26 @@ def test_c_host_example_compiles_against_the_header_and_library(tmp_path):
     assert exe.exists()
 
 
-def test_facade_n_gpus_refuses_outside_a_job(monkeypatch):
-    """price_american_option(..., n_gpus=N) shards over N ranks -- called from a lone process it
-    must refuse (never a silent single-GPU pricing), before any GPU call."""
+def test_facade_n_gpus_never_prices_on_fewer_gpus(monkeypatch):
+    """price_american_option(..., n_gpus=N) shards over N ranks.  From a plain process it starts the
+    ranks itself (launcher.RankPool); here there is no GPU, so every rank fails to bring its context up and the call
+    raises with the ranks named -- never a silent single-GPU pricing, and no GPU call in this process.  Inside a job
+    of another size it refuses outright."""
+    import time
+
     import pytest
 
-    from options_model_amd import price_american_option
+    from options_model_amd import launcher, price_american_option
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
-    with pytest.raises(RuntimeError, match="2-rank job"):
+    t0 = time.monotonic()
+    with pytest.raises(launcher.RankError, match="rank 0"):
         price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 10_000, 50, n_gpus=2)
+    assert time.monotonic() - t0 < 120
+    launcher.close_pools()
     monkeypatch.setenv("WORLD_SIZE", "4")
     monkeypatch.setenv("RANK", "0")
-    with pytest.raises(RuntimeError, match="WORLD_SIZE=4"):
+    with pytest.raises(RuntimeError, match="inside a 4-rank job"):
         price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 10_000, 50, n_gpus=2)
     with pytest.raises(ValueError, match="n_gpus"):
         price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 10_000, 50, n_gpus=0)
-    with pytest.raises(ValueError, match="regressor='nn' runs on one GPU"):
-        price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 10_000, 50, n_gpus=2, regressor="nn")
