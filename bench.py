@@ -475,16 +475,24 @@ def main():
             # add the ranks' contributions in another order) and no exchange timed out does the section use it
             good = False
             if pricer.enable_p2p():
-                try:
-                    ids = [3000, 3001, 3002, 3003]
-                    ctx.set_option("p2p_exchange", 1)
-                    on = [o["sum"] for o in price_group(ids, "reference")[1]]
-                    ctx.set_option("p2p_exchange", 0)
-                    off = [o["sum"] for o in price_group(ids, "reference")[1]]
-                    good = all(abs(x - y) <= 1e-12 * abs(y) for x, y in zip(on, off))
-                except Exception as e:  # a timed-out exchange surfaces as an error of the call
-                    print(f"bench.py rank {rank}: direct exchange failed its self-check: {e}", file=sys.stderr)
-                    good = False
+                # BOTH pricings run on EVERY rank whatever happens to either: a rank that skipped the collective form
+                # after an error would leave its peers inside those all-reduces (mismatched collectives = a hang
+                # until the watchdog).  Errors are remembered, the ranks vote afterwards.
+                ids = [3000, 3001, 3002, 3003]
+                on = off = None
+                for use in (1, 0):
+                    ctx.set_option("p2p_exchange", use)
+                    try:
+                        got = [o["sum"] for o in price_group(ids, "reference")[1]]
+                    except Exception as e:  # a timed-out exchange surfaces as an error of the call (on every rank)
+                        print(f"bench.py rank {rank}: self-check pricing (direct exchange {'on' if use else 'off'}) "
+                              f"failed: {e}", file=sys.stderr)
+                        got = None
+                    if use:
+                        on = got
+                    else:
+                        off = got
+                good = on is not None and off is not None and all(abs(x - y) <= 1e-12 * abs(y) for x, y in zip(on, off))
             good = pricer.allreduce_max(0.0 if good else 1.0) == 0.0
             ctx.set_option("p2p_exchange", 1 if good else 0)
             exchange = ("direct writes into every peer's mailbox (omc_p2p_*), one launch per time step" if good

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OMC_ABI_VERSION 5
+#define OMC_ABI_VERSION 6
 
 typedef struct omc_ctx omc_ctx;
 
@@ -104,11 +104,7 @@ int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* knobs: "gbm_vec" / "heston_vec" (pairs per thread: 1,2,4; 0 = auto), "world_size" (ranks behind
  * the all-reduce hook, see below), "step_graph" (1 / 0: replay the per-step sweep as one captured HIP
  * graph or launch its kernels one by one; -1 = default, off: same speed at 1M x 252, and a capture per new
- * geometry costs milliseconds), "step_persistent" (1: run the per-step
- * reference sweep as ONE persistent launch with an in-launch exchange of the partial moments --
- * csrc/omc_lsm_persist.hip; bounded spins, falls back to launches if its workgroups cannot all be
- * resident; default 0: measured slower than one launch per step on MI355X),
- * "seq_overlap" (omc_price_american_seq on a context with a communicator, two-pass flow, equal geometry:
+ * geometry costs milliseconds), "seq_overlap" (omc_price_american_seq on a context with a communicator, two-pass flow, equal geometry:
  * 1 = the moment all-reduce of pricing k runs on a second stream under the path generation of pricing k+1
  * (second path buffer) and all result sums travel in one collective at the end -- bit-identical results;
  * 0 = one pricing after the other; -1 = default: off -- a job turns it on after it has checked, on its live
@@ -116,12 +112,6 @@ int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
  * "seq_event_stride" (omc_price_american_seq: k > 0 = every k-th pricing of a sequence carries its own HIP
  * events, so a sequence yields several samples of the per-kernel times; 0 = default: the first pricing only) */
 int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
-/* measurement aid: with option "step_stamps" = 1 the per-step reference sweep runs a build of its kernel
- * that records eight 100 MHz time stamps per launch and workgroup (entry, partials in, fit solved,
- * barrier passed, rows in, paths done, block sums done, exit); this copies them out, laid out
- * [n_steps + 1][256][8] uint64 with launch index n_steps - t.  Not part of the pricing path. */
-int omc_debug_read(omc_ctx* ctx, void* host, size_t bytes);
-
 /* ---- per-step flows across GPUs without a collective per step ------------------------------ */
 /* The per-step flows exchange 8 doubles per pricing after every time step.  Instead of an all-reduce per step, every
  * rank can WRITE its contribution into every peer's memory (xGMI) and sum what arrives itself: omc_p2p_export
@@ -132,7 +122,12 @@ int omc_debug_read(omc_ctx* ctx, void* host, size_t bytes);
  * keeps the collective for everything else (the two-pass flow's moment table, the result sums).  Every rank gets
  * the same bits; a contribution that does not arrive within the deadline makes the pricing call fail (error 3100,
  * sticky: omc_p2p_status reports it) -- it never hangs.  Option "p2p_exchange" = 0 switches back to the collective
- * without disconnecting. */
+ * without disconnecting; "p2p_deadline_ms" = how long an exchange waits for a peer's contribution (default 2000),
+ * "p2p_first_deadline_ms" = the same for the FIRST exchange of a pricing call (default 30000: nothing aligns the ranks
+ * before it, and a first-use code-object load or a multi-GB allocation on one rank can skew them by seconds).
+ * The failure is COLLECTIVE: a rank that gave up poisons its slot in every peer's mailbox and adds its error word to
+ * the all-reduced result sums, so every rank of the job returns 3100 -- a peer that was merely slow cannot leave the
+ * others with a finite price built on a contribution that was given up on.  */
 int omc_p2p_export(omc_ctx* ctx, void* handle_out, size_t bytes /* >= 64 */);
 int omc_p2p_connect(omc_ctx* ctx, int rank, int world, const void* handles, size_t bytes /* >= world * 64 */);
 int omc_p2p_disconnect(omc_ctx* ctx);

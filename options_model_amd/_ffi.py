@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
 MODELS = {"gbm": 0, "heston": 1}
@@ -70,7 +70,6 @@ SIGNATURES = {
     "omc_memcpy_h2d": (C.c_int, [_P, _P, _P, _SZ]),
     "omc_memcpy_d2h": (C.c_int, [_P, _P, _P, _SZ]),
     "omc_set_option": (C.c_int, [_P, C.c_char_p, _I64]),
-    "omc_debug_read": (C.c_int, [_P, _P, _SZ]),
     "omc_gbm_paths_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _D, _U64, _U64, _U64, _I]),
     "omc_heston_paths_f32": (C.c_int, [_P, _P, _I64, _I64, _I] + [_D] * 8 + [_U64, _U64, _U64, _I]),
     "omc_gbm_paths_from_normals_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _D, _P, _I64, _I]),

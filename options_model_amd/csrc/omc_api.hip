@@ -53,7 +53,13 @@ struct DevBuf {
         }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {  // no room for the 12.5 % growth slack: ask for exactly what is needed
+            (void)hipGetLastError();
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
         if (e != hipSuccess) {
+            (void)hipGetLastError();  // a failed hipMalloc must not surface at the next launch's hipGetLastError()
             g_err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
             p = nullptr;
             return (int)e;
@@ -75,8 +81,7 @@ struct omc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf S, sx, tex, ex, D, part, gmom, betas, part1, result, scratch, sweep_args, dbg;
-    int step_stamps = 0;  // measurement mode: the per-step kernels time-stamp themselves into `dbg`
+    DevBuf S, sx, tex, ex, D, part, gmom, betas, part1, result, scratch, sweep_args;
     DevBuf bslab, btable, bres, bdisc;  // batched path: problem slab, table, results, discounts
     DevBuf mlp_part, mlp_loss, mlp_wt;  // NN training: gradient partials, epoch loss, transposed connections
     DevBuf cn_scratch, cn_data, cn_net, cn_cont;  // per-step ContNet flow: set bookkeeping, rows, net + Adam state, values
@@ -117,6 +122,8 @@ struct omc_ctx {
     omc::P2P* p2p = nullptr;
     int p2p_use = 1;            // option "p2p_exchange": 0 = keep the collective even when connected
     bool p2p_used = false;      // an exchange was enqueued since the last wait
+    double p2p_deadline_s = 2.0;  // option "p2p_deadline_ms": how long an exchange waits for a peer's contribution
+    double p2p_first_deadline_s = 30.0;  // "p2p_first_deadline_ms": the same for the FIRST exchange of a call
     // omc_price_american_seq across GPUs: the moment all-reduce of pricing k runs on its own stream while the
     // main stream generates the paths of pricing k+1 into the second path buffer
     hipStream_t comm_stream = nullptr;
@@ -135,12 +142,7 @@ struct omc_ctx {
     char* sweep_pin = nullptr;     // pinned upload ring
     int sweep_pin_slot = 0;
     int step_graph = -1;           // -1: environment default (off), 0 off, 1 on
-    // persistent per-step sweep (one launch for the whole backward induction): -1 default (off), 0 off, 1 on
-    int step_persistent = -1;
-    int persist_failed = 0;        // a bounded spin gave up once on this context: stay with launches
-    int persist_used = 0;          // the pricing(s) enqueued since the last wait went through it
     int device_cus = 0;
-    DevBuf persist_scratch;
     bool distributed() const { return comm != nullptr || hook != nullptr; }
 };
 
@@ -240,10 +242,6 @@ int prepare_lsm(omc_ctx* c, int64_t M, int N, double r, double T, bool two_pass,
     w->sx = (float*)c->sx.p;
     w->tex = (int32_t*)c->tex.p;
     w->live = (float*)c->ex.p;
-    if (c->step_stamps) {
-        if ((rc = c->dbg.ensure(sizeof(unsigned long long) * 8 * 256 * (size_t)(N + 1)))) return rc;
-        w->dbg = (unsigned long long*)c->dbg.p;
-    }
     w->D = (double*)c->D.p;
     w->part = (double*)c->part.p;
     w->gmom = (double*)c->gmom.p;
@@ -291,19 +289,6 @@ int allreduce(omc_ctx* c, double* dptr, int count)
 bool p2p_active(const omc_ctx* c)
 {
     return c->p2p && c->p2p_use && omc::p2p_connected(c->p2p) && c->distributed() && omc::p2p_world(c->p2p) == c->world;
-}
-
-bool step_persistent_enabled(const omc_ctx* c)
-{
-    if (c->persist_failed) return false;
-    if (c->step_persistent >= 0) return c->step_persistent != 0;
-    // Off unless asked for: measured on MI355X the in-launch exchange costs more than
-    // the kernel boundary it replaces (8.5 vs 6.2 us per step at 1M paths, 24 vs 21 us at 8M).
-    static const int env = [] {
-        const char* e = getenv("OMC_STEP_PERSISTENT");
-        return e ? atoi(e) : 0;
-    }();
-    return env != 0;
 }
 
 bool step_graph_enabled(const omc_ctx* c)
@@ -394,21 +379,14 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
     } else {
         const bool ext = c->distributed();
         const bool flags = semantics == OMC_SEM_REFERENCE;
-        if (!ext && flags && !w.cont && step_persistent_enabled(c) &&
-            omc::lsm_persist_supported(p, c->device_cus)) {
-            if ((rc = c->persist_scratch.ensure(omc::lsm_persist_scratch_bytes()))) return rc;
-            static const double spin_s = getenv("OMC_PERSIST_SPIN_SECONDS") ? atof(getenv("OMC_PERSIST_SPIN_SECONDS")) : 0.25;
-            HIP_TRY(omc::lsm_sweep_persistent(st, p, w, c->persist_scratch.p, write_state, spin_s));
-            c->persist_used = 1;
-            return 0;
-        }
         int graphed = kNoGraph;
-        if (!ext && step_graph_enabled(c) && !c->step_stamps) {
+        if (!ext && step_graph_enabled(c)) {
             graphed = enqueue_sweep_graph(c, p, w, semantics, write_state);
             if (graphed != 0 && graphed != kNoGraph) return graphed;
         }
         if (graphed == kNoGraph) {
             const int nblk = omc::lsm_sweep_blocks(p.M);
+            if (ext && p2p_active(c)) omc::p2p_begin_call(c->p2p);  // its first exchange absorbs start-up skew
             for (int t = p.N; t >= 1; --t) {
                 HIP_TRY(omc::lsm_step(st, p, w, semantics, t, ext));
                 if (ext && t >= 2) {
@@ -426,28 +404,29 @@ int enqueue_lsm(omc_ctx* c, const omc::LsmProblem& p, const omc::LsmWorkspace& w
     }
     // {sum, sumsq, n_exercised, n_zero, sum_nitm, ..} -> global sums.  Slot 4 is built from the moment
     // table, which is ALREADY global on every rank: fill_result divides it by the world size again.
+    // (slot 6: "a direct exchange gave up on this rank" -- after the all-reduce every rank knows, check_p2p)
+    if (c->p2p_used) HIP_TRY(omc::p2p_stamp_results(c->p2p, st, w.result, 1));
     if (c->distributed() && !c->defer_result_allreduce && (rc = allreduce(c, w.result, 8))) return rc;
     return 0;
 }
 
-// The persistent sweep's bounded spins gave up (result slot 7 carries its error word): remember it on the
-// context -- the caller re-enqueues the pricing, which then takes the launch-per-step sweep.
-bool persistent_gave_up(omc_ctx* c, const double* h)
-{
-    if (!c->persist_used || h[7] == 0.0) return false;
-    c->persist_failed = 1;
-    return true;
-}
-
-// after a wait: did a direct exchange give up (its bounded poll ran out)?  The sums are NaN then.
-int check_p2p(omc_ctx* c)
+// after a wait: did a direct exchange give up (its bounded poll ran out) -- on this rank (its sticky error word; the
+// sums are NaN then) or on ANY rank (slot 6 of the all-reduced result sums of the n pricings just waited for)?
+// Every rank of the job returns the error, not only the one whose deadline ran out.
+int check_p2p(omc_ctx* c, const double* h = nullptr, int n = 0)
 {
     if (!c->p2p_used) return 0;
     c->p2p_used = false;
     unsigned long long w = 0;
     HIP_TRY(omc::p2p_error_word(c->p2p, c->stream, &w));
-    if (w) return fail(3100, "direct peer exchange of the per-step moments timed out (a peer's contribution never arrived); "
-                             "omc_p2p_disconnect and use the collective");
+    bool peer = false;
+    for (int i = 0; h && i < n; ++i) peer = peer || h[(size_t)i * 8 + 6] != 0.0;
+    if (w == 1)
+        return fail(3100, "direct peer exchange of the per-step moments timed out (a peer's contribution never arrived); "
+                          "omc_p2p_disconnect and use the collective");
+    if (w || peer)
+        return fail(3100, "direct peer exchange of the per-step moments: another rank gave up on an exchange (its deadline "
+                          "ran out), so this job's sums are not to be trusted; omc_p2p_disconnect and use the collective");
     return 0;
 }
 
@@ -559,7 +538,7 @@ int omc_ctx_destroy(omc_ctx* c)
     if (c->p2p) omc::p2p_destroy(c->p2p);
     c->p2p = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
-                      &c->result, &c->scratch, &c->sweep_args, &c->dbg, &c->persist_scratch, &c->bslab, &c->btable, &c->bres, &c->bdisc,
+                      &c->result, &c->scratch, &c->sweep_args, &c->bslab, &c->btable, &c->bres, &c->bdisc,
                       &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
                       &c->mS, &c->mstate, &c->mtable, &c->mb_slab, &c->mb_table, &c->mb_bc})
         b->release();
@@ -638,15 +617,15 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     else if (!strcmp(key, "heston_vec")) c->heston_vec = (int)value;
     else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
     else if (!strcmp(key, "step_graph")) c->step_graph = value < 0 ? -1 : (value ? 1 : 0);
-    else if (!strcmp(key, "step_stamps")) c->step_stamps = value ? 1 : 0;
     else if (!strcmp(key, "seq_overlap")) c->seq_overlap = value < 0 ? -1 : (value ? 1 : 0);
     else if (!strcmp(key, "seq_event_stride")) c->seq_event_stride = value > 0 ? (int)value : 0;
     else if (!strcmp(key, "seq_step_k")) c->seq_step_k = value < 0 ? -1 : (int)(value > 32 ? 32 : value);
     else if (!strcmp(key, "seq_step_wgs")) c->seq_step_wgs = value > 0 ? (int)value : 0;
     else if (!strcmp(key, "p2p_exchange")) c->p2p_use = value ? 1 : 0;
-    else if (!strcmp(key, "step_persistent")) {
-        c->step_persistent = value < 0 ? -1 : (value ? 1 : 0);
-        if (value > 0) c->persist_failed = 0;  // explicit request: try again
+    else if (!strcmp(key, "p2p_deadline_ms") || !strcmp(key, "p2p_first_deadline_ms")) {
+        if (value <= 0) return fail(-4, "a p2p deadline must be positive.");
+        (key[4] == 'f' ? c->p2p_first_deadline_s : c->p2p_deadline_s) = (double)value * 1e-3;
+        if (c->p2p) omc::p2p_set_deadline(c->p2p, c->p2p_deadline_s, c->p2p_first_deadline_s);
     }
     else return fail(-4, "unknown option key.");
     return 0;
@@ -657,17 +636,6 @@ int omc_set_allreduce_hook(omc_ctx* c, omc_allreduce_fn fn, void* user)
     if (!c) return fail(-7, "null context.");
     c->hook = fn;
     c->hook_user = user;
-    return 0;
-}
-
-// measurement aid: the time stamps the per-step kernels wrote ("step_stamps" option), [n_steps+1][256][8]
-int omc_debug_read(omc_ctx* c, void* host, size_t bytes)
-{
-    int rc;
-    if ((rc = bind(c))) return rc;
-    if (!host || !c->dbg.p || bytes > c->dbg.cap) return fail(-7, "no debug buffer of that size.");
-    HIP_TRY(hipMemcpyAsync(host, c->dbg.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -747,6 +715,7 @@ int omc_p2p_export(omc_ctx* c, void* handle_out, size_t bytes)
     rc = omc::p2p_export(&p, handle_out, &err);
     if (rc) return fail(rc, err.c_str());
     c->p2p = p;
+    omc::p2p_set_deadline(p, c->p2p_deadline_s, c->p2p_first_deadline_s);
     return 0;
 }
 
@@ -910,18 +879,13 @@ int omc_lsm_poly(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     omc::LsmWorkspace w;
     if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, semantics == OMC_SEM_TWO_PASS, betas_out != nullptr, &w))) return rc;
     omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
-    for (int attempt = 0;; ++attempt) {
-        c->persist_used = 0;
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        if ((rc = enqueue_lsm(c, p, w, semantics, sx_out || tex_out))) return rc;
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-        if ((rc = copy_outputs(c, w, n_paths, n_steps, betas_out, sx_out, tex_out))) return rc;
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if ((rc = check_p2p(c))) return rc;
-        if (attempt == 0 && persistent_gave_up(c, c->hres)) continue;
-        break;
-    }
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = enqueue_lsm(c, p, w, semantics, sx_out || tex_out))) return rc;
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = copy_outputs(c, w, n_paths, n_steps, betas_out, sx_out, tex_out))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = check_p2p(c, c->hres, 1))) return rc;
     memset(res, 0, sizeof *res);
     fill_result(res, c->hres, c->distributed() ? n_paths * c->world : n_paths, c->distributed() ? c->world : 1);
     float ms = 0;
@@ -1113,18 +1077,13 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     // the collective and are copied afterwards.
     const bool zero_copy = c->hres_dev && !c->distributed();
     double* hres = c->hres_pin ? c->hres_pin : c->hres;
-    for (int attempt = 0;; ++attempt) {
-        c->persist_used = 0;
-        double* result = nullptr;
-        if ((rc = enqueue_pricing(c, p, S_keep, ld, zero_copy ? c->hres_dev : nullptr, c->ev, &result))) return rc;
-        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        if (!zero_copy)
-            HIP_TRY(hipMemcpyAsync(hres, result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-        if ((rc = wait_stream(c))) return rc;
-        if ((rc = check_p2p(c))) return rc;
-        if (attempt == 0 && persistent_gave_up(c, hres)) continue;
-        break;
-    }
+    double* result = nullptr;
+    if ((rc = enqueue_pricing(c, p, S_keep, ld, zero_copy ? c->hres_dev : nullptr, c->ev, &result))) return rc;
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    if (!zero_copy)
+        HIP_TRY(hipMemcpyAsync(hres, result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    if ((rc = check_p2p(c, hres, 1))) return rc;
     memset(res, 0, sizeof *res);
     fill_result(res, hres, c->distributed() ? p->n_paths * c->world : p->n_paths,
                 c->distributed() ? c->world : 1);  // distributed: sums are global
@@ -1427,13 +1386,25 @@ static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
     }
     if (k < 2) return 1;
     if (p[0].semantics == OMC_SEM_TWO_PASS || p[0].n_steps < 1) return 1;
-    if (c->step_stamps || step_persistent_enabled(c) || step_graph_enabled(c)) return 1;
+    if (step_graph_enabled(c)) return 1;
     for (int i = 1; i < n; ++i)
         if (p[i].semantics != p[0].semantics || p[i].n_paths != p[0].n_paths || p[i].n_steps != p[0].n_steps ||
             p[i].r != p[0].r || p[i].T != p[0].T)
             return 1;
-    // K path matrices stay resident: bounded by a byte budget (default 64 GB of the 288)
-    static const double budget = getenv("OMC_SEQ_STEP_BYTES") ? atof(getenv("OMC_SEQ_STEP_BYTES")) : 64e9;
+    // K path matrices stay resident: bounded by a byte budget -- at most 64 GB of the 288 (OMC_SEQ_STEP_BYTES), and
+    // never more than 80 % of what is free on THIS card right now plus what the context already holds for them (a
+    // card shared with torch or with other ranks has less; omc_price_american_seq also halves K when the allocation
+    // fails all the same)
+    static const double cap = getenv("OMC_SEQ_STEP_BYTES") ? atof(getenv("OMC_SEQ_STEP_BYTES")) : 64e9;
+    double budget = cap;
+    size_t free_b = 0, total_b = 0;
+    (void)hipSetDevice(c->device);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const double avail = 0.8 * (double)free_b + (double)c->mS.cap;
+        if (avail < budget) budget = avail;
+    } else {
+        (void)hipGetLastError();
+    }
     const int64_t ld = (p[0].n_paths + 63) / 64 * 64;
     const double sbytes = 4.0 * (double)ld * (double)(p[0].n_steps + 1);
     const int fit = (int)(budget / sbytes);
@@ -1441,6 +1412,47 @@ static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
     if (k > n) k = n;
     if (k > 32) k = 32;
     return k < 2 ? 1 : k;
+}
+
+// Device memory of the K-pricings-per-launch sweep (K path matrices + per-pricing state).  -> 0, or the HIP error.
+static int seq_multi_alloc(omc_ctx* c, int64_t M, int N, int K)
+{
+    int rc;
+    const int64_t ld = (M + 63) / 64 * 64;
+    const size_t sbytes = sizeof(float) * (size_t)ld * (size_t)(N + 1);
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t per = up(sizeof(float) * (size_t)M) + up(sizeof(int32_t) * (size_t)M) + up(sizeof(float) * (size_t)M + 16) +
+                       up(sizeof(double) * 2 * 8 * omc::kMaxLsmBlocks) + up(sizeof(double) * 4 * (size_t)(N + 1));
+    const size_t gbytes = up(sizeof(double) * 8 * (size_t)K * (size_t)(N + 1));
+    if ((rc = c->mS.ensure(sbytes * (size_t)K))) return rc;
+    if ((rc = c->mstate.ensure(gbytes + per * (size_t)K))) return rc;
+    return c->mtable.ensure(omc::lsm_sweep_args_bytes() * (size_t)K);
+}
+
+// Reserve for K pricings per launch; when the card has no room (shared with torch, several ranks on one device, a
+// smaller card) halve K down to one pricing at a time instead of failing the sequence.  Ranks of one job must agree
+// on K (their per-step collectives carry 8K doubles): with a communicator they take the smallest K any rank got.
+static int seq_multi_reserve(omc_ctx* c, const omc_params* p, int K, int* K_out)
+{
+    int rc = 0;
+    while (K >= 2 && (rc = seq_multi_alloc(c, p[0].n_paths, p[0].n_steps, K)) != 0) {
+        if (rc != (int)hipErrorOutOfMemory && rc != (int)hipErrorMemoryAllocation) return rc;
+        K /= 2;
+    }
+    if (K < 2) K = 1;
+    if (c->comm && omc::comm_world(c->comm) > 1) {
+        if ((rc = c->result.ensure(sizeof(double) * 8))) return rc;
+        double neg = -(double)K;
+        double* d = (double*)c->result.p;
+        HIP_TRY(hipMemcpyAsync(d, &neg, sizeof neg, hipMemcpyHostToDevice, c->stream));
+        std::string err;
+        if ((rc = omc::comm_allreduce_f64(c->comm, d, 1, 1 /* max */, c->stream, &err))) return fail(rc, err.c_str());
+        HIP_TRY(hipMemcpyAsync(&neg, d, sizeof neg, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        K = (int)llround(-neg);
+    }
+    *K_out = K < 2 ? 1 : K;
+    return 0;
 }
 
 static int enqueue_seq_step_multi(omc_ctx* c, const omc_params* p, int n, int K, double* dst)
@@ -1504,6 +1516,7 @@ static int enqueue_seq_step_multi(omc_ctx* c, const omc_params* p, int n, int K,
             }
             HIP_TRY(omc::p2p_set_jobs(c->p2p, c->stream, parts, gm, nb, gs, Kb));
         }
+        if (i0 == 0 && p2p) omc::p2p_begin_call(c->p2p);  // its first exchange absorbs start-up skew
         if (i0 == 0) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         for (int k = 0; k < Kb; ++k)
             if ((rc = enqueue_paths(c, &p[i0 + k], (float*)((char*)c->mS.p + sbytes * (size_t)k), ld))) return rc;
@@ -1558,42 +1571,38 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     if (!c->ev_seq) HIP_TRY(hipEventCreate(&c->ev_seq));
     ev_end = c->ev_seq;
     const bool overlapped = seq_can_overlap(c, p, n);
-    const int multi = overlapped ? 1 : seq_multi_width(c, p, n);
-    for (int attempt = 0;; ++attempt) {
-        c->persist_used = 0;
-        if (overlapped && (rc = enqueue_seq_overlapped(c, p, n, c->seq_pin))) return rc;
-        // across GPUs the sums stay in device memory (one slot per pricing) and are all-reduced together after
-        // the last pricing -- the hook / communicator sees ONE call with 8n doubles -- then copied out
-        const bool dist = c->distributed() && !overlapped;
-        if (dist && (rc = c->seq_local.ensure(sizeof(double) * 8 * (size_t)n))) return rc;
-        double* local = (double*)c->seq_local.p;
-        c->defer_result_allreduce = dist;
-        if (multi > 1 && (rc = enqueue_seq_step_multi(c, p, n, multi, dist ? local : c->seq_dev))) {
-            c->defer_result_allreduce = false;
-            return rc;
-        }
-        for (int i = 0; i < n && !overlapped && multi <= 1; ++i) {
-            hipEvent_t* evs = nullptr;
-            const int smp = seq_sample_index(c, i);
-            if (smp >= 0 && (rc = sample_events(c, smp, &evs))) break;
-            rc = enqueue_pricing(c, &p[i], nullptr, 0, dist ? local + 8 * (size_t)i : c->seq_dev + 8 * (size_t)i,
-                                 evs, nullptr);
-            if (rc) break;
-            if (evs && smp == 0 && hipEventRecord(evs[2], c->stream) != hipSuccess) { rc = fail(999, "hipEventRecord failed"); break; }
-        }
+    int multi = overlapped ? 1 : seq_multi_width(c, p, n);
+    if (multi > 1 && (rc = seq_multi_reserve(c, p, multi, &multi))) return rc;
+    if (overlapped && (rc = enqueue_seq_overlapped(c, p, n, c->seq_pin))) return rc;
+    // across GPUs the sums stay in device memory (one slot per pricing) and are all-reduced together after
+    // the last pricing -- the hook / communicator sees ONE call with 8n doubles -- then copied out
+    const bool dist = c->distributed() && !overlapped;
+    if (dist && (rc = c->seq_local.ensure(sizeof(double) * 8 * (size_t)n))) return rc;
+    double* local = (double*)c->seq_local.p;
+    c->defer_result_allreduce = dist;
+    if (multi > 1 && (rc = enqueue_seq_step_multi(c, p, n, multi, dist ? local : c->seq_dev))) {
         c->defer_result_allreduce = false;
-        if (rc) return rc;
-        if (dist) {
-            if ((rc = allreduce(c, local, 8 * n))) return rc;
-            HIP_TRY(hipMemcpyAsync(c->seq_pin, local, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        }
-        HIP_TRY(hipEventRecord(ev_end, c->stream));
-        if ((rc = wait_stream(c))) return rc;
-        if ((rc = check_p2p(c))) return rc;
-        bool redo = false;
-        for (int i = 0; i < n && attempt == 0; ++i) redo = redo || persistent_gave_up(c, c->seq_pin + 8 * (size_t)i);
-        if (!redo) break;
+        return rc;
     }
+    for (int i = 0; i < n && !overlapped && multi <= 1; ++i) {
+        hipEvent_t* evs = nullptr;
+        const int smp = seq_sample_index(c, i);
+        if (smp >= 0 && (rc = sample_events(c, smp, &evs))) break;
+        rc = enqueue_pricing(c, &p[i], nullptr, 0, dist ? local + 8 * (size_t)i : c->seq_dev + 8 * (size_t)i,
+                             evs, nullptr);
+        if (rc) break;
+        if (evs && smp == 0 && hipEventRecord(evs[2], c->stream) != hipSuccess) { rc = fail(999, "hipEventRecord failed"); break; }
+    }
+    c->defer_result_allreduce = false;
+    if (rc) return rc;
+    if (dist) {
+        if (c->p2p_used) HIP_TRY(omc::p2p_stamp_results(c->p2p, c->stream, local, n));  // (enqueue_lsm stamps one at a time)
+        if ((rc = allreduce(c, local, 8 * n))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->seq_pin, local, sizeof(double) * 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipEventRecord(ev_end, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    if ((rc = check_p2p(c, c->seq_pin, n))) return rc;
     float ms_all = 0;
     HIP_TRY(hipEventElapsedTime(&ms_all, c->ev[0], ev_end));
     // kernel times: a pricing that carried events reports its own, the others those of the latest one before them

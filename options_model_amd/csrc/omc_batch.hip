@@ -324,7 +324,7 @@ void batch_build(const BatchItem* items, int n, bool american, bool two_pass, ch
         s.sx = (float*)(slab + L.sx); s.tex = (int32_t*)(slab + L.tex); s.live = (float*)(slab + L.ex); s.D = D;
         s.part = part;
         s.gmom = (double*)(slab + L.gmom); s.betas = (double*)(slab + L.betas);
-        s.t = 0; s.nblk = L.nblk_sweep; s.external = 0; s.pstride = L.pstride; s.gstride = 8; s.cont = nullptr; s.ldc = 0; s.dbg = nullptr;
+        s.t = 0; s.nblk = L.nblk_sweep; s.external = 0; s.pstride = L.pstride; s.gstride = 8; s.cont = nullptr; s.ldc = 0;
         Pass1Args& a1 = p.p1;
         a1.S = s.S; a1.ld = L.ld; a1.M = M; a1.N = N; a1.is_put = it.is_put; a1.K = it.K; a1.invK = s.invK;
         a1.D = D; a1.part1 = two_pass ? (double*)(slab + L.part1) : nullptr; a1.ntiles = L.ntiles; a1.tchunk = 16;

@@ -84,7 +84,6 @@ struct LsmWorkspace {
     double* result;   // [8] sum, sumsq, n_exercised, n_zero, sum_nitm, -, -, -
     const float* cont = nullptr;  // per-step sweeps, "values" mode: continuation values [N+1][ldc]
     int64_t ldc = 0;
-    unsigned long long* dbg = nullptr;  // measurement builds: in-kernel time stamps [N+1][nblk][8]
     // optional: events recorded right around the two big kernels of the two-pass flow
     hipEvent_t ev_p1_begin = nullptr, ev_p1_end = nullptr, ev_p2_begin = nullptr, ev_p2_end = nullptr;
 };
@@ -118,15 +117,6 @@ hipError_t lsm_reduce_step_moments_multi(hipStream_t st, const void* table_dev, 
 hipError_t lsm_final_multi(hipStream_t st, const void* table_dev, int K, int64_t M);
 hipError_t lsm_sweep_indirect(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, int semantics,
                               const void* args_dev);
-
-// The per-step REFERENCE sweep as one persistent launch (omc_lsm_persist.hip): state on chip, the per-step
-// grid-wide dependency as an in-launch all-gather.  `scratch`: lsm_persist_scratch_bytes() of device memory.
-// result[7] != 0 afterwards: a bounded spin gave up (workgroups not co-resident) -- results invalid, rerun
-// with the launch-per-step sweep.
-size_t lsm_persist_scratch_bytes();
-bool lsm_persist_supported(const LsmProblem& p, int device_cus);
-hipError_t lsm_sweep_persistent(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w, void* scratch,
-                                bool write_state, double spin_seconds);
 
 // two-pass flow (semantics 2)
 hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w);

@@ -29,12 +29,6 @@ __global__ __launch_bounds__(BLOCK) void lsm_step_kernel(StepArgs a)
     lsm_step_body<SEM, VEC, BLOCK>(a, blockIdx.x, a.nblk);
 }
 
-// measurement build (omc_set_option "step_stamps"): same kernel with in-kernel time stamps
-__global__ __launch_bounds__(1024) void lsm_step_stamp_kernel(StepArgs a)
-{
-    lsm_step_body<0, 4, 1024, true>(a, blockIdx.x, a.nblk);
-}
-
 // the same with the argument block in device memory: the N launches of one sweep differ only in `t`,
 // so a captured HIP graph of them can be replayed for any pricing of the same geometry after
 // refreshing that block
@@ -54,14 +48,6 @@ __global__ __launch_bounds__(kBlock) void lsm_reduce_step_kernel(const double* p
 
 template <int VEC, int TPW, int PUT>
 __global__ __launch_bounds__(kBlock) void lsm_pass1_kernel(Pass1Args a) { lsm_pass1_body<VEC, TPW, PUT>(a); }
-
-// measurement builds only (-DOMC_DIAG_BUILD, then OMC_PASS1_DIAG=1|2|3; wrong results by construction): which
-// part of the kernel costs what.  Not compiled into the product library: no environment variable can make a
-// default build return wrong prices.
-#ifdef OMC_DIAG_BUILD
-template <int DIAG>
-__global__ __launch_bounds__(kBlock) void lsm_pass1_diag_kernel(Pass1Args a) { lsm_pass1_body<4, 4, 1, DIAG>(a); }
-#endif
 
 __global__ __launch_bounds__(kBlock) void lsm_reduce_pass1_kernel(const double* part1, double* gmom,
                                                                   int64_t ntiles, int N)
@@ -185,7 +171,6 @@ static void fill_step_args(StepArgs& a, const LsmProblem& p, const LsmWorkspace&
     a.pstride = kPStride;
     a.gstride = w.gstride;
     a.cont = w.cont; a.ldc = w.ldc;
-    a.dbg = w.dbg;
 }
 
 template <int SEM, int VEC, int BLOCK>
@@ -205,10 +190,6 @@ static hipError_t lsm_step_impl(hipStream_t st, const LsmProblem& p, const LsmWo
     const bool v4 = vec4_ok(p);
     const size_t dyn = semantics == 1 ? sizeof(double) * (size_t)(p.N + 1) : 0;
     const bool big = lsm_step_block_threads() == 1024;
-    if (w.dbg && !ind && semantics == 0 && v4 && big) {
-        hipLaunchKernelGGL(lsm_step_stamp_kernel, dim3(a.nblk), dim3(1024), 0, st, a);
-        return hipGetLastError();
-    }
 #define OMC_STEP(SEM, VEC)                                                       \
     do {                                                                         \
         if (big) launch_step<SEM, VEC, 1024>(st, a, ind, t, dyn);               \
@@ -362,18 +343,6 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     a.tchunk = (tch_env >= 2 && tch_env <= 126) ? tch_env : tchunk;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
-#ifdef OMC_DIAG_BUILD
-    static const int diag_env = getenv("OMC_PASS1_DIAG") ? atoi(getenv("OMC_PASS1_DIAG")) : 0;
-    if (diag_env >= 1 && diag_env <= 3 && v4 && tpw == 4 && p.is_put) {
-        if (diag_env == 1) hipLaunchKernelGGL((lsm_pass1_diag_kernel<1>), grid, dim3(kBlock), 0, st, a);
-        else if (diag_env == 2) hipLaunchKernelGGL((lsm_pass1_diag_kernel<2>), grid, dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((lsm_pass1_diag_kernel<3>), grid, dim3(kBlock), 0, st, a);
-        if (w.ev_p1_end) (void)hipEventRecord(w.ev_p1_end, st);
-        hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1, 8), dim3(kBlock), 0, st, w.part1, w.gmom,
-                           a.ntiles, p.N);
-        return hipGetLastError();
-    }
-#endif
     auto launch = [&](auto vec, auto tp) {
         constexpr int V = decltype(vec)::value, T = decltype(tp)::value;
         if (p.is_put) hipLaunchKernelGGL((lsm_pass1_kernel<V, T, 1>), grid, dim3(kBlock), 0, st, a);

@@ -79,8 +79,6 @@ struct StepArgs {
     // (float32, as the reference's networks return it) instead of the fitted polynomial
     const float* cont;
     int64_t ldc;
-    // diagnostic builds only (STAMP): 8 s_memrealtime stamps (100 MHz) per launch and workgroup
-    unsigned long long* dbg;
 };
 
 // One launch per time step t = N .. 1 (the launch boundary is the grid-wide barrier the
@@ -114,21 +112,10 @@ constexpr int kStepMaxBlocks = 256;
 constexpr int kStepPL = kStepMaxBlocks / 64;
 constexpr int kStepMaxItems = 32;  // slots one workgroup walks at most (K <= 32 pricings per launch)
 
-template <int SEM, int VEC, int BLOCK, bool STAMP = false>
+template <int SEM, int VEC, int BLOCK>
 __device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int G)
 {
     constexpr int WAVES = BLOCK / 64;
-    // STAMP: where a launch spends its time, seen from wave 0 of every workgroup (the wave on the
-    // critical path: it owns the prologue).  Values leave through a.dbg only.
-    unsigned long long stamp[8];
-    auto mark = [&](int k) {
-        if constexpr (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            stamp[k] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    mark(0);
     __shared__ double wl[WAVES * kWaveRedDoubles];
     __shared__ double sh_w[kStepMaxItems * WAVES * 8];
     __shared__ double sh_beta[4];
@@ -238,17 +225,12 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int
 #pragma unroll
                     for (int i = 1; i < kStepPL; ++i) acc[q] += pv[i][q];
                 }
-                if constexpr (STAMP) {
-                    asm volatile("s_waitcnt vmcnt(4)");  // the partials are in (4 row loads behind them)
-                    mark(1);
-                }
                 const double s = wave_reduce8(acc, wl);  // total of quantity lane >> 3 in every lane
 #pragma unroll
                 for (int q = 0; q < 8; ++q) m[q] = __shfl(s, 8 * q);
             }
             double beta[3];
             solve_poly2(m, beta);  // every lane, same result
-            mark(2);
             if (lane == 0) {
                 sh_beta[0] = beta[0]; sh_beta[1] = beta[1]; sh_beta[2] = beta[2]; sh_beta[3] = m[0];
                 if (w == 0) {
@@ -265,11 +247,6 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int
         b0 = sh_beta[0]; b1 = sh_beta[1]; b2 = sh_beta[2]; nfit = sh_beta[3];
     } else if (SEM == 1 && do_mom) {
         __syncthreads();
-    }
-    mark(3);
-    if constexpr (STAMP) {
-        asm volatile("s_waitcnt vmcnt(0)");  // this wave's first rows / state are in
-        mark(4);
     }
 
     const double Dm = do_mom ? a.D[N - (t - 1)] : 0.0;
@@ -381,25 +358,14 @@ __device__ __forceinline__ void lsm_step_body(StepArgs a, const int w, const int
         consume(B, lB);
         fetch(B, vB, lB);
     }
-    mark(5);
     if (do_mom) {
         __syncthreads();
-        mark(6);
         if (tid < 8 * item) {  // one thread per (slot, quantity): waves added in wave order
             const int it = tid >> 3, q = tid & 7;
             double tot = 0.0;
 #pragma unroll
             for (int ww = 0; ww < WAVES; ++ww) tot += sh_w[(it * WAVES + ww) * 8 + q];
             a.part[(size_t)((t - 1) & 1) * 8 * a.pstride + (size_t)q * a.pstride + (w + it * G)] = tot;
-        }
-    }
-    if constexpr (STAMP) {
-        asm volatile("s_waitcnt vmcnt(0)");
-        mark(7);
-        if (tid == 0 && a.dbg) {
-            unsigned long long* d = a.dbg + ((size_t)(N - t) * a.nblk + w) * 8;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) d[k] = stamp[k];
         }
     }
 }
@@ -457,9 +423,7 @@ struct Pass1Args {
 // The next step's rows are loaded before the current one is reduced.
 // Targets are the discounted TERMINAL payoffs.
 // PUT: 1 put, 0 call, -1 decided at run time (the batched launch mixes both).
-// DIAG (measurement builds only, results are wrong): 1 = arithmetic only (rows loaded once per chunk),
-// 2 = loads only (rows folded into one integer), 3 = no per-step wave reduce.
-template <int VEC, int TPW, int PUT = -1, int DIAG = 0>
+template <int VEC, int TPW, int PUT = -1>
 __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
 {
     __shared__ double wl[kBlock / 64][kWaveRedDoubles];
@@ -499,22 +463,10 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
             pN[k][v] = (valid[k] && p > 0.0) ? p : 0.0;
         }
     }
-    bool diag_loaded = false;
     auto load_rows = [&](float (&buf)[TPW][VEC], int t) {
-        if (DIAG == 1) {
-            if (diag_loaded) {  // keep the registers "defined by something" without a memory access
-#pragma unroll
-                for (int k = 0; k < TPW; ++k)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) asm volatile("" : "+v"(buf[k][v]));
-                return;
-            }
-        }
 #pragma unroll
         for (int k = 0; k < TPW; ++k) loadf_stream<VEC>(colp[k] + (int64_t)t * a.ld, buf[k]);
     };
-    uint32_t diag_fold = 0;
-    double diag_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // Branch-free accumulation: an out-of-the-money (or padding) path contributes u = 0, p = 0
     // (adding +0.0 is exact, so the sums are those of the masked loop, bit for bit), and the
     // step's discount factor multiplies the three target sums once per lane instead of once per
@@ -528,13 +480,6 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     for (int k = 0; k < TPW; ++k) thrk[k] = valid[k] ? thr : (is_put ? -__builtin_inff() : __builtin_inff());
     auto process = [&](auto put_tag, const float (&buf)[TPW][VEC], int t) {
         constexpr bool IS_PUT = decltype(put_tag)::value;
-        if (DIAG == 2) {
-#pragma unroll
-            for (int k = 0; k < TPW; ++k)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) diag_fold ^= __float_as_uint(buf[k][v]);
-            return;
-        }
         double acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.0;
@@ -565,12 +510,10 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
             for (int v = 0; v < VEC; ++v) u2[v] = u[v] * u[v];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-#ifndef OMC_EXP_USUMS  // (experiment build: the four target-free sums are the generator's job, see omc_paths_dev.h)
                 acc[1] += u[v];
                 acc[2] += u2[v];
                 acc[3] = fma(u2[v], u[v], acc[3]);
                 acc[4] = fma(u2[v], u2[v], acc[4]);
-#endif
                 acc[5] = fma(pN[k][v], m[v], acc[5]);
                 acc[6] = fma(u[v], pN[k][v], acc[6]);
                 acc[7] = fma(u2[v], pN[k][v], acc[7]);
@@ -581,11 +524,6 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         acc[5] *= d;
         acc[6] *= d;
         acc[7] *= d;
-        if (DIAG == 3) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) diag_acc[q] += acc[q];
-            return;
-        }
         const double s = wave_reduce8(acc, wl[wave]);
         if ((lane & 7) == 0) a.part1[((size_t)t * 8 + (lane >> 3)) * a.ntiles + tg] = s;
     };
@@ -604,10 +542,6 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     auto sweep = [&](auto put_tag) {
         load_rows(bufA, t0);
         load_rows(bufB, min(t0 + 1, tl));
-        if (DIAG == 1) {
-            load_rows(bufC, tl);
-            diag_loaded = true;
-        }
         for (int t = t0; t < t1; t += 3) {
             load_rows(bufC, min(t + 2, tl));
             __builtin_amdgcn_sched_barrier(0);
@@ -628,13 +562,6 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         sweep(std::true_type{});
     else
         sweep(std::false_type{});
-    if (DIAG == 2) {
-        if (diag_fold == 0x12345678u) a.part1[tg] = 1.0;  // keeps the loads alive, practically never taken
-    }
-    if (DIAG == 3) {
-        const double s = wave_reduce8(diag_acc, wl[wave]);
-        if ((lane & 7) == 0) a.part1[((size_t)t0 * 8 + (lane >> 3)) * a.ntiles + tg] = s;
-    }
 }
 
 __device__ __forceinline__ void lsm_reduce_pass1_body(const double* __restrict__ part1,

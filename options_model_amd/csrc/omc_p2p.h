@@ -22,12 +22,15 @@ int p2p_connect(P2P* p, int rank, int world, const void* handles, std::string* e
 void p2p_destroy(P2P* p);
 bool p2p_connected(const P2P* p);
 int p2p_world(const P2P* p);
-void p2p_set_deadline(P2P* p, double seconds);
+void p2p_set_deadline(P2P* p, double seconds, double first_seconds);
+void p2p_begin_call(P2P* p);  // the next exchange is a call's first: it waits first_seconds
 // one exchange = reduce this rank's partials of step t, publish to all peers, gather, sum in rank order -> gmom[t]
 hipError_t p2p_exchange_step(P2P* p, hipStream_t st, const LsmWorkspace& w, int t, int nblk);
 hipError_t p2p_set_jobs(P2P* p, hipStream_t st, const double* const* part, double* const* gmom, const int* nblk,
                         const int* gstride, int n);
 hipError_t p2p_exchange_step_multi(P2P* p, hipStream_t st, int K, int t);
 hipError_t p2p_error_word(P2P* p, hipStream_t st, unsigned long long* out);
+// results[i * 8 + 6] = (this rank's error word != 0) for i < n, ahead of the all-reduce of the result sums
+hipError_t p2p_stamp_results(P2P* p, hipStream_t st, double* results, int n);
 
 }  // namespace omc

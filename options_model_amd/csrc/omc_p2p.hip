@@ -16,6 +16,12 @@
 //     e & 1 is never overwritten before it has been read.  Epochs only grow: nothing is ever reset.
 // Bounded: a flag that does not arrive within the deadline sets a sticky error word in the rank's own memory (later
 // exchanges return at once), the sums become NaN, the host reports an error -- never a hang.
+// COLLECTIVE failure: a rank whose error word is set publishes a POISON flag (the largest epoch) instead of its
+// epoch into every peer's mailbox, in both parities, from then on; a peer that reads it sets its own error word
+// (and poisons in turn).  A rank that is merely slow -- alive, but past a peer's deadline -- can therefore not leave
+// the others with finite sums built on a contribution that was given up on: the next exchange fails everywhere.
+// What a poison cannot reach any more (the failure happened in a pricing's LAST exchange) is caught by the host:
+// every rank adds its error word to slot 6 of the result sums before their all-reduce (p2p_stamp_results).
 // The reference has no counterpart (no distributed code at all).
 #include "omc_lsm_dev.h"
 #include "omc_p2p.h"
@@ -37,6 +43,8 @@ struct P2PJob {  // one pricing: where its partials are and where the global mom
     double* gmom;
     int nblk, pstride, gstride, pad;
 };
+
+constexpr unsigned long long kPoison = ~0ull;  // epochs only grow and never get here
 
 struct P2PArgs {
     Mailbox* box[kP2PMaxWorld];  // every rank's mailbox as mapped in THIS process (own included)
@@ -71,16 +79,24 @@ __device__ __forceinline__ void exchange_body(const P2PJob& j, const P2PArgs& a,
             __hip_atomic_store(&a.box[r]->data[par][a.rank][k * 8 + q], loc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the wave's stores above have left before the flags do
+        const bool dead = __hip_atomic_load(&own->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
         if (tid < a.world)
-            __hip_atomic_store(&a.box[tid]->flag[par][a.rank][k], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&a.box[tid]->flag[par][a.rank][k], dead ? kPoison : a.epoch, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
         // 3. ... and waits for every rank's flag in its own mailbox (bounded)
-        bool ok = true;
+        bool ok = true, poisoned = false;
         if (tid < a.world) {
             ok = false;
-            if (__hip_atomic_load(&own->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+            if (!dead) {
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
-                    if (__hip_atomic_load(&own->flag[par][tid][k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= a.epoch) {
+                    const unsigned long long f =
+                        __hip_atomic_load(&own->flag[par][tid][k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (f == kPoison) {
+                        poisoned = true;
+                        break;
+                    }
+                    if (f >= a.epoch) {
                         ok = true;
                         break;
                     }
@@ -90,7 +106,16 @@ __device__ __forceinline__ void exchange_body(const P2PJob& j, const P2PArgs& a,
             }
         }
         const bool all = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-        if (!all && tid == 0) __hip_atomic_store(&own->error, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!all) {
+            // 1 = own deadline ran out, 2 = a peer had given up; sticky
+            const bool any_poison = __builtin_amdgcn_ballot_w64(poisoned) != 0ull;
+            if (tid == 0 && !dead)
+                __hip_atomic_store(&own->error, any_poison ? 2ull : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < a.world) {  // tell every peer, in the slot of this exchange AND of the next one
+                __hip_atomic_store(&a.box[tid]->flag[par][a.rank][k], kPoison, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&a.box[tid]->flag[par ^ 1][a.rank][k], kPoison, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         if (tid == 0) arrived = all ? 1 : 0;
     }
@@ -114,6 +139,15 @@ __global__ __launch_bounds__(kBlock) void p2p_exchange_multi_kernel(const P2PJob
     exchange_body(jobs[blockIdx.x], a, (int)blockIdx.x);
 }
 
+// slot 6 of each of n result vectors (8 doubles each) := this rank's error word as 0 / 1, so that the all-reduce of the
+// result sums carries "some rank's exchange gave up" to every rank
+__global__ void p2p_stamp_kernel(double* results, int n, const Mailbox* own)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        results[(size_t)i * 8 + 6] = __hip_atomic_load(&own->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;
+}
+
 }  // namespace
 
 struct P2P {
@@ -122,6 +156,8 @@ struct P2P {
     Mailbox* box[kP2PMaxWorld] = {};
     unsigned long long epoch = 0;
     double deadline_s = 2.0;
+    double first_deadline_s = 30.0;  // the first exchange of a call: ranks may still be loading code objects / allocating
+    bool next_is_first = true;
     P2PJob* jobs_dev = nullptr;  // kP2PMaxPricings entries
 };
 
@@ -192,7 +228,12 @@ void p2p_destroy(P2P* p)
 
 bool p2p_connected(const P2P* p) { return p && p->box[p->rank] != nullptr && p->world >= 1 && p->box[0] != nullptr; }
 int p2p_world(const P2P* p) { return p ? p->world : 0; }
-void p2p_set_deadline(P2P* p, double seconds) { if (p && seconds > 0) p->deadline_s = seconds; }
+void p2p_set_deadline(P2P* p, double seconds, double first_seconds)
+{
+    if (p && seconds > 0) p->deadline_s = seconds;
+    if (p && first_seconds > 0) p->first_deadline_s = first_seconds;
+}
+void p2p_begin_call(P2P* p) { if (p) p->next_is_first = true; }
 
 static P2PArgs make_args(P2P* p, int t, int njobs)
 {
@@ -200,7 +241,11 @@ static P2PArgs make_args(P2P* p, int t, int njobs)
     for (int r = 0; r < kP2PMaxWorld; ++r) a.box[r] = p->box[r];
     a.rank = p->rank; a.world = p->world; a.t = t; a.njobs = njobs;
     a.epoch = ++p->epoch;
-    a.deadline_ticks = (unsigned long long)(p->deadline_s * 1e8);
+    // Nothing aligns the ranks before a call's first exchange (a first-use code-object load or a multi-GB allocation
+    // on one rank can skew them by seconds): that one waits first_deadline_s, every later one deadline_s.
+    const double dl = p->next_is_first && p->first_deadline_s > p->deadline_s ? p->first_deadline_s : p->deadline_s;
+    p->next_is_first = false;
+    a.deadline_ticks = (unsigned long long)(dl * 1e8);
     return a;
 }
 
@@ -230,6 +275,13 @@ hipError_t p2p_set_jobs(P2P* p, hipStream_t st, const double* const* part, doubl
 hipError_t p2p_exchange_step_multi(P2P* p, hipStream_t st, int K, int t)
 {
     hipLaunchKernelGGL(p2p_exchange_multi_kernel, dim3(K), dim3(kBlock), 0, st, (const P2PJob*)p->jobs_dev, make_args(p, t, K));
+    return hipGetLastError();
+}
+
+hipError_t p2p_stamp_results(P2P* p, hipStream_t st, double* results, int n)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(p2p_stamp_kernel, dim3((n + 63) / 64), dim3(64), 0, st, results, n, (const Mailbox*)p->own);
     return hipGetLastError();
 }
 

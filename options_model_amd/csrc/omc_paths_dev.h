@@ -8,25 +8,14 @@
 namespace omc {
 
 
-#ifndef OMC_NT_STORE
-#define OMC_NT_STORE 0  // experiment: path rows written with the nontemporal hint
-#endif
-
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
 {
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    if constexpr (VEC == 1) {
-        if (OMC_NT_STORE) __builtin_nontemporal_store(v[0], p);
-        else *p = v[0];
-    } else if constexpr (VEC == 2) {
-        if (OMC_NT_STORE) __builtin_nontemporal_store((f2v){v[0], v[1]}, reinterpret_cast<f2v*>(p));
-        else *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
-    } else {
-        if (OMC_NT_STORE) __builtin_nontemporal_store((f4v){v[0], v[1], v[2], v[3]}, reinterpret_cast<f4v*>(p));
-        else *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    }
+    // plain stores: the nontemporal hint on these rows only moves time from this kernel to the next reader
+    // (measured)
+    if constexpr (VEC == 1) *p = v[0];
+    else if constexpr (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    else *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // ------------------------------------------------------------------ GBM
@@ -48,14 +37,6 @@ struct PathArgs {
     uint32_t k0, k1, stream;
     uint64_t pair_offset;
 };
-
-#ifdef OMC_EXP_USUMS
-// EXPERIMENT BUILD ONLY (-DOMC_EXP_USUMS, tools/exp_usums.sh): what would it cost the store-bound generator to also
-// form the four regression sums that need no target (sum u .. sum u^4 over the in-the-money paths, u = S/K - 1) per
-// time step, so that pass 1 could drop them?  K = 100, put, hard-wired; per step a wave reduction and one store of
-// the wave's partials into a scratch array.  Results of the pricing are unaffected (nothing reads the scratch).
-__device__ double g_exp_usums[256 * 2048 * 8];
-#endif
 
 template <int VEC, bool ANTI>
 __device__ __forceinline__ void gbm_paths_body(const PathArgs& g)
@@ -95,30 +76,6 @@ __device__ __forceinline__ void gbm_paths_body(const PathArgs& g)
                     sa[v] = sa[v] * fast_exp2(__builtin_fmaf(-b, z[v][i], a));
                 store_vec<VEC>(row + P, sa);
             }
-#ifdef OMC_EXP_USUMS
-            {
-                __shared__ double wl_exp[kBlock / 64][kWaveRedDoubles];
-                double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                auto add = [&](float sv) {
-                    const double m = sv < 100.0f ? 1.0 : 0.0;
-                    const double u = fma((double)sv, 0.01, -1.0) * m;
-                    const double u2 = u * u;
-                    acc[1] += u;
-                    acc[2] += u2;
-                    acc[3] = fma(u2, u, acc[3]);
-                    acc[4] = fma(u2, u2, acc[4]);
-                };
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    add(s[v]);
-                    if (ANTI) add(sa[v]);
-                }
-                const double sred = wave_reduce8(acc, wl_exp[threadIdx.x >> 6]);
-                const int wave_id = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-                if ((threadIdx.x & 7) == 0 && t < 256 && wave_id < 2048)
-                    g_exp_usums[((size_t)t * 2048 + wave_id) * 8 + ((threadIdx.x & 63) >> 3)] = sred;
-            }
-#endif
         }
     }
 }

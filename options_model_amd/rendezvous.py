@@ -34,11 +34,31 @@ STALE_SLACK_S = 30.0  # ranks of one launch start within seconds of each other
 
 
 def _process_start() -> float:
+    """Wall-clock start time of THIS process: psutil, else /proc (start time in clock ticks since boot + the boot
+    time), else the import time of this module -- which can be long after the start (a rank that imports this module
+    more than STALE_SLACK_S after rank 0 published would reject rank 0's frame as stale), hence only the last resort."""
     try:
         import psutil
         return float(psutil.Process().create_time())
     except Exception:
+        pass
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])  # field 22 (starttime); the comm field may hold spaces
+        with open("/proc/stat") as f:
+            btime = next(float(ln.split()[1]) for ln in f if ln.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
         return _IMPORT_TIME
+
+
+def _not_before() -> float:
+    """Frames older than this are leftovers of an earlier launch.  A launch that carries a nonce (launcher.py,
+    bench.py, torchrun's run id) has file names no other launch can produce: nothing to reject there."""
+    nonce = os.environ.get("OMC_RDZV_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID")
+    if nonce and nonce != "none":
+        return 0.0
+    return _process_start() - STALE_SLACK_S
 
 
 _IMPORT_TIME = time.time()
@@ -140,7 +160,7 @@ def publish(payload: bytes, tag: str | None = None) -> str:
 def fetch(nbytes: int, tag: str | None = None, timeout_s: float = 120.0) -> bytes:
     """Ranks > 0: wait for rank 0's payload.  Raises TimeoutError -- never hangs the job."""
     paths = [os.path.join(d, _name(tag)) for d in _dirs()]
-    not_before = _process_start() - STALE_SLACK_S
+    not_before = _not_before()
     t0 = time.monotonic()
     while True:
         for path in paths:
@@ -173,7 +193,7 @@ def exchange(rank: int, make_payload, nbytes: int, tag: str | None = None, timeo
 # ------------------------------------------------------------------ a collective yes / no
 def _collect(base: str, kind: str, world: int, phase: str, timeout_s: float) -> dict:
     got, missing = {}, set(range(world))
-    not_before = _process_start() - STALE_SLACK_S
+    not_before = _not_before()
     t0 = time.monotonic()
     while missing:
         for r in sorted(missing):

@@ -235,6 +235,7 @@ from options_model_amd.dist import RcclPricer
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 sp = RcclPricer(0, rank, world)
 assert sp.enable_p2p()
+sp.ctx.set_option("p2p_first_deadline_ms", 2000)            # (default 30 s: a call's first exchange absorbs start-up skew)
 kw = dict(semantics="reference", n_steps=12, seed=9)
 sp.price_american(40_000 * world, stream=1, **kw)          # one good pricing: the mailboxes work
 if rank == 1:
@@ -275,6 +276,55 @@ def test_a_lost_peer_ends_the_direct_exchange_with_an_error_not_a_hang(standin, 
     status = [ln for ln in so.splitlines() if ln.startswith("STATUS")][0]
     assert status.endswith(", 1)"), status       # the sticky error word
     assert took < 60
+
+_P2P_SLOW = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+from options_model_amd import _ffi
+from options_model_amd.dist import RcclPricer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+sp = RcclPricer(0, rank, world)
+assert sp.enable_p2p()
+sp.ctx.set_option("p2p_deadline_ms", 300)
+sp.ctx.set_option("p2p_first_deadline_ms", 300)
+kw = dict(semantics="reference", n_steps=12, seed=9)
+good = sp.price_american(40_000 * world, stream=1, **kw)   # one good pricing: the mailboxes work
+if rank == 1:
+    time.sleep(2.0)                                          # SLOW, not dead: 1.7 s past rank 0's deadline, then it joins
+try:
+    out = sp.price_american(40_000 * world, stream=2, **kw)
+    print("RESULT price %%r" %% out["price"])
+except _ffi.OmcError as e:
+    print("RESULT error: %%s" %% e)
+print("STATUS", sp.ctx.p2p_status())
+os._exit(0)
+"""
+
+
+def test_a_slow_peer_fails_the_exchange_on_every_rank(standin, tmp_path):
+    """rank 1 is two seconds late for a pricing whose exchange deadline is 0.3 s -- alive, not
+    lost.  Rank 0 gives up (error word 1) and from then on publishes poison instead of its epoch; rank 1, arriving late,
+    must NOT assemble a finite price from rank 0's abandoned contributions: it reads the poison, sets its own error word
+    (2) and fails too.  Both calls return 3100; neither returns a price."""
+    script = tmp_path / "p2p_slow.py"
+    script.write_text(_P2P_SLOW % ROOT)
+    port = 29990 + os.getpid() % 9
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMC_RCCL_LIB=standin, OMC_RDZV_NONCE=f"slow{os.getpid()}",
+                   OMC_STANDIN_TIMEOUT_S="30")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    lines, status = [], []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        lines.append([ln for ln in so.splitlines() if ln.startswith("RESULT")][0])
+        status.append([ln for ln in so.splitlines() if ln.startswith("STATUS")][0])
+    assert "error" in lines[0] and "timed out" in lines[0], lines
+    assert "error" in lines[1] and "another rank gave up" in lines[1], lines  # the slow rank fails as well
+    assert status[0].endswith(", 1)") and status[1].endswith(", 2)"), status
 
 
 def test_config3_shard_size_through_the_native_communicator(ctx, standin):

@@ -427,23 +427,3 @@ def test_per_step_sweep_graph_replay_equals_kernel_by_kernel(ctx, sem):
         assert (a["price"], a["sumsq"], a["n_exercised"], a["n_zero"], a["sum_nitm"]) == (
             b["price"], b["sumsq"], b["n_exercised"], b["n_zero"], b["sum_nitm"])
     assert res[1][0]["price"] == res[1][3]["price"]
-
-
-@pytest.mark.parametrize("M,N", [(40000, 30), (1_000_000, 64)])
-def test_persistent_sweep_option_equals_launch_per_step(ctx, M, N):
-    """omc_set_option "step_persistent": the whole per-step reference sweep as one launch with an in-launch
-    exchange of the partial moments (csrc/omc_lsm_persist.hip; opt-in -- measured slower than one launch per
-    step).  Same regression sets, same decisions; sums agree to rounding (another order inside a wave)."""
-    So = orc.gbm_paths(M, N, 100.0, R, SIG, T, 321) if M <= 100_000 else None
-    S = ctx.to_device(So) if So is not None else ctx.gbm_paths(M, N, 100.0, R, SIG, T, seed=321)
-    ctx.set_option("step_persistent", 0)
-    a = ctx.lsm_poly(S, K, R, T, True, "reference", want_state=True)
-    ctx.set_option("step_persistent", 1)
-    b = ctx.lsm_poly(S, K, R, T, True, "reference", want_state=True)
-    c = ctx.lsm_poly(S, K, R, T, True, "reference", want_state=False)
-    ctx.set_option("step_persistent", -1)
-    S.free()
-    assert np.array_equal(a["nitm"], b["nitm"]) and np.array_equal(a["tex"], b["tex"]) and np.array_equal(a["sx"], b["sx"])
-    assert b["price"] == pytest.approx(a["price"], rel=1e-13) and c["price"] == b["price"]
-    assert (a["n_exercised"], a["n_zero"], a["sum_nitm"]) == (b["n_exercised"], b["n_zero"], b["sum_nitm"])
-    assert np.allclose(a["betas"], b["betas"], rtol=1e-9, atol=1e-12)

@@ -1,15 +1,22 @@
 #!/bin/bash
-# Round-3 measurement steps, one per gpurun call:
-#   bash tools/gpu_r03.sh bench TAG   the driver's exact bench command + rocprofv3 kernel stats (two_pass, reference) + c3 / c4 lines
-#   bash tools/gpu_r03.sh pmc TAG     PMC passes: HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes)
+# Round-4 measurement steps, one per gpurun call:
+#   bash tools/gpu_r04.sh tests TAG   the driver's GPU test command (pytest -x -q -m gpu), then smoke
+#   bash tools/gpu_r04.sh bench TAG   the driver's exact bench command + rocprofv3 kernel stats (two_pass, reference) + c3 / c4 lines
+#   bash tools/gpu_r04.sh pmc TAG     PMC passes: HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes)
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 WHAT=${1:-bench}
-TAG=${2:-r03}
+TAG=${2:-r04}
 R="$GRAFT_REPO_ROOT"
 ok() { [ "$1" -ne 124 ] && [ "$1" -ne 137 ]; }
 case "$WHAT" in
+tests)
+  timeout -k 10 1000 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
+  tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
+  timeout -k 10 300 python __graft_entry__.py --smoke > gpurun_out/${TAG}_smoke.log 2>&1; rc=$?
+  tail -4 gpurun_out/${TAG}_smoke.log; echo "smoke exit=$rc"
+  ;;
 bench)
   timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_driver.json 2> gpurun_out/bench_${TAG}_driver.err; rc=$?
   echo "bench (driver's command) exit=$rc"; ok $rc || exit 1
