@@ -84,6 +84,7 @@ struct omc_ctx {
     DevBuf S, sx, tex, ex, D, part, gmom, betas, part1, result, scratch, sweep_args;
     DevBuf bslab, btable, bres, bdisc;  // batched path: problem slab, table, results, discounts
     DevBuf mlp_part, mlp_loss, mlp_wt;  // NN training: gradient partials, epoch loss, transposed connections
+    DevBuf mlp_gred, shard;             // sharded NN training: reduced gradient of a step; epoch selection tables
     DevBuf cn_scratch, cn_data, cn_net, cn_cont;  // per-step ContNet flow: set bookkeeping, rows, net + Adam state, values
     std::vector<char> h_table;
     std::vector<double> h_disc, h_bres;
@@ -281,6 +282,17 @@ int allreduce(omc_ctx* c, double* dptr, int count)
     if (c->hook) {
         if (c->hook(c->hook_user, dptr, count)) return fail(998, "all-reduce hook failed");
     }
+    return 0;
+}
+
+// the same for `n` host doubles (n <= 8 * rows of `dev`, a device scratch of the caller's): up, all-reduce, down, wait
+int allreduce_host(omc_ctx* c, double* dev, double* host, int n)
+{
+    int rc;
+    HIP_TRY(hipMemcpyAsync(dev, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = allreduce(c, dev, n))) return rc;
+    HIP_TRY(hipMemcpyAsync(host, dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -539,7 +551,7 @@ int omc_ctx_destroy(omc_ctx* c)
     c->p2p = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->sweep_args, &c->bslab, &c->btable, &c->bres, &c->bdisc,
-                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
+                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->mlp_gred, &c->shard, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
                       &c->mS, &c->mstate, &c->mtable, &c->mb_slab, &c->mb_table, &c->mb_bc})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
@@ -2004,18 +2016,25 @@ int omc_nn_build_rows(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
     for (int i = 0; i < 16; ++i) stats16[i] = i < 7 ? 0.0 : 1.0;
     stats16[0] = 1.0;  // the constant feature: mean 1, std 0 -> 1
     stats16[14] = 0.0;
-    if (R == 0) return 0;
+    if (R == 0 && !c->distributed()) return 0;  // (a rank without rows still takes part in the job's sums)
+    // On a context with a communicator / hook the statistics are those of ALL ranks' rows: the sums (slot 7 = row
+    // count) and then the squared deviations from the GLOBAL means are added over the ranks -- the two-pass formula
+    // of :550-563 over the union of the shards, in float64 -- and this rank's rows are normalised with them.
     double sums[8], mean[8], dev[8];
     HIP_TRY(omc::nn_rows_stats(c->stream, p, w.D, c->scratch.p, 0, nullptr, sums));
-    for (int q = 0; q < 8; ++q) mean[q] = sums[q] / (double)R;
+    if (c->distributed() && (rc = allreduce_host(c, w.gmom, sums, 8))) return rc;
+    const double Rg = c->distributed() ? sums[7] : (double)R;  // rows of the job
+    for (int q = 0; q < 8; ++q) mean[q] = sums[q] / Rg;
     HIP_TRY(omc::nn_rows_stats(c->stream, p, w.D, c->scratch.p, 1, mean, dev));
+    if (c->distributed() && (rc = allreduce_host(c, w.gmom, dev, 8))) return rc;
+    const double R_stat = Rg;
     // layout: feat_mean[0..6], feat_std[7..13], y_mean [14], y_std [15]; zero std -> 1 (:551-563)
     for (int q = 0; q < 6; ++q) {
-        const double sd = std::sqrt(dev[q] / (double)R);
+        const double sd = std::sqrt(dev[q] / R_stat);
         stats16[1 + q] = mean[q];
         stats16[8 + q] = sd > 1e-13 * std::fabs(mean[q]) ? sd : 1.0;
     }
-    const double ysd = std::sqrt(dev[6] / (double)R);
+    const double ysd = std::sqrt(dev[6] / R_stat);
     stats16[14] = mean[6];
     stats16[15] = ysd > 1e-13 * std::fabs(mean[6]) ? ysd : 1.0;
     HIP_TRY(omc::nn_rows_write(c->stream, p, w.D, c->scratch.p, stats16, stats16 + 7, stats16[14], stats16[15], data,
@@ -2081,6 +2100,124 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
     const int64_t nb = (n_rows + batch - 1) / batch;
     *step += nb;
     *mean_loss = acc / (double)nb;
+    return 0;
+}
+
+// ---- the NN regressor sharded over the ranks of a job (options_model_3.py:542-613)
+int omc_nn_half_counts(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, int is_put,
+                       int64_t* counts)
+{
+    int rc;
+    if ((rc = bind_in(c))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (!counts) return fail(-7, "null pointer.");
+    if (n_steps < 2) return 0;
+    const size_t bytes = sizeof(int64_t) * 2 * (size_t)(n_steps - 1);
+    if ((rc = c->scratch.ensure(bytes))) return rc;
+    omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, 0.0, 1.0};
+    HIP_TRY(omc::nn_rows_half_counts(c->stream, p, n_paths / 2, (int64_t*)c->scratch.p));
+    HIP_TRY(hipMemcpyAsync(counts, c->scratch.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int omc_mlp_shard_epoch(omc_ctx* c, const float* data, int64_t n_rows_local, int64_t rows_global, int64_t batch,
+                        uint64_t shuffle_key, const int64_t* gstart, const int64_t* lstart, int nseg, float* data_epoch,
+                        uint32_t* drop_pos, int64_t* step_off)
+{
+    int rc;
+    if ((rc = bind_in(c))) return rc;
+    if (!gstart || !lstart || !step_off || (n_rows_local > 0 && (!data || !data_epoch || !drop_pos)))
+        return fail(-7, "null pointer.");
+    if (n_rows_local < 0 || rows_global <= 0 || batch <= 0 || nseg <= 0 || n_rows_local > rows_global)
+        return fail(-3, "row counts, batch and segment count must be positive.");
+    if (gstart[0] != 0 || gstart[nseg] != rows_global) return fail(-4, "segment table does not cover [0, rows_global).");
+    const int64_t steps = (rows_global + batch - 1) / batch;
+    // scratch: segment tables | selection scan | sel_row, sel_i | step offsets
+    const size_t tab = sizeof(int64_t) * (size_t)(2 * nseg + 1), scan = omc::mlp_shard_scratch_bytes(rows_global),
+                 sel = sizeof(int64_t) * (size_t)(n_rows_local + 1), so = sizeof(int64_t) * (size_t)(steps + 1);
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    if ((rc = c->shard.ensure(up(tab) + up(scan) + 2 * up(sel) + up(so)))) return rc;
+    char* b = (char*)c->shard.p;
+    int64_t* d_g = (int64_t*)b;
+    int64_t* d_l = d_g + nseg + 1;
+    void* d_scan = b + up(tab);
+    int64_t* sel_row = (int64_t*)(b + up(tab) + up(scan));
+    int64_t* sel_i = (int64_t*)((char*)sel_row + up(sel));
+    int64_t* d_so = (int64_t*)((char*)sel_i + up(sel));
+    HIP_TRY(hipMemcpyAsync(d_g, gstart, sizeof(int64_t) * (size_t)(nseg + 1), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_l, lstart, sizeof(int64_t) * (size_t)nseg, hipMemcpyHostToDevice, c->stream));
+    // own segments must tile [0, n_rows_local) of the rank's matrix: checked here, on the host, before any kernel
+    // indexes `data` with them
+    {
+        std::vector<std::pair<int64_t, int64_t>> own;
+        for (int s = 0; s < nseg; ++s) {
+            if (gstart[s + 1] < gstart[s]) return fail(-4, "segment table is not ascending.");
+            if (lstart[s] >= 0 && gstart[s + 1] > gstart[s]) own.push_back({lstart[s], gstart[s + 1] - gstart[s]});
+        }
+        std::sort(own.begin(), own.end());
+        int64_t at = 0;
+        for (auto& o : own) {
+            if (o.first != at) return fail(-4, "this rank's segments do not tile its rows.");
+            at += o.second;
+        }
+        if (at != n_rows_local) return fail(-4, "this rank's segments do not add up to its row count.");
+    }
+    const int64_t* total_dev = nullptr;
+    HIP_TRY(omc::mlp_shard_select(c->stream, rows_global, shuffle_key, d_g, d_l, nseg, d_scan, sel_row, sel_i, &total_dev));
+    HIP_TRY(omc::mlp_shard_gather(c->stream, data, sel_row, sel_i, n_rows_local, batch, steps, data_epoch, drop_pos, d_so));
+    int64_t total = -1;
+    HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(step_off, d_so, sizeof(int64_t) * (size_t)(steps + 1), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (total != n_rows_local) return fail(-4, "the epoch's permutation selected another number of rows than the rank owns.");
+    return 0;
+}
+
+static int allreduce_cb(void* user, double* dptr, int count) { return allreduce((omc_ctx*)user, dptr, count); }
+
+int omc_mlp_train_epoch_sharded(omc_ctx* c, const float* data_epoch, int64_t n_rows_local, int64_t rows_global,
+                                int64_t batch, int hidden, int layers, float* params, float* adam_m, float* adam_v,
+                                int64_t* step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                double dropout, uint64_t seed, const int64_t* step_off, const uint32_t* drop_pos,
+                                double* mean_loss)
+{
+    int rc = bind_in(c);
+    if (rc) return rc;
+    if (!params || !adam_m || !adam_v || !step || !mean_loss || !step_off || (n_rows_local > 0 && (!data_epoch || !drop_pos)))
+        return fail(-7, "null pointer.");
+    if (n_rows_local < 0 || rows_global <= 0 || batch <= 0 || *step < 0) return fail(-3, "row counts, batch must be positive.");
+    if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
+    if (!(lr > 0.0)) return fail(-4, "learning rate must be positive.");
+    const int64_t steps = (rows_global + batch - 1) / batch;
+    if (step_off[0] != 0 || step_off[steps] != n_rows_local) return fail(-4, "step offsets do not cover the rank's rows.");
+    for (int64_t k = 0; k < steps; ++k)
+        if (step_off[k + 1] < step_off[k] || step_off[k + 1] - step_off[k] > batch) return fail(-4, "step offsets are not ascending.");
+    omc::MlpTrainPlan t;
+    t.data = data_epoch; t.params = params; t.adam_m = adam_m; t.adam_v = adam_v;
+    t.nrows = n_rows_local; t.batch = batch; t.first_step = *step; t.hidden = hidden; t.layers = layers;
+    t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.weight_decay = weight_decay;
+    t.dropout = dropout; t.seed = seed; t.shuffle_key = 0;
+    t.step_off = step_off; t.rows_global = rows_global; t.drop_pos = drop_pos;
+    t.allreduce = allreduce_cb; t.allreduce_user = c;  // no communicator / hook: the sum of one rank
+    const int64_t kb = omc::mlp_plan_kernel_batch(t);
+    if (omc::mlp_train_kernel_choice(hidden, layers, kb) == 0)
+        return fail(-9, "the fused trainer supports hidden = 64 or 128 with 2 or 3 hidden layers (and 32 x 2).");
+    const int np = omc::mlp_train_param_count(hidden, layers);
+    if ((rc = c->mlp_part.ensure(omc::mlp_partial_bytes(hidden, layers, kb)))) return rc;
+    if ((rc = c->mlp_wt.ensure(omc::mlp_wt_bytes(hidden, layers)))) return rc;
+    if ((rc = c->mlp_loss.ensure(sizeof(double)))) return rc;
+    if ((rc = c->mlp_gred.ensure((sizeof(double) + sizeof(float)) * (size_t)(np + 1)))) return rc;
+    HIP_TRY(hipMemsetAsync(c->mlp_loss.p, 0, sizeof(double), c->stream));
+    t.partial = (float*)c->mlp_part.p; t.loss_acc = (double*)c->mlp_loss.p; t.wt = (float*)c->mlp_wt.p;
+    t.gred = (double*)c->mlp_gred.p;
+    HIP_TRY(omc::mlp_train_steps(c->stream, t));
+    double acc = 0.0;
+    HIP_TRY(hipMemcpyAsync(&acc, c->mlp_loss.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *step += steps;
+    *mean_loss = acc / (double)steps;
     return 0;
 }
 

@@ -150,6 +150,17 @@ struct MlpTrainPlan {
     uint64_t seed;         // dropout bits
     uint64_t shuffle_key;  // 0: rows in storage order; else a keyed pseudo-random permutation
     bool wt_current = false;  // `wt` already mirrors `params` (the Adam kernel of an earlier call kept it so)
+    // Sharded training (one rank of a job, omc_mlp_train_epoch_sharded): `data` holds THIS rank's rows of the epoch,
+    // already in epoch order; step k trains on rows [step_off[k], step_off[k + 1]) of it -- this rank's part of the
+    // global minibatch k, which has min(batch, rows_global - k * batch) rows over all ranks -- scales by the GLOBAL
+    // minibatch size, and the gradient sums (+ loss) of all ranks are added through `allreduce` before Adam, so every
+    // rank applies the same update.  nrows = this rank's rows; batch = the GLOBAL minibatch size.
+    const int64_t* step_off = nullptr;   // HOST, [steps + 1]; null: not sharded
+    int64_t rows_global = 0;
+    const uint32_t* drop_pos = nullptr;  // device [nrows]: position of row i inside its global minibatch (dropout key)
+    double* gred = nullptr;              // device [param count + 1]: the step's reduced gradient + loss sum
+    int (*allreduce)(void* user, double* dptr, int count) = nullptr;  // in-place sum over the ranks, stream-ordered
+    void* allreduce_user = nullptr;
 };
 // many small networks of one shape trained side by side: ONE launch pair per optimizer step for all of them (the
 // curve entry points train one net per curve point).  Table rows are built on the host (mlp_batch_table_image) and
@@ -204,8 +215,30 @@ hipError_t nn_feature_stats(hipStream_t st, const double* x, const int32_t* t, c
                             double T, double dt, double* scratch, double* out16);
 // the permutation the trainer walks (for tests): out[i] = stored row visited at epoch position i
 hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out);
+// exclusive prefix of cnt[0..n) into offs[0..n), total into offs[n] (one workgroup; omc_rows.hip)
+hipError_t nn_scan_counts(hipStream_t st, const int32_t* cnt, int64_t n, int64_t* offs);
+// per time step, the in-the-money paths among columns [0, half) and [half, M) of a path matrix: counts_dev
+// [(N - 1)][2] int64, index N - 1 - t (the reference's row order: later steps first)
+hipError_t nn_rows_half_counts(hipStream_t st, const LsmProblem& p, int64_t half, int64_t* counts_dev);
+// ---- NN regressor sharded over ranks: which rows of an epoch's global minibatches are THIS rank's
+// The job's rows in the reference's order (step desc, global column asc) form `nseg` segments, each owned by one
+// rank: gstart[s] = global index of its first row (ascending; gstart[nseg] = rows_global), lstart[s] = the row of the
+// rank's OWN matrix where it starts, or -1 when another rank owns it (device arrays).  Epoch position i trains global
+// row perm(i) (the keyed permutation of the single-GPU trainer over rows_global); this rank's positions, ascending,
+// -> sel_row (own row) / sel_i (position).  scratch: mlp_shard_scratch_bytes(rows_global).  *total_dev -> device
+// int64 = how many (must equal the rank's row count).
+size_t mlp_shard_scratch_bytes(int64_t rows_global);
+hipError_t mlp_shard_select(hipStream_t st, int64_t rows_global, uint64_t shuffle_key, const int64_t* gstart,
+                            const int64_t* lstart, int nseg, void* scratch, int64_t* sel_row, int64_t* sel_i,
+                            const int64_t** total_dev);
+// data_epoch[j] = data[sel_row[j]] (32-byte rows), drop_pos[j] = sel_i[j] mod batch; step_off[k] = first j with
+// sel_i[j] >= k * batch for k = 0 .. steps (device int64 [steps + 1])
+hipError_t mlp_shard_gather(hipStream_t st, const float* data, const int64_t* sel_row, const int64_t* sel_i,
+                            int64_t n_local, int64_t batch, int64_t steps, float* data_epoch, uint32_t* drop_pos,
+                            int64_t* step_off);
 // one epoch: ceil(nrows / batch) optimizer steps (forward+backward kernel, reduce+Adam kernel)
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t);
+int64_t mlp_plan_kernel_batch(const MlpTrainPlan& t);  // the minibatch size that picks the kernel / sizes the partials
 
 // ---- omc_contnet.hip: the per-step ContNet(1 -> h -> h -> 1) regressor of the reference's v1 / v2 pricers
 int cn_padded_width(int hidden);          // width of the trainer that hosts h units (32 / 64 / 128), -1: too wide

@@ -19,6 +19,7 @@
 // No atomics: a training run is bitwise reproducible.
 #include "omc_device.h"
 #include "omc_kernels.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -149,6 +150,9 @@ struct MlpTrainArgs {
     int ntiles;
     float two_over_b, inv_keep;
     uint32_t keep16, step, k0, k1;
+    // sharded training (omc_mlp_train_epoch_sharded): dropout key of local row i of this step = its position in the
+    // GLOBAL minibatch (so every rank draws the masks of the unsharded run); null: the row's own position
+    const uint32_t* drop_pos = nullptr;
 };
 
 // sizes for L hidden layers of 64 units (flat layout: mlp_params_of(64, L))
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
 
     for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += nwaves) {
         const int64_t row = (int64_t)tile * 32 + c;
+        const uint32_t drow = (a.drop_pos && a.keep16 < 65536u && row < a.nrows) ? a.drop_pos[row] : (uint32_t)row;
         const bool live = row < a.nrows;
         float4 x = xnext;
         float y = x.w;                 // upper half-wave: column 7 is the target ...
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
         // next tile's rows: issued once this tile's are consumed (a wait on the older load would
         // otherwise drain this one too), in flight for the rest of the tile
         xnext = fetch(tile + nwaves);
-        relu_dropout<false>(act[0], (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
+        relu_dropout<false>(act[0], drow, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
                     act[j][1] = mfma(W[(32 + c) * kLdW2 + k], act[j - 1][kt][s], act[j][1]);
                 }
             }
-            relu_dropout<false>(act[j], (uint32_t)row, a.step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, a.keep16,
+            relu_dropout<false>(act[j], drow, a.step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, a.keep16,
                                 a.inv_keep, a.k0, a.k1);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -546,6 +551,30 @@ __device__ __forceinline__ void mlp_adam_body_flat(const MlpAdamArgs& a, const i
 
 __global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a) { mlp_adam_body(a); }
 
+// Sharded training.  (1) this rank's gradient sums of the step, partials added in mlp_adam_body's order, as doubles
+// (the loss sum rides in slot nparams) -> (2) the host enqueues the all-reduce over the ranks -> (3) Adam from the
+// reduced sums: mlp_adam_body with ONE partial, the float of the global sum.
+__global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int stride,
+                                                              int nparams, double* __restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p > nparams) return;
+    float g = 0.0f;
+#pragma unroll 1
+    for (int s0 = 0; s0 < 16; ++s0) {
+        float gs = 0.0f;
+        for (int w = s0; w < nparts; w += 16) gs += partial[(size_t)w * stride + p];
+        g += gs;
+    }
+    out[p] = (double)g;
+}
+
+__global__ __launch_bounds__(256) void mlp_grad_to_float_kernel(const double* __restrict__ in, int n, float* __restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n) out[p] = (float)in[p];
+}
+
 // ------------------------------------------------------------------ feature statistics
 // Means and population variances of the six non-constant regression features
 // [x, x^2, x^3, max(x-1,0), s, x*s] (create_regression_features, options_model_3.py:105-121;
@@ -679,6 +708,7 @@ struct MlpTileArgs {
     int tile0, accumulate;  // this launch: tiles tile0 .. tile0 + gridDim.x; add onto the partials?
     float two_over_b, inv_keep;
     uint32_t keep16, step, k0, k1;
+    const uint32_t* drop_pos = nullptr;  // see MlpTrainArgs
 };
 
 template <int NT>
@@ -750,6 +780,7 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
     if (tile >= a.ntiles) return;
     const bool first = !a.accumulate;
     const int64_t row = (int64_t)tile * 32 + c;
+    const uint32_t drow = (a.drop_pos && a.keep16 < 65536u && row < a.nrows) ? a.drop_pos[row] : (uint32_t)row;
     const bool live = row < a.nrows;
     float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) x = reinterpret_cast<const float4*>(a.data + shuffle_index(a.shuf, (uint64_t)(a.row0 + row)) * 8)[h];
@@ -773,7 +804,7 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
         act[0][mt] = mfma(w.z, x.z, act[0][mt]);
         act[0][mt] = mfma(w.w, x.w, act[0][mt]);
     }
-    relu_dropout_t<NT, true>(act[0], (uint32_t)row, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
+    relu_dropout_t<NT, true>(act[0], drow, a.step, 0x100u + (uint32_t)h, a.keep16, a.inv_keep, a.k0, a.k1);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
@@ -813,7 +844,7 @@ __global__ __launch_bounds__(64) void mlp_train_tile_kernel(MlpTileArgs a)
                 }
             }
         }
-        relu_dropout_t<NT, true>(act[j], (uint32_t)row, a.step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, a.keep16,
+        relu_dropout_t<NT, true>(act[j], drow, a.step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, a.keep16,
                                  a.inv_keep, a.k0, a.k1);
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt)
@@ -1005,6 +1036,7 @@ struct MlpQuadArgs {
     int ntiles, pstride;
     float two_over_b, inv_keep;
     uint32_t keep16, step, k0, k1;
+    const uint32_t* drop_pos = nullptr;  // see MlpTrainArgs
 };
 
 // ReLU + inverted dropout on ONE 32-unit tile's pre-activations (16 per lane), in place; same bit budget as
@@ -1044,6 +1076,7 @@ __device__ __forceinline__ void mlp_train_quad_body(const MlpQuadArgs& a, const 
     float* out = a.partial + (size_t)tile * a.pstride;
     const float* Wo = a.params + H * 8 + (L - 1) * CONN;
     const int64_t row = (int64_t)tile * 32 + c;
+    const uint32_t drow = (a.drop_pos && a.keep16 < 65536u && row < a.nrows) ? a.drop_pos[row] : (uint32_t)row;
     const bool live = row < a.nrows;
     float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) x = reinterpret_cast<const float4*>(a.data + shuffle_index(a.shuf, (uint64_t)(a.row0 + row)) * 8)[h];
@@ -1068,7 +1101,7 @@ __device__ __forceinline__ void mlp_train_quad_body(const MlpQuadArgs& a, const 
         acc = mfma(wv.y, x.y, acc);
         acc = mfma(wv.z, x.z, acc);
         acc = mfma(wv.w, x.w, acc);
-        relu_dropout_1(acc, (uint32_t)row, a.step, 0x100u + 0x10u * (uint32_t)w + (uint32_t)h, a.keep16, a.inv_keep, a.k0,
+        relu_dropout_1(acc, drow, a.step, 0x100u + 0x10u * (uint32_t)w + (uint32_t)h, a.keep16, a.inv_keep, a.k0,
                        a.k1);
         hreg[0] = acc;
 #pragma unroll
@@ -1106,7 +1139,7 @@ __device__ __forceinline__ void mlp_train_quad_body(const MlpQuadArgs& a, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bj[32 * w + rho(r)];
         acc = product(a.wt + (size_t)(j - 1) * H * H, sAct[j - 1], acc);
-        relu_dropout_1(acc, (uint32_t)row, a.step, 0x100u * (uint32_t)(j + 1) + 0x10u * (uint32_t)w + (uint32_t)h, a.keep16,
+        relu_dropout_1(acc, drow, a.step, 0x100u * (uint32_t)(j + 1) + 0x10u * (uint32_t)w + (uint32_t)h, a.keep16,
                        a.inv_keep, a.k0, a.k1);
         hreg[j] = acc;
 #pragma unroll
@@ -1733,6 +1766,96 @@ __global__ __launch_bounds__(256) void mlp_shuffle_kernel(Shuffle s, int64_t* ou
     if (i < s.n) out[i] = (int64_t)shuffle_index(s, i);
 }
 
+// ---- sharded epochs: this rank's positions of the epoch's keyed permutation over ALL ranks' rows
+struct ShardSel {
+    Shuffle sh;             // permutation of [0, rows_global)
+    const int64_t* gstart;  // [nseg + 1]
+    const int64_t* lstart;  // [nseg], -1 = not this rank's
+    int nseg;
+};
+constexpr int kSelPerThread = 16, kSelPerBlock = 256 * kSelPerThread;
+
+// own row of global row g, or -1
+__device__ __forceinline__ int64_t shard_locate(const ShardSel& s, int64_t g)
+{
+    int lo = 0, hi = s.nseg;  // gstart[lo] <= g < gstart[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s.gstart[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    const int64_t l = s.lstart[lo];
+    return l < 0 ? -1 : l + (g - s.gstart[lo]);
+}
+
+// WRITE = false: cnt[block] = own positions among the block's kSelPerBlock; WRITE = true: the positions themselves,
+// ascending, at offs[block] + rank inside the block
+template <bool WRITE>
+__global__ __launch_bounds__(256) void shard_select_kernel(ShardSel s, int32_t* __restrict__ cnt,
+                                                           const int64_t* __restrict__ offs, int64_t* __restrict__ sel_row,
+                                                           int64_t* __restrict__ sel_i)
+{
+    __shared__ int scan[256];
+    const int tid = threadIdx.x;
+    const uint64_t i0 = (uint64_t)blockIdx.x * kSelPerBlock + (uint64_t)tid * kSelPerThread;
+    int64_t own[kSelPerThread];
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < kSelPerThread; ++j) {
+        const uint64_t i = i0 + j;
+        own[j] = i < s.sh.n ? shard_locate(s, (int64_t)shuffle_index(s.sh, i)) : -1;
+        n += own[j] >= 0;
+    }
+    scan[tid] = n;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // inclusive scan of the threads' counts
+        const int v = tid >= d ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    if (!WRITE) {
+        if (tid == 255) cnt[blockIdx.x] = scan[255];
+        return;
+    }
+    int64_t o = offs[blockIdx.x] + (scan[tid] - n);
+#pragma unroll
+    for (int j = 0; j < kSelPerThread; ++j) {
+        if (own[j] < 0) continue;
+        sel_row[o] = own[j];
+        sel_i[o] = (int64_t)(i0 + j);
+        ++o;
+    }
+}
+
+__global__ __launch_bounds__(256) void shard_gather_kernel(const float4* __restrict__ data, const int64_t* __restrict__ sel_row,
+                                                           const int64_t* __restrict__ sel_i, int64_t n, int64_t batch,
+                                                           float4* __restrict__ out, uint32_t* __restrict__ drop_pos)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per half row (16 bytes)
+    const int64_t j = t >> 1;
+    if (j >= n) return;
+    const int h = (int)(t & 1);
+    out[j * 2 + h] = data[sel_row[j] * 2 + h];
+    if (h == 0) drop_pos[j] = (uint32_t)(sel_i[j] % batch);
+}
+
+// step_off[k] = first j with sel_i[j] >= k * batch (sel_i ascending), k = 0 .. steps
+__global__ __launch_bounds__(256) void shard_step_off_kernel(const int64_t* __restrict__ sel_i, int64_t n, int64_t batch,
+                                                             int64_t steps, int64_t* __restrict__ step_off)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k > steps) return;
+    const int64_t key = k * batch;
+    int64_t lo = 0, hi = n;  // first index with sel_i >= key
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sel_i[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    step_off[k] = lo;
+}
+
 }  // namespace
 
 // Which kernel trains (hidden, layers) at this minibatch size: 1 = workgroup kernel (64 units,
@@ -1780,6 +1903,85 @@ hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, 
     return hipGetLastError();
 }
 
+size_t mlp_shard_scratch_bytes(int64_t rows_global)
+{
+    const size_t nb = (size_t)((rows_global + kSelPerBlock - 1) / kSelPerBlock);
+    return sizeof(int64_t) * (nb + 2) + sizeof(int32_t) * (nb + 2);
+}
+
+hipError_t mlp_shard_select(hipStream_t st, int64_t rows_global, uint64_t shuffle_key, const int64_t* gstart,
+                            const int64_t* lstart, int nseg, void* scratch, int64_t* sel_row, int64_t* sel_i,
+                            const int64_t** total_dev)
+{
+    const int64_t nb = (rows_global + kSelPerBlock - 1) / kSelPerBlock;
+    int64_t* offs = (int64_t*)scratch;
+    int32_t* cnt = (int32_t*)(offs + nb + 2);
+    *total_dev = offs + nb;
+    if (nb == 0 || nseg <= 0) return hipMemsetAsync(offs, 0, sizeof(int64_t) * (size_t)(nb + 1), st);
+    ShardSel s;
+    s.sh = make_shuffle(rows_global, shuffle_key);
+    s.gstart = gstart; s.lstart = lstart; s.nseg = nseg;
+    hipLaunchKernelGGL(shard_select_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, s, cnt, (const int64_t*)nullptr,
+                       (int64_t*)nullptr, (int64_t*)nullptr);
+    hipError_t e = nn_scan_counts(st, cnt, nb, offs);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(shard_select_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, s, cnt, (const int64_t*)offs, sel_row, sel_i);
+    return hipGetLastError();
+}
+
+hipError_t mlp_shard_gather(hipStream_t st, const float* data, const int64_t* sel_row, const int64_t* sel_i,
+                            int64_t n_local, int64_t batch, int64_t steps, float* data_epoch, uint32_t* drop_pos,
+                            int64_t* step_off)
+{
+    if (n_local > 0)
+        hipLaunchKernelGGL(shard_gather_kernel, dim3((unsigned)((2 * n_local + 255) / 256)), dim3(256), 0, st,
+                           (const float4*)data, sel_row, sel_i, n_local, batch, (float4*)data_epoch, drop_pos);
+    hipLaunchKernelGGL(shard_step_off_kernel, dim3((unsigned)((steps + 1 + 255) / 256)), dim3(256), 0, st, sel_i, n_local, batch,
+                       steps, step_off);
+    return hipGetLastError();
+}
+
+// The optimizer steps of one epoch: step k trains on `local` rows starting at `row0` of t.data and is one minibatch of
+// `global` rows (single GPU: the same thing; sharded: this rank's part of the job's minibatch).
+struct StepSpan { int64_t row0, local, global; };
+static inline int64_t plan_steps(const MlpTrainPlan& t)
+{
+    const int64_t rows = t.step_off ? t.rows_global : t.nrows;
+    return (rows + t.batch - 1) / t.batch;
+}
+static inline StepSpan plan_span(const MlpTrainPlan& t, int64_t k)
+{
+    const int64_t rows = t.step_off ? t.rows_global : t.nrows;
+    const int64_t o = k * t.batch, g = rows - o < t.batch ? rows - o : t.batch;
+    if (!t.step_off) return {o, g, g};
+    return {t.step_off[k], t.step_off[k + 1] - t.step_off[k], g};
+}
+static inline Shuffle plan_shuffle(const MlpTrainPlan& t)
+{
+    return t.step_off ? make_shuffle(t.nrows, 0) : make_shuffle(t.nrows, t.shuffle_key);  // sharded: rows are in epoch order
+}
+// After the forward / backward launch(es) of a step: Adam on this rank's partials, or -- sharded -- on the sum of all
+// ranks' partials.  `b` is complete except for the partial source.  -> 0 or the all-reduce's error.
+static int finish_step(hipStream_t st, const MlpTrainPlan& t, MlpAdamArgs b, int adam_blocks)
+{
+    if (!t.step_off) {
+        hipLaunchKernelGGL(mlp_adam_kernel, dim3(adam_blocks), dim3(256), 0, st, b);
+        return 0;
+    }
+    const int n = b.nparams + 1;
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b.partial, b.nparts, b.stride,
+                       b.nparams, t.gred);
+    const int rc = t.allreduce(t.allreduce_user, t.gred, n);
+    if (rc) return rc;
+    float* gf = reinterpret_cast<float*>(t.gred + n);  // [n] floats behind the doubles
+    hipLaunchKernelGGL(mlp_grad_to_float_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t.gred, n, gf);
+    b.partial = gf;
+    b.nparts = 1;
+    b.stride = n;
+    hipLaunchKernelGGL(mlp_adam_kernel, dim3(adam_blocks), dim3(256), 0, st, b);
+    return 0;
+}
+
 template <int L>
 static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
 {
@@ -1789,10 +1991,12 @@ static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
         hipError_t e = set_max_dynamic_lds(attr_mask, reinterpret_cast<const void*>(mlp_train_kernel<L>), lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
+    const Shuffle sh = plan_shuffle(t);
     int64_t step = t.first_step;
-    for (int64_t o = 0; o < t.nrows; o += t.batch) {
-        const int64_t nb = (t.nrows - o < t.batch) ? t.nrows - o : t.batch;
+    const int64_t nsteps = plan_steps(t);
+    for (int64_t k = 0; k < nsteps; ++k) {
+        const StepSpan sp = plan_span(t, k);
+        const int64_t o = sp.row0, nb = sp.local;
         ++step;
         MlpTrainArgs a;
         a.data = t.data;
@@ -1802,7 +2006,8 @@ static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
         a.nrows = nb;
         a.shuf = sh;
         a.ntiles = (int)((nb + 31) / 32);
-        a.two_over_b = (float)(2.0 / (double)nb);
+        a.two_over_b = (float)(2.0 / (double)sp.global);
+        a.drop_pos = t.drop_pos ? t.drop_pos + o : nullptr;
         a.keep16 = t.dropout > 0.0 ? (uint32_t)llround((1.0 - t.dropout) * 65536.0) : 65536u;
         a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
         a.step = (uint32_t)step;
@@ -1810,7 +2015,7 @@ static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
         a.k1 = (uint32_t)(t.seed >> 32);
         int groups = (a.ntiles + 3) / 4;
         if (groups > kMlpMaxGroups) groups = kMlpMaxGroups;
-        hipLaunchKernelGGL(mlp_train_kernel<L>, dim3(groups), dim3(256), lds_bytes, st, a);
+        if (groups > 0) hipLaunchKernelGGL(mlp_train_kernel<L>, dim3(groups), dim3(256), lds_bytes, st, a);  // (a rank may own no row of a step)
         MlpAdamArgs b;
         b.params = t.params;
         b.m = t.adam_m;
@@ -1821,7 +2026,7 @@ static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
         b.nparams = train_params(L);
         b.stride = g_stride(L);
         b.wt = nullptr; b.H = kH; b.L = L;
-        b.inv_b = (float)(1.0 / (double)nb);
+        b.inv_b = (float)(1.0 / (double)sp.global);
         const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
         b.lr_t = (float)(t.lr / bc1);
         b.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
@@ -1829,7 +2034,7 @@ static hipError_t train_steps(hipStream_t st, const MlpTrainPlan& t)
         b.beta2 = (float)t.beta2;
         b.eps = (float)t.eps;
         b.wd = (float)t.weight_decay;
-        hipLaunchKernelGGL(mlp_adam_kernel, dim3((train_params(L) + 16) / 16), dim3(256), 0, st, b);
+        if (finish_step(st, t, b, (train_params(L) + 16) / 16)) return hipErrorUnknown;
     }
     return hipGetLastError();
 }
@@ -1844,10 +2049,12 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
         if (e != hipSuccess) return e;
     }
     if (!t.wt_current) hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
-    const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
+    const Shuffle sh = plan_shuffle(t);
     int64_t step = t.first_step;
-    for (int64_t o = 0; o < t.nrows; o += t.batch) {
-        const int64_t nb = (t.nrows - o < t.batch) ? t.nrows - o : t.batch;
+    const int64_t nsteps = plan_steps(t);
+    for (int64_t k = 0; k < nsteps; ++k) {
+        const StepSpan sp = plan_span(t, k);
+        const int64_t o = sp.row0, nb = sp.local;
         ++step;
         MlpTileArgs a;
         a.data = t.data;
@@ -1859,7 +2066,8 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
         a.shuf = sh;
         a.ntiles = (int)((nb + 31) / 32);
         a.pstride = tile_pstride(H, L);
-        a.two_over_b = (float)(2.0 / (double)nb);
+        a.two_over_b = (float)(2.0 / (double)sp.global);
+        a.drop_pos = t.drop_pos ? t.drop_pos + o : nullptr;
         a.keep16 = t.dropout > 0.0 ? (uint32_t)llround((1.0 - t.dropout) * 65536.0) : 65536u;
         a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
         a.step = (uint32_t)step;
@@ -1881,7 +2089,7 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
         b.nparams = mlp_params_of(H, L);
         b.stride = a.pstride;
         b.wt = t.wt; b.H = H; b.L = L;
-        b.inv_b = (float)(1.0 / (double)nb);
+        b.inv_b = (float)(1.0 / (double)sp.global);
         const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
         b.lr_t = (float)(t.lr / bc1);
         b.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
@@ -1889,7 +2097,7 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
         b.beta2 = (float)t.beta2;
         b.eps = (float)t.eps;
         b.wd = (float)t.weight_decay;
-        hipLaunchKernelGGL(mlp_adam_kernel, dim3((mlp_params_of(H, L) + 16) / 16), dim3(256), 0, st, b);
+        if (finish_step(st, t, b, (mlp_params_of(H, L) + 16) / 16)) return hipErrorUnknown;
     }
     return hipGetLastError();
 }
@@ -1899,10 +2107,12 @@ template <int H, int L>
 static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
 {
     if (!t.wt_current) hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
-    const Shuffle sh = make_shuffle(t.nrows, t.shuffle_key);
+    const Shuffle sh = plan_shuffle(t);
     int64_t step = t.first_step;
-    for (int64_t o = 0; o < t.nrows; o += t.batch) {
-        const int64_t nb = (t.nrows - o < t.batch) ? t.nrows - o : t.batch;
+    const int64_t nsteps = plan_steps(t);
+    for (int64_t k = 0; k < nsteps; ++k) {
+        const StepSpan sp = plan_span(t, k);
+        const int64_t o = sp.row0, nb = sp.local;
         ++step;
         MlpQuadArgs a;
         a.data = t.data;
@@ -1914,13 +2124,14 @@ static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
         a.shuf = sh;
         a.ntiles = (int)((nb + 31) / 32);
         a.pstride = tile_pstride(H, L);
-        a.two_over_b = (float)(2.0 / (double)nb);
+        a.two_over_b = (float)(2.0 / (double)sp.global);
+        a.drop_pos = t.drop_pos ? t.drop_pos + o : nullptr;
         a.keep16 = t.dropout > 0.0 ? (uint32_t)llround((1.0 - t.dropout) * 65536.0) : 65536u;
         a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
         a.step = (uint32_t)step;
         a.k0 = (uint32_t)t.seed;
         a.k1 = (uint32_t)(t.seed >> 32);
-        hipLaunchKernelGGL((mlp_train_quad_kernel<H, L>), dim3(a.ntiles), dim3(H * 2), 0, st, a);
+        if (a.ntiles > 0) hipLaunchKernelGGL((mlp_train_quad_kernel<H, L>), dim3(a.ntiles), dim3(H * 2), 0, st, a);
         MlpAdamArgs b;
         b.params = t.params;
         b.m = t.adam_m;
@@ -1931,7 +2142,7 @@ static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
         b.nparams = mlp_params_of(H, L);
         b.stride = a.pstride;
         b.wt = t.wt; b.H = H; b.L = L;
-        b.inv_b = (float)(1.0 / (double)nb);
+        b.inv_b = (float)(1.0 / (double)sp.global);
         const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
         b.lr_t = (float)(t.lr / bc1);
         b.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
@@ -1939,14 +2150,22 @@ static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
         b.beta2 = (float)t.beta2;
         b.eps = (float)t.eps;
         b.wd = (float)t.weight_decay;
-        hipLaunchKernelGGL(mlp_adam_kernel, dim3((mlp_params_of(H, L) + 16) / 16), dim3(256), 0, st, b);
+        if (finish_step(st, t, b, (mlp_params_of(H, L) + 16) / 16)) return hipErrorUnknown;
     }
     return hipGetLastError();
 }
 
+int64_t mlp_plan_kernel_batch(const MlpTrainPlan& t)
+{
+    if (!t.step_off) return t.batch;
+    int64_t mx = 1;  // sharded: the kernel (and its partial buffer) must cover this rank's largest step
+    for (int64_t k = 0, n = plan_steps(t); k < n; ++k) mx = std::max(mx, t.step_off[k + 1] - t.step_off[k]);
+    return mx;
+}
+
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
 {
-    const int choice = mlp_train_kernel_choice(t.hidden, t.layers, t.batch);
+    const int choice = mlp_train_kernel_choice(t.hidden, t.layers, mlp_plan_kernel_batch(t));
     if (choice == 1) return t.layers == 2 ? train_steps<2>(st, t) : train_steps<3>(st, t);
     if (choice == 2) {
         if (t.hidden == 64) return t.layers == 2 ? tile_steps<64, 2>(st, t) : tile_steps<64, 3>(st, t);

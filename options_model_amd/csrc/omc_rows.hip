@@ -68,6 +68,35 @@ __global__ __launch_bounds__(1024) void rows_scan_kernel(const int32_t* __restri
     if (tid == 1023) offs[n] = seg[1023];
 }
 
+// half[(N-1-t) * 2 + h] = in-the-money paths at step t among columns [0, half) (h = 0) / [half, M) (h = 1);
+// one workgroup per time step
+__global__ __launch_bounds__(kBlock) void rows_half_count_kernel(RowsArgs a, int64_t half, int64_t* __restrict__ out)
+{
+    __shared__ long long acc[2][kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = 1 + (int)blockIdx.x;
+    if (t >= a.N) return;
+    const float* rowp = a.S + (int64_t)t * a.ld;
+    long long c0 = 0, c1 = 0;
+    for (int64_t p0 = 0; p0 < a.M; p0 += kBlock) {
+        const int64_t p = p0 + tid;
+        const bool f = p < a.M && itm(rowp[p], a.K, a.is_put);
+        const uint64_t b0 = __builtin_amdgcn_ballot_w64(f && p < half), b1 = __builtin_amdgcn_ballot_w64(f && p >= half);
+        c0 += __builtin_popcountll(b0);
+        c1 += __builtin_popcountll(b1);
+    }
+    if (lane == 0) {
+        acc[0][wave] = c0;
+        acc[1][wave] = c1;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        long long s = 0;
+        for (int w = 0; w < kBlock / 64; ++w) s += acc[tid][w];
+        out[(size_t)(a.N - 1 - t) * 2 + tid] = s;
+    }
+}
+
 // features of one in-the-money (t, path): [x, x^2, x^3, max(x-1,0), s, x*s] and the target y
 __device__ __forceinline__ void row_values(double sd, double payN, double K, double st, double disc, double (&f)[8])
 {
@@ -225,6 +254,20 @@ hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, v
                            a, cnt);
     hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int64_t)n, offs);
     *total_dev = offs + n;
+    return hipGetLastError();
+}
+
+hipError_t nn_scan_counts(hipStream_t st, const int32_t* cnt, int64_t n, int64_t* offs)
+{
+    hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, n, offs);
+    return hipGetLastError();
+}
+
+hipError_t nn_rows_half_counts(hipStream_t st, const LsmProblem& p, int64_t half, int64_t* counts_dev)
+{
+    if (p.N < 2) return hipSuccess;
+    const RowsArgs a = make_args(p, nullptr);
+    hipLaunchKernelGGL(rows_half_count_kernel, dim3(p.N - 1), dim3(kBlock), 0, st, a, half, counts_dev);
     return hipGetLastError();
 }
 
