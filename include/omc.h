@@ -292,6 +292,15 @@ int omc_lsm_apply_mlp(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
                       double r, double T, int is_put, int hidden, int layers, const float* params,
                       const double* feat_mean, const double* feat_std, double y_mean, double y_std,
                       double dropout, uint64_t seed, omc_result* res, float* sx_out, int32_t* tex_out);
+/* the same on one rank's shard of a job: the dropout key of column j is its column in the UNSHARDED matrix,
+ * j + col_base0 for the first half of this matrix's columns (first partners) and j - n_paths / 2 + col_base1 for the
+ * second -- (pair_offset, P_global + pair_offset) -- so a shard draws the masks the single GPU draws.  The sums in
+ * `res` are the shard's; the caller adds them over the ranks. */
+int omc_lsm_apply_mlp_shard(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                      double r, double T, int is_put, int hidden, int layers, const float* params,
+                      const double* feat_mean, const double* feat_std, double y_mean, double y_std,
+                      double dropout, uint64_t seed, omc_result* res, float* sx_out, int32_t* tex_out,
+                            int64_t col_base0, int64_t col_base1);
 /* Pass 1 of the NN flow (options_model_3.py:482-563) straight from a device path matrix: every
  * in-the-money (step, path), steps N-1 down to 1 and paths ascending within a step (the reference's
  * order), becomes one row of `data` ([rows][8] float32, device): the 7 features [1, x, x^2, x^3,
@@ -299,7 +308,8 @@ int omc_lsm_apply_mlp(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
  * population stds over all rows (zero std -> 1), and the target (terminal payoff discounted to t)
  * normalised likewise.  *n_rows = number of rows; with data == NULL only the count is made (call
  * once to size the buffer, then again with data and cap_rows >= *n_rows).  stats16 (host) =
- * feat_mean[7], feat_std[7], y_mean, y_std. */
+ * feat_mean[7], feat_std[7], y_mean, y_std -- on a context with a communicator / hook those of ALL ranks' rows (see the
+ * sharded NN regressor below); every rank of the job must then make the call, also one without any row. */
 int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
                       double r, double T, int is_put, float* data, int64_t cap_rows, int64_t* n_rows,
                       double* stats16);
@@ -318,6 +328,40 @@ int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t
                         double lr, double beta1, double beta2, double eps, double weight_decay,
                         double dropout, uint64_t seed, uint64_t shuffle_key, double* mean_loss);
 int omc_mlp_shuffle_indices(omc_ctx* ctx, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device);
+
+/* ---- the NN regressor sharded over the ranks of a job (options_model_3.py:542-613) ---------
+ * The reference trains ONE network on the rows of ALL paths.  With the paths sharded by antithetic pair, every rank
+ * builds the rows of its own paths and the job trains the network the single GPU would train:
+ *   1. omc_nn_build_rows on a context with a communicator / hook: the normalisers are those of ALL ranks' rows (row
+ *      count, sums and squared deviations from the global means all-reduced: 3 x 8 doubles); *n_rows stays the rank's
+ *      own count and `data` its own rows.
+ *   2. The job's rows in the reference's order (step N-1 .. 1, global column ascending) are the concatenation of
+ *      segments (step, half, rank) -- a rank's matrix holds its pairs' first partners in columns [0, P_local) and the
+ *      second partners behind them, the global matrix all ranks' first partners, then all second partners.
+ *      omc_nn_half_counts returns a rank's segment sizes ([n_steps - 1][2] int64 on the host, index n_steps - 1 - t);
+ *      the ranks exchange them (omc_comm_allreduce_f64 of a zero-padded table) and build gstart[nseg + 1] (global index
+ *      of each segment's first row, ascending, gstart[nseg] = rows_global) and lstart[nseg] (where the segment starts
+ *      among the rank's own rows, -1 for another rank's) -- options_model_amd/nn_dist.py: segment_tables.
+ *   3. Per epoch, omc_mlp_shard_epoch evaluates the single-GPU trainer's keyed permutation over rows_global, keeps the
+ *      positions whose row this rank owns (ascending), gathers those rows into data_epoch ([n_rows_local][8] float32,
+ *      device), their positions inside their minibatch into drop_pos (device uint32: the dropout key, so every rank
+ *      draws the masks of the unsharded run) and returns step_off (HOST int64 [steps + 1], steps = ceil(rows_global /
+ *      batch)): minibatch k holds this rank's rows [step_off[k], step_off[k + 1]) of data_epoch.
+ *   4. omc_mlp_train_epoch_sharded runs the epoch: forward / backward over the rank's part of each minibatch, scaled
+ *      by the GLOBAL minibatch size; the gradient sums and the loss sum (parameter count + 1 doubles) are all-reduced
+ *      on the context's stream; every rank applies the same Adam step, so the parameters stay identical on all ranks
+ *      and equal those of the single-GPU run up to float32 summation order.  *mean_loss is the job's.
+ * Pass 2 (omc_lsm_apply_mlp) is local; its sums are added over the ranks by the caller. */
+int omc_nn_half_counts(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, int is_put,
+                       int64_t* counts /* host [(n_steps - 1)][2] */);
+int omc_mlp_shard_epoch(omc_ctx* ctx, const float* data, int64_t n_rows_local, int64_t rows_global, int64_t batch,
+                        uint64_t shuffle_key, const int64_t* gstart, const int64_t* lstart, int nseg, float* data_epoch,
+                        uint32_t* drop_pos, int64_t* step_off);
+int omc_mlp_train_epoch_sharded(omc_ctx* ctx, const float* data_epoch, int64_t n_rows_local, int64_t rows_global,
+                                int64_t batch, int hidden, int layers, float* params, float* adam_m, float* adam_v,
+                                int64_t* step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                double dropout, uint64_t seed, const int64_t* step_off, const uint32_t* drop_pos,
+                                double* mean_loss);
 
 /* ---- local-vol paths through the implied-vol network ------------------------ */
 /* replaces simulate_local_vol_paths_antithetic (options_model_3.py:300-333) together with the

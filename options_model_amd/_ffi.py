@@ -108,8 +108,14 @@ SIGNATURES = {
     "omc_mlp_train_batch_supported": (C.c_int, [_I, _I, _I64]),
     "omc_mlp_train_epoch_batch": (C.c_int, [_P, C.POINTER(MlpJob), _I, _I, _I] + [_D] * 5),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
+    "omc_nn_half_counts": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _I, _P]),
+    "omc_mlp_shard_epoch": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _P, _P, _I, _P, _P, _P]),
+    "omc_mlp_train_epoch_sharded": (C.c_int, [_P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, C.POINTER(C.c_int64)]
+                                    + [_D] * 6 + [_U64, _P, _P, C.POINTER(C.c_double)]),
     "omc_lsm_apply_mlp": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _I, _P, _P, _P, _D, _D, _D, _U64,
                                     C.POINTER(Result), _P, _P]),
+    "omc_lsm_apply_mlp_shard": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _I, _P, _P, _P, _D, _D, _D, _U64,
+                                          C.POINTER(Result), _P, _P, _I64, _I64]),
     "omc_localvol_param_count": (C.c_int, [_I, _I]),
     "omc_localvol_paths_f32": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _D, _I, _I, _P, _D, _D, _D, _P]),
     "omc_nn_build_rows": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _P, _I64, C.POINTER(C.c_int64), _P]),
@@ -513,6 +519,43 @@ class Context:
             float(weight_decay), float(dropout), int(seed), int(shuffle_key), C.byref(loss)))
         return loss.value, st.value
 
+    # -- the NN regressor sharded over ranks (include/omc.h; host logic in nn_dist.py)
+    def nn_half_counts(self, S_ptr, ld, n_paths, n_steps, K, is_put):
+        """-> int64 [(n_steps - 1), 2]: in-the-money paths per step (index n_steps - 1 - t) in the first / second half
+        of the rank's columns."""
+        out = np.zeros((max(int(n_steps) - 1, 0), 2), np.int64)
+        _check(self.lib, self.lib.omc_nn_half_counts(self.handle, int(S_ptr), int(ld), int(n_paths), int(n_steps), float(K),
+                                                     int(bool(is_put)), out.ctypes.data))
+        return out
+
+    def mlp_shard_epoch(self, data_ptr, n_rows_local, rows_global, batch, shuffle_key, gstart, lstart, data_epoch_ptr,
+                        drop_pos_ptr):
+        """This rank's rows of the epoch, gathered in epoch order -> step_off (int64 [steps + 1], host)."""
+        g = np.ascontiguousarray(gstart, np.int64)
+        l_ = np.ascontiguousarray(lstart, np.int64)
+        assert g.size == l_.size + 1
+        steps = (int(rows_global) + int(batch) - 1) // int(batch)
+        so = np.zeros(steps + 1, np.int64)
+        _check(self.lib, self.lib.omc_mlp_shard_epoch(
+            self.handle, int(data_ptr) if n_rows_local else None, int(n_rows_local), int(rows_global), int(batch),
+            int(shuffle_key), g.ctypes.data, l_.ctypes.data, int(l_.size), int(data_epoch_ptr) if n_rows_local else None,
+            int(drop_pos_ptr) if n_rows_local else None, so.ctypes.data))
+        return so
+
+    def mlp_train_epoch_sharded(self, data_epoch_ptr, n_rows_local, rows_global, batch, params_ptr, m_ptr, v_ptr, step, lr,
+                                dropout, seed, step_off, drop_pos_ptr, hidden=64, layers=2, beta1=0.9, beta2=0.999,
+                                eps=1e-8, weight_decay=1e-5):
+        """One epoch of the job's training on this rank's rows -> (the job's mean loss, new step)."""
+        st = C.c_int64(int(step))
+        loss = C.c_double(0.0)
+        so = np.ascontiguousarray(step_off, np.int64)
+        _check(self.lib, self.lib.omc_mlp_train_epoch_sharded(
+            self.handle, int(data_epoch_ptr) if n_rows_local else None, int(n_rows_local), int(rows_global), int(batch),
+            int(hidden), int(layers), int(params_ptr), int(m_ptr), int(v_ptr), C.byref(st), float(lr), float(beta1),
+            float(beta2), float(eps), float(weight_decay), float(dropout), int(seed), so.ctypes.data,
+            int(drop_pos_ptr) if n_rows_local else None, C.byref(loss)))
+        return loss.value, st.value
+
     def mlp_train_epoch_batch(self, jobs, hidden, layers, dropout, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5):
         """One epoch for every network of `jobs` (list of dicts: data_ptr, n_rows, batch, params_ptr, m_ptr, v_ptr,
         step, lr, seed, shuffle_key), all of shape hidden x layers, side by side -> [(mean_loss, new_step), ...]."""
@@ -528,19 +571,21 @@ class Context:
         return [(a.mean_loss, a.step) for a in arr]
 
     def lsm_apply_mlp(self, S_ptr, ld, n_paths, n_steps, K, r, T, is_put, params_ptr, feat_mean, feat_std,
-                      y_mean, y_std, dropout, seed, want_state=False, hidden=64, layers=2):
-        """Pass 2 of the NN flow on a device path matrix -> result dict (+ sx, tex if want_state)."""
+                      y_mean, y_std, dropout, seed, want_state=False, hidden=64, layers=2, col_bases=None):
+        """Pass 2 of the NN flow on a device path matrix -> result dict (+ sx, tex if want_state).
+        col_bases = (base0, base1): the matrix is one rank's shard (omc_lsm_apply_mlp_shard)."""
         fm = np.ascontiguousarray(feat_mean, np.float64)
         fs = np.ascontiguousarray(feat_std, np.float64)
         assert fm.size == 7 and fs.size == 7
         res = Result()
         sx = np.empty(n_paths, np.float32) if want_state else None
         tex = np.empty(n_paths, np.int32) if want_state else None
-        _check(self.lib, self.lib.omc_lsm_apply_mlp(
+        b0, b1 = (0, int(n_paths) // 2) if col_bases is None else (int(col_bases[0]), int(col_bases[1]))
+        _check(self.lib, self.lib.omc_lsm_apply_mlp_shard(
             self.handle, int(S_ptr), int(ld), int(n_paths), int(n_steps), float(K), float(r), float(T),
             int(bool(is_put)), int(hidden), int(layers), int(params_ptr), fm.ctypes.data, fs.ctypes.data,
             float(y_mean), float(y_std), float(dropout), int(seed), C.byref(res),
-            sx.ctypes.data if want_state else None, tex.ctypes.data if want_state else None))
+            sx.ctypes.data if want_state else None, tex.ctypes.data if want_state else None, b0, b1))
         out = res.as_dict()
         if want_state:
             out["sx"], out["tex"] = sx, tex

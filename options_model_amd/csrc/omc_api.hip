@@ -1944,6 +1944,16 @@ int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
                       const double* feat_mean, const double* feat_std, double y_mean, double y_std,
                       double dropout, uint64_t seed, omc_result* res, float* sx_out, int32_t* tex_out)
 {
+    return omc_lsm_apply_mlp_shard(c, S, ld, n_paths, n_steps, K, r, T, is_put, hidden, layers, params, feat_mean, feat_std,
+                                   y_mean, y_std, dropout, seed, res, sx_out, tex_out, 0, n_paths / 2);
+}
+
+int omc_lsm_apply_mlp_shard(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
+                            double r, double T, int is_put, int hidden, int layers, const float* params,
+                            const double* feat_mean, const double* feat_std, double y_mean, double y_std,
+                            double dropout, uint64_t seed, omc_result* res, float* sx_out, int32_t* tex_out,
+                            int64_t col_base0, int64_t col_base1)
+{
     int rc;
     if ((rc = bind_in(c))) return rc;
     if ((rc = check_market(1.0, K, T, r))) return rc;
@@ -1959,7 +1969,7 @@ int omc_lsm_apply_mlp(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
     if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w))) return rc;
     omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
     HIP_TRY(omc::mlp_apply_pass2(c->stream, p, hidden, layers, params, feat_mean, feat_std, y_mean, y_std,
-                                 dropout, seed, w.sx, w.tex));
+                                 dropout, seed, w.sx, w.tex, col_base0, col_base1));
     HIP_TRY(omc::lsm_final_reduce(c->stream, p, w, 1));
     HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
     if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;

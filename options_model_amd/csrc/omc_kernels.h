@@ -196,7 +196,7 @@ int mlp_train_kernel_choice(int hidden, int layers, int64_t batch);  // 0: this 
 int mlp_apply_param_count(int hidden, int layers);
 hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, int hidden, int layers, const float* params,
                            const double* feat_mean, const double* feat_std, double y_mean, double y_std,
-                           double dropout, uint64_t seed, float* sx, int32_t* tex);
+                           double dropout, uint64_t seed, float* sx, int32_t* tex, int64_t col_base0, int64_t col_base1);
 // local-vol paths through the implied-vol network (hidden 64, `layers` residual blocks), row f-4
 int localvol_param_count(int hidden, int layers);
 hipError_t localvol_paths(hipStream_t st, float* S, int64_t ld, int64_t M, int N, int layers, const float* params,

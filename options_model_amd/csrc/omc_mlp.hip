@@ -655,6 +655,9 @@ struct MlpApplyArgs {
     float inv_keep;
     uint32_t keep16, k0, k1;
     int ntiles;
+    // dropout key of column p: its column in the UNSHARDED matrix (p + base0 for the first half of this matrix's
+    // columns, p - half + base1 for the second), so that a shard draws the masks the single GPU draws
+    int64_t key_half, key_base0, key_base1;
 };
 
 // Flat parameter layout for any (H hidden units, L hidden layers): W1|b1 as [H][8], then for
@@ -1518,6 +1521,7 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
     const int64_t p = (int64_t)tile * 32 + c;
     const bool live = p < a.M;
     const float* col = a.S + (live ? p : a.M - 1);
+    const uint32_t pk = (uint32_t)(p < a.key_half ? p + a.key_base0 : p - a.key_half + a.key_base1);  // dropout key
     const double K = a.K;
     const uint32_t rtag = (uint32_t)h + 2u * (uint32_t)(p >> 32);
     float sx = col[(int64_t)a.N * a.ld];
@@ -1556,7 +1560,7 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
             act[mt] = mfma(wr[2], xin.z, act[mt]);
             act[mt] = mfma(wr[3], xin.w, act[mt]);
         }
-        relu_dropout_n<NT>(act, (uint32_t)p, (uint32_t)t, 0x300u + rtag, a.keep16, a.inv_keep, a.k0, a.k1);
+        relu_dropout_n<NT>(act, pk, (uint32_t)t, 0x300u + rtag, a.keep16, a.inv_keep, a.k0, a.k1);
 #pragma unroll
         for (int l = 0; l < L - 1; ++l) {
             const float* W = sWh + l * (H * LDW + H);
@@ -1575,7 +1579,7 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
                     for (int mt = 0; mt < NT; ++mt) nxt[mt] = mfma(W[(32 * mt + c) * LDW + k], act[kt][s], nxt[mt]);
                 }
             }
-            relu_dropout_n<NT>(nxt, (uint32_t)p, (uint32_t)t, 0x400u + 0x100u * (uint32_t)l + rtag, a.keep16,
+            relu_dropout_n<NT>(nxt, pk, (uint32_t)t, 0x400u + 0x100u * (uint32_t)l + rtag, a.keep16,
                                a.inv_keep, a.k0, a.k1);
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) act[mt] = nxt[mt];
@@ -2291,9 +2295,10 @@ static hipError_t launch_apply(hipStream_t st, const MlpApplyArgs& a)
 
 hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, int hidden, int layers, const float* params,
                            const double* feat_mean, const double* feat_std, double y_mean, double y_std,
-                           double dropout, uint64_t seed, float* sx, int32_t* tex)
+                           double dropout, uint64_t seed, float* sx, int32_t* tex, int64_t col_base0, int64_t col_base1)
 {
     MlpApplyArgs a;
+    a.key_half = p.M / 2; a.key_base0 = col_base0; a.key_base1 = col_base1;
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
     a.K = p.K; a.T = p.T; a.dt = p.T / (double)p.N;
     a.params = params;

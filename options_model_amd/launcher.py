@@ -207,7 +207,10 @@ class RankPool:
         return answers
 
     def call(self, fn: str, kwargs: dict, timeout_s: float = 600.0):
-        """-> rank 0's result (a dict).  An error raised on the ranks is re-raised here: ValueError as ValueError
+        return self.call_all(fn, kwargs, timeout_s)[0]
+
+    def call_all(self, fn: str, kwargs: dict, timeout_s: float = 600.0):
+        """-> every rank's result (dicts, rank order); call() returns rank 0's.  An error raised on the ranks is re-raised here: ValueError as ValueError
         (every rank validates the same arguments), anything else as RankError -- after which the pool is closed,
         because ranks that failed at different points are no longer in step."""
         with self._lock:
@@ -224,7 +227,7 @@ class RankPool:
                     raise ValueError(bad[0][1].get("error", "invalid argument"))  # nothing collective was entered
                 self.close(kill=True)
                 raise RankError("; ".join(f"rank {r}: {a.get('type')}: {a.get('error')}" for r, a in bad))
-            return answers[0]["result"]
+            return [a["result"] for a in answers]
 
     def close(self, kill: bool = False):
         if getattr(self, "_closed", True):

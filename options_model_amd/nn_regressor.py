@@ -81,8 +81,9 @@ def features(x, s_t):
     return torch.stack([torch.ones_like(x), x, x * x, x * x * x, torch.clamp(x - 1, min=0), s, x * s], dim=1)
 
 
-def generate_paths(ctx, S, model_kw, S0, r, sigma, T, seed, stream=0):
-    """Fill the torch tensor S [N+1, M] (float32, contiguous) with the HIP path kernels."""
+def generate_paths(ctx, S, model_kw, S0, r, sigma, T, seed, stream=0, pair_offset=0):
+    """Fill the torch tensor S [N+1, M] (float32, contiguous) with the HIP path kernels.  pair_offset: global index of
+    the matrix's first antithetic pair (a rank's shard of a larger pricing)."""
     torch = _torch()
     N, M = S.shape[0] - 1, S.shape[1]
     assert S.is_contiguous() and S.dtype == torch.float32
@@ -93,10 +94,10 @@ def generate_paths(ctx, S, model_kw, S0, r, sigma, T, seed, stream=0):
         hp = {k: model_kw[k] for k in ("v0", "kappa", "theta", "xi", "rho")}
         _ffi._check(ctx.lib, ctx.lib.omc_heston_paths_f32(ctx.handle, S.data_ptr(), M, M, N, S0, r, T,
                                                            hp["v0"], hp["kappa"], hp["theta"], hp["xi"],
-                                                           hp["rho"], seed, stream, 0, 0))
+                                                           hp["rho"], seed, stream, int(pair_offset), 0))
     else:
         _ffi._check(ctx.lib, ctx.lib.omc_gbm_paths_f32(ctx.handle, S.data_ptr(), M, M, N, S0, r, sigma,
-                                                        T, seed, stream, 0, 1))
+                                                        T, seed, stream, int(pair_offset), 1))
 
 
 def collect_rows(S, K, r, T, is_put, step_chunk=32):
