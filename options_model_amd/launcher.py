@@ -199,6 +199,10 @@ class RankPool:
                         msg = json.loads(ln)
                         if msg.get("id") == req["id"]:
                             answers[r] = msg
+                            if not msg.get("ok") and msg.get("type") != "ValueError":
+                                # this rank has left the collective call: its peers may be waiting for it inside a
+                                # collective that has no deadline -- do not wait for their answers
+                                raise RankError(f"rank {r}: {msg.get('type')}: {msg.get('error')}")
                 for r, p in enumerate(self.procs):
                     if answers[r] is None and p.poll() is not None:
                         raise RankError(f"rank {r} exited (code {p.returncode}) during {req['fn']}")

@@ -22,6 +22,11 @@ for line in sys.stdin:
     elif fn == "bad":
         print(json.dumps(dict(id=rid, ok=False, type="ValueError", error="S0, K, T must be positive.")), flush=True)
         continue
+    elif fn == "fail_then_hang":
+        if rank == kw.get("rank"):
+            print(json.dumps(dict(id=rid, ok=False, type="RuntimeError", error="kernel launch failed")), flush=True)
+        time.sleep(300)  # the failing rank hangs in its teardown, the others inside a collective
+        continue
     elif fn == "die" and rank == kw.get("rank"):
         sys.exit(5)
     elif fn == "sleep" and rank == kw.get("rank"):

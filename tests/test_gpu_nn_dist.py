@@ -54,14 +54,17 @@ def test_sharded_nn_regressor_equals_the_single_gpu_run(single, plain_process, w
         assert r0["sum_nitm"] == one.sum_nitm and r0["n_paths"] == one.n_paths       # the same rows
         assert r0["info"]["batch"] == one.info["batch"] and r0["info"]["optimizer_steps"] == one.info["optimizer_steps"]
         # the same minibatches and masks; per-rank float32 partial sums added in another association (in float64):
-        assert r0["info"]["best_loss"] == pytest.approx(one.info["best_loss"], rel=2e-3)
-        assert r0["price"] == pytest.approx(one.price, rel=3e-3)  # boundary paths follow the last bits of the weights
+        # (measured on MI355X: loss 3e-6 / 4e-5 relative without / with dropout; price 2e-4 .. 2.6e-3 relative)
+        assert r0["info"]["best_loss"] == pytest.approx(one.info["best_loss"], rel=2e-4)
+        # the weights agree to float32 rounding amplified by ~2,200 Adam steps; paths whose payoff sits that close to
+        # the network's output exercise at another step.  Bound: 1.5 standard errors of the single-GPU price itself.
+        assert abs(r0["price"] - one.price) <= 1.5 * one.stderr, (r0["price"], one.price, one.stderr)
 
 
 def test_facade_nn_n_gpus_from_a_plain_process(single, plain_process):
     from options_model_amd import price_american_option
     res = price_american_option(*ARGS, regressor="nn", seed=11, n_gpus=2, device=0, nn_options=dict(NN, nn_dropout=0.0))
     assert res.info["launched_ranks"] == 2 and res.info["trainer"] == "hip" and res.info["transport"] == "rccl-native"
-    assert res.price == pytest.approx(single["nodrop"].price, rel=3e-3) and res.sum_nitm == single["nodrop"].sum_nitm
+    assert abs(res.price - single["nodrop"].price) <= 1.5 * single["nodrop"].stderr and res.sum_nitm == single["nodrop"].sum_nitm
     with pytest.raises(ValueError, match="multiple of"):
         price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 120_002, 40, regressor="nn", n_gpus=2, device=0)

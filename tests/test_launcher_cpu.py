@@ -47,6 +47,16 @@ def test_a_dead_rank_fails_the_call_names_the_rank_and_closes_the_pool():
         p.call("x", {})
 
 
+def test_an_error_on_one_rank_does_not_wait_for_its_peers():
+    """A rank that answers with an error has left the collective call; its peers may sit in a collective without a
+    deadline.  The call fails at once with that rank's error and the pool is taken down."""
+    p = _pool(3)
+    t0 = time.monotonic()
+    with pytest.raises(launcher.RankError, match="rank 2: RuntimeError: kernel launch failed"):
+        p.call("fail_then_hang", dict(rank=2), timeout_s=120)
+    assert time.monotonic() - t0 < 30 and all(q.poll() is not None for q in p.procs)
+
+
 def test_deadline_ends_a_stuck_rank():
     p = _pool(2)
     t0 = time.monotonic()
