@@ -39,6 +39,44 @@ bench)
   timeout -k 10 400 python bench.py --config c4 --steps 20 --warmup 5 --no-variants > gpurun_out/bench_${TAG}_c4.json 2> gpurun_out/bench_${TAG}_c4.err; rc=$?
   echo "bench c4 exit=$rc"
   ;;
+c5)
+  # config 5 (NN 2 x 64): the drop-in call timed, then the same under rocprofv3 kernel stats
+  timeout -k 10 300 python tools/time_c5.py > gpurun_out/${TAG}_c5.json 2> gpurun_out/${TAG}_c5.err; rc=$?
+  echo "c5 exit=$rc"; cat gpurun_out/${TAG}_c5.json | cut -c1-600; ok $rc || exit 1
+  cd /tmp && export TMPDIR=/tmp
+  OUT="$R/gpurun_out/prof_${TAG}_c5"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 "$R/tools/time_c5.py" \
+      > "$R/gpurun_out/${TAG}_c5_under_rocprof.json" 2> "$OUT.err"; rc=$?
+  echo "rocprof c5 exit=$rc"; ok $rc || exit 1
+  f=$(find "$OUT" -name "*kernel_stats.csv" | head -1); cp "$f" "$R/gpurun_out/${TAG}_c5_kernel_stats.csv"; head -12 "$f" | cut -c1-170
+  rm -rf "$OUT"
+  cd "$R"
+  # dropout's share of a tile: the trainer with and without it, batch 2^17 and 2^19
+  timeout -k 10 300 python tools/bench_mlp.py 16777216 131072,524288 2 0.0,0.1 > gpurun_out/${TAG}_mlp_dropout.jsonl 2> gpurun_out/${TAG}_mlp_dropout.err; rc=$?
+  echo "mlp dropout on/off exit=$rc"; cat gpurun_out/${TAG}_mlp_dropout.jsonl
+  ;;
+heston_sq)
+  # SQ counters of the Heston generator at config 4
+  cd /tmp && export TMPDIR=/tmp
+  OUT="$R/gpurun_out/pmc_sq_${TAG}_c4"
+  timeout -k 10 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT" -- \
+    python3 "$R/bench.py" --config c4 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed > /dev/null 2> "$OUT.err"; rc=$?
+  echo "heston sq exit=$rc"; ok $rc || exit 1
+  python3 - "$OUT" <<'PY' | tee "$R/gpurun_out/pmc_sq_summary_${TAG}_c4.txt"
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+for k, d in acc.items():
+    if "omc::" not in k: continue
+    print(k)
+    for c, (s, n) in sorted(d.items()):
+        print(f"   {c:24s} {s / n:16.0f}   ({n} dispatches)")
+PY
+  rm -rf "$OUT"
+  ;;
 pmc)
   cd /tmp && export TMPDIR=/tmp
   for SEM in two_pass reference; do
