@@ -469,14 +469,13 @@ struct MlpAdamArgs {
 // 16 parameters per workgroup, 16 threads per parameter: thread (slice, j) sums partials
 // slice, slice + 16, ... of parameter j (independent loads, all in flight together), the 16 slice
 // sums are added in slice order through LDS, thread (0, j) applies Adam.
-// PW parameters per workgroup of 16 * PW threads (16: the small launches; 64: a wave reads 256 contiguous bytes of a
-// partial -- the large-batch trainer's 256 partials of 19 KB).  The additions and their order do not depend on PW.
-template <int PW = 16>
+// (Measured in round 4: 64 parameters per workgroup -- 256-byte reads of a partial -- takes the same 5.0 us at 256
+// partials; the kernel is bound by the latency of its 16 loads per thread, not by their coalescing.)
 __device__ __forceinline__ void mlp_adam_body(const MlpAdamArgs& a)
 {
-    __shared__ float red[16][PW + 1];
-    const int j = threadIdx.x % PW, slice = threadIdx.x / PW;
-    const int p = blockIdx.x * PW + j;
+    __shared__ float red[16][17];
+    const int j = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int p = blockIdx.x * 16 + j;
     float g = 0.0f;
     if (p <= a.nparams) {
 #pragma unroll 16
@@ -552,8 +551,7 @@ __device__ __forceinline__ void mlp_adam_body_flat(const MlpAdamArgs& a, const i
     }
 }
 
-__global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a) { mlp_adam_body<16>(a); }
-__global__ __launch_bounds__(1024) void mlp_adam_wide_kernel(MlpAdamArgs a) { mlp_adam_body<64>(a); }
+__global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a) { mlp_adam_body(a); }
 
 // Sharded training.  (1) this rank's gradient sums of the step, partials added in mlp_adam_body's order, as doubles
 // (the loss sum rides in slot nparams) -> (2) the host enqueues the all-reduce over the ranks -> (3) Adam from the
@@ -1972,11 +1970,7 @@ static inline Shuffle plan_shuffle(const MlpTrainPlan& t)
 // ranks' partials.  `b` is complete except for the partial source.  -> 0 or the all-reduce's error.
 static inline void launch_adam(hipStream_t st, const MlpAdamArgs& b, int adam_blocks)
 {
-    static const int wide_env = getenv("OMC_MLP_ADAM_WIDE") ? atoi(getenv("OMC_MLP_ADAM_WIDE")) : 1;
-    if (wide_env && b.nparts >= 64)  // many partials: 64 parameters per workgroup, 256-byte reads (same sums, same order)
-        hipLaunchKernelGGL(mlp_adam_wide_kernel, dim3((b.nparams + 64) / 64), dim3(1024), 0, st, b);
-    else
-        hipLaunchKernelGGL(mlp_adam_kernel, dim3(adam_blocks), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(mlp_adam_kernel, dim3(adam_blocks), dim3(256), 0, st, b);
 }
 
 static int finish_step(hipStream_t st, const MlpTrainPlan& t, MlpAdamArgs b, int adam_blocks)
