@@ -232,7 +232,7 @@ __device__ __forceinline__ void cn_forward_body(const CnFwdArgs& fa)
     constexpr int NP = H * 8 + H * H + H + H + 1;
     extern __shared__ float sp[];
     const CnArgs& a = fa.c;
-    for (int i = threadIdx.x; i < NP; i += kCnBlock) sp[i] = fa.params[i];
+    stage_block(fa.params, NP, (int)threadIdx.x, [&](int i, float v) { sp[i] = v; });  // kCnBlock == 256
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * kCnBlock + threadIdx.x;
     if (j >= a.M) return;

@@ -63,6 +63,32 @@ __device__ __forceinline__ void normals4(uint64_t pair, uint32_t block, uint32_t
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// ------------------------------------------------------------------ staging a parameter block into LDS
+// put(i, src[i]) for i in [0, n), 256-thread workgroups.  A plain `for (i = tid; i < n; i += 256) dst[f(i)] = src[i]`
+// compiles to load -> s_waitcnt vmcnt(0) -> ds_write per (pair of) iteration(s): one global round trip after the
+// other -- 8 of them for a 64 x 64 connection, ~10 us at the head of every launch of the trainer (round 4, seen in
+// the ISA).  Here a thread's loads of a chunk (up to 16) are all issued before the first store, so a chunk costs one
+// round trip.  n is a compile-time constant at every call site: the bounds checks fold away.
+template <class Put>
+__device__ __forceinline__ void stage_block(const float* __restrict__ src, const int n, const int tid, Put&& put)
+{
+    __builtin_assume(tid >= 0 && tid < 256);
+    for (int base = 0; base < n; base += 256 * 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = base + tid + 256 * k;
+            v[k] = i < n ? src[i] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = base + tid + 256 * k;
+            if (i < n) put(i, v[k]);
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------ block reduction
 // Sums acc[0..7] over the 256 threads of the block in a fixed order (bitwise
 // reproducible run to run).  `red` is LDS, kNQ*kRedStride doubles.  On return lanes of

@@ -198,16 +198,40 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
     // mask only: with H' = mask * relu(Z), Ws = W / keep: Z_j = Ws H'_{j-1} + b, dZ_{j-1} =
     // [H'_{j-1} > 0] Ws^T dZ_j, and the gradients taken against H' (connections, output weights)
     // are multiplied by 1 / keep once, on the way out.
-    for (int i = tid; i < kH * 8; i += 256) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[i];
+    // Every load of the staging is issued before the first LDS store (one global round trip for the whole parameter
+    // block instead of one per pair of loop iterations: the launch's fixed cost, 11.9 -> see DESIGN.md section 6).
+    {
+        constexpr int kTail = kH * 8 + (L - 1) * (kH * kH + kH);  // output weights [kH], then the output bias
+        float w1v[2], wcv[L - 1][16], bcv[L - 1];
 #pragma unroll
-    for (int j = 0; j < L - 1; ++j) {
-        const float* src = a.params + kH * 8 + j * (kH * kH + kH);
-        float* dst = sWc + j * kConn;
-        for (int i = tid; i < kH * kH; i += 256) dst[(i >> 6) * kLdW2 + (i & 63)] = src[i] * a.inv_keep;
-        if (tid < kH) dst[kH * kLdW2 + tid] = src[kH * kH + tid];
+        for (int k = 0; k < 2; ++k) w1v[k] = a.params[tid + 256 * k];  // kH * 8 = 512
+#pragma unroll
+        for (int j = 0; j < L - 1; ++j) {
+            const float* src = a.params + kH * 8 + j * (kH * kH + kH);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wcv[j][k] = src[tid + 256 * k];  // kH * kH = 4096
+            bcv[j] = src[kH * kH + (tid & (kH - 1))];
+        }
+        float wov = a.params[kTail + (tid & (kH - 1))], bov = a.params[kTail + kH];
+        asm volatile("" : "+v"(wov), "+v"(bov));  // keeps these two loads in the batch (hipcc sinks them below the stores)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 256 * k;
+            sW1[(i >> 3) * kLdW1 + (i & 7)] = w1v[k];
+        }
+#pragma unroll
+        for (int j = 0; j < L - 1; ++j) {
+            float* dst = sWc + j * kConn;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = tid + 256 * k;
+                dst[(i >> 6) * kLdW2 + (i & 63)] = wcv[j][k] * a.inv_keep;
+            }
+            if (tid < kH) dst[kH * kLdW2 + tid] = bcv[j];
+        }
+        if (tid < kH) sWo[tid] = wov * a.inv_keep;
+        if (tid == 0) sBo[0] = bov;
     }
-    if (tid < kH) sWo[tid] = a.params[kH * 8 + (L - 1) * (kH * kH + kH) + tid] * a.inv_keep;
-    if (tid == 0) sBo[0] = a.params[kH * 8 + (L - 1) * (kH * kH + kH) + kH];
     __syncthreads();
 
     v16f gW[L - 1][2][2];
@@ -1507,16 +1531,21 @@ __global__ __launch_bounds__(256) void mlp_apply_kernel(MlpApplyArgs a)
     float* sWo = sWh + (L - 1) * (H * LDW + H);
     float* sBo = sWo + H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    for (int i = tid; i < H * 8; i += 256) sW1[(i >> 3) * kLdW1 + (i & 7)] = a.params[i];
+    // (stage_block: a chunk's loads are all in flight before its first LDS store, omc_device.h)
+    stage_block(a.params, H * 8, tid, [&](int i, float v) { sW1[(i >> 3) * kLdW1 + (i & 7)] = v; });
 #pragma unroll
     for (int l = 0; l < L - 1; ++l) {
         const float* src = a.params + H * 8 + l * (H * H + H);
         float* dst = sWh + l * (H * LDW + H);
-        for (int i = tid; i < H * H; i += 256) dst[(i / H) * LDW + (i % H)] = src[i];
-        for (int i = tid; i < H; i += 256) dst[H * LDW + i] = src[H * H + i];
+        stage_block(src, H * H + H, tid, [&](int i, float v) {  // weights [H][H] -> [H][H + 1], then the bias row
+            if (i < H * H) dst[(i / H) * LDW + (i % H)] = v;
+            else dst[H * LDW + (i - H * H)] = v;
+        });
     }
-    for (int i = tid; i < H; i += 256) sWo[i] = a.params[H * 8 + (L - 1) * (H * H + H) + i];
-    if (tid == 0) sBo[0] = a.params[H * 8 + (L - 1) * (H * H + H) + H];
+    stage_block(a.params + H * 8 + (L - 1) * (H * H + H), H + 1, tid, [&](int i, float v) {
+        if (i < H) sWo[i] = v;
+        else sBo[0] = v;
+    });
     __syncthreads();
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= a.ntiles) return;  // whole wave; no barrier below
@@ -1636,14 +1665,16 @@ __global__ __launch_bounds__(256) void localvol_paths_kernel(LocalVolArgs a)
     float* sLay = sWin + kH * 4;      // L x { W [64][65], b, gamma, beta }
     float* sWo = sLay + a.L * kLayer;  // [64] + bias
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    for (int i = tid; i < kH * 4; i += 256) sWin[i] = a.params[i];
+    stage_block(a.params, kH * 4, tid, [&](int i, float v) { sWin[i] = v; });
     for (int l = 0; l < a.L; ++l) {
         const float* src = a.params + kH * 4 + l * (kH * kH + 3 * kH);
         float* dst = sLay + l * kLayer;
-        for (int i = tid; i < kH * kH; i += 256) dst[(i >> 6) * kLdW2 + (i & 63)] = src[i];
-        for (int i = tid; i < 3 * kH; i += 256) dst[kH * kLdW2 + i] = src[kH * kH + i];
+        stage_block(src, kH * kH + 3 * kH, tid, [&](int i, float v) {
+            if (i < kH * kH) dst[(i >> 6) * kLdW2 + (i & 63)] = v;
+            else dst[kH * kLdW2 + (i - kH * kH)] = v;
+        });
     }
-    for (int i = tid; i <= kH; i += 256) sWo[i] = a.params[kH * 4 + a.L * (kH * kH + 3 * kH) + i];
+    stage_block(a.params + kH * 4 + a.L * (kH * kH + 3 * kH), kH + 1, tid, [&](int i, float v) { sWo[i] = v; });
     __syncthreads();
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= a.ntiles) return;  // whole wave; no barrier below
