@@ -91,7 +91,7 @@ def test_facade_n_gpus_never_prices_on_fewer_gpus(monkeypatch):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     t0 = time.monotonic()
-    with pytest.raises(launcher.RankError, match="rank 0"):
+    with pytest.raises(launcher.RankError, match=r"rank \d"):  # whichever rank reports first
         price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 10_000, 50, n_gpus=2)
     assert time.monotonic() - t0 < 120
     launcher.close_pools()
