@@ -68,3 +68,33 @@ def test_facade_nn_n_gpus_from_a_plain_process(single, plain_process):
     assert abs(res.price - single["nodrop"].price) <= 1.5 * single["nodrop"].stderr and res.sum_nitm == single["nodrop"].sum_nitm
     with pytest.raises(ValueError, match="multiple of"):
         price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 120_002, 40, regressor="nn", n_gpus=2, device=0)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_nn_tiny_and_empty_shards(plain_process, world):
+    """Edge cases of the sharded flow: a handful of rows (one ragged minibatch per epoch, ranks owning a few rows or
+    NONE of a step's minibatch -- empty launches are skipped, the rank still takes part in every all-reduce), a rank
+    without any row, and a job without any row (options_model_3.py:518-519: fall back to the discounted terminal
+    payoff).  Each equals the single-GPU call on the same seeds."""
+    from options_model_amd import price_american_option
+    nn = dict(nn_hidden=64, nn_layers=2, nn_epochs=3, nn_dropout=0.0, torch_seed=5)
+    cases = [
+        dict(S0=100.0, K=100.0, T=1.0, n_paths=128, n_steps=6, option_type="put"),      # ~300 rows, one minibatch
+        dict(S0=118.0, K=100.0, T=0.25, n_paths=16 * world, n_steps=4, option_type="put"),  # a few rows; some ranks none
+        dict(S0=50.0, K=100.0, T=0.5, n_paths=64, n_steps=5, option_type="call"),        # nothing ever in the money
+        dict(S0=100.0, K=100.0, T=1.0, n_paths=3000, n_steps=9, option_type="put"),      # several minibatches of 256
+    ]
+    pool = plain_process.pool(world, [0] * world)
+    for c in cases:
+        kw = dict(S0=c["S0"], K=c["K"], r=0.05, sigma=0.2, T=c["T"], n_paths=c["n_paths"], n_steps=c["n_steps"],
+                  model="GBM", option_type=c["option_type"], heston_params=None, seed=3, stream=1)
+        res = pool.call_all("price_american_option_nn", dict(kw, **nn), timeout_s=300)
+        one = price_american_option(c["S0"], c["K"], 0.05, 0.2, c["T"], c["n_paths"], c["n_steps"], model="GBM",
+                                    option_type=c["option_type"], regressor="nn", seed=3, stream=1, nn_options=nn)
+        assert len({r["price"] for r in res}) == 1, c
+        r0 = res[0]
+        assert r0["sum_nitm"] == one.sum_nitm and r0["n_paths"] == one.n_paths, (c, r0["sum_nitm"], one.sum_nitm)
+        assert r0["price"] == pytest.approx(one.price, rel=2e-3, abs=1e-9), (c, r0["price"], one.price)
+        if one.sum_nitm:
+            assert r0["info"]["optimizer_steps"] == one.info["optimizer_steps"]
+            assert r0["info"]["best_loss"] == pytest.approx(one.info["best_loss"], rel=1e-3)
