@@ -248,6 +248,25 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
 #pragma unroll
     for (int i = 0; i < 4; ++i) gW1[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
+    // L == 2 (config 5's net): the one 64 x 64 connection also lives in REGISTERS, in the two operand layouts the
+    // tile loop consumes -- forward A operand W[unit c / 32 + c][k-step's unit] and its transpose for dH -- 128 of
+    // the 148 registers this instantiation leaves free (one wave per SIMD: 512 are there).  That removes 128 of a
+    // tile's ~200 LDS operand reads and the waits in front of the MFMAs that consume them.  (L == 3 has no room.)
+    constexpr bool kRegW = (L == 2);
+    float wfw[kRegW ? 2 : 1][kRegW ? 2 : 1][kRegW ? 16 : 1], wbw[kRegW ? 2 : 1][kRegW ? 2 : 1][kRegW ? 16 : 1];
+    if constexpr (kRegW) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = unit_of(kt, s, h);
+                wfw[0][kt][s] = sWc[(c)*kLdW2 + k];
+                wfw[1][kt][s] = sWc[(32 + c) * kLdW2 + k];
+                wbw[0][kt][s] = sWc[k * kLdW2 + c];
+                wbw[1][kt][s] = sWc[k * kLdW2 + 32 + c];
+            }
+    }
+
     for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += nwaves) {
         const int64_t row = (int64_t)tile * 32 + c;
         const uint32_t drow = (a.drop_pos && a.keep16 < 65536u && row < a.nrows) ? a.drop_pos[row] : (uint32_t)row;
@@ -296,8 +315,13 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const int k = unit_of(kt, s, h);
-                    act[j][0] = mfma(W[(c)*kLdW2 + k], act[j - 1][kt][s], act[j][0]);
-                    act[j][1] = mfma(W[(32 + c) * kLdW2 + k], act[j - 1][kt][s], act[j][1]);
+                    if constexpr (kRegW) {
+                        act[j][0] = mfma(wfw[0][kt][s], act[j - 1][kt][s], act[j][0]);
+                        act[j][1] = mfma(wfw[1][kt][s], act[j - 1][kt][s], act[j][1]);
+                    } else {
+                        act[j][0] = mfma(W[(c)*kLdW2 + k], act[j - 1][kt][s], act[j][0]);
+                        act[j][1] = mfma(W[(32 + c) * kLdW2 + k], act[j - 1][kt][s], act[j][1]);
+                    }
                 }
             }
             relu_dropout<false>(act[j], drow, a.step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, a.keep16,
@@ -380,9 +404,14 @@ __global__ __launch_bounds__(256) void mlp_train_kernel(MlpTrainArgs a)
             for (int it = 0; it < 2; ++it) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const float* wr = W + unit_of(it, s, h) * kLdW2 + c;
-                    d[0] = mfma(wr[0], dz[it][s], d[0]);
-                    d[1] = mfma(wr[32], dz[it][s], d[1]);
+                    if constexpr (kRegW) {
+                        d[0] = mfma(wbw[0][it][s], dz[it][s], d[0]);
+                        d[1] = mfma(wbw[1][it][s], dz[it][s], d[1]);
+                    } else {
+                        const float* wr = W + unit_of(it, s, h) * kLdW2 + c;
+                        d[0] = mfma(wr[0], dz[it][s], d[0]);
+                        d[1] = mfma(wr[32], dz[it][s], d[1]);
+                    }
                 }
             }
 #pragma unroll
