@@ -199,6 +199,8 @@ def _job_pricer(n_gpus: int, device=None):
 
         from .dist import RcclPricer
         rank = int(os.environ["RANK"])
+        if isinstance(device, (list, tuple)):  # one device per rank
+            device = device[rank]
         local = int(os.environ.get("LOCAL_RANK", rank)) if device is None else int(device)
         sp = RcclPricer(local, rank, world)
         _job[key] = sp

@@ -131,7 +131,9 @@ class AdvancedOptionPricer:
         (e.g. the Streamlit UI going through compute_curve_worker_enhanced).
         n_gpus > 1 (or OMC_N_GPUS for the same callers): the American pricing shards its paths over that many
         GPUs, one rank process per GPU -- started from here when this is a plain process (api.py, launcher.py);
-        `devices` lists one HIP device per rank (default: rank r -> device r; OMC_DEVICES="0,1,.." likewise)."""
+        `devices` lists one HIP device per rank (default: rank r -> device r; OMC_DEVICES="0,1,.." likewise).
+        Curves (compute_curve_for_S0) are thousands of SMALL pricings: they run as one batch on one GPU whatever
+        n_gpus says."""
         if regressor is None:
             regressor = os.environ.get("OMC_REGRESSOR", "nn").lower()
         if regressor not in ("poly", "nn"):
