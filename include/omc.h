@@ -355,8 +355,9 @@ int omc_mlp_shuffle_indices(omc_ctx* ctx, int64_t n_rows, uint64_t shuffle_key, 
 int omc_nn_half_counts(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, int is_put,
                        int64_t* counts /* host [(n_steps - 1)][2] */);
 int omc_mlp_shard_epoch(omc_ctx* ctx, const float* data, int64_t n_rows_local, int64_t rows_global, int64_t batch,
-                        uint64_t shuffle_key, const int64_t* gstart, const int64_t* lstart, int nseg, float* data_epoch,
-                        uint32_t* drop_pos, int64_t* step_off);
+                        uint64_t shuffle_key, const int64_t* gstart, const int64_t* lstart, int nseg,
+                        int segs_per_step /* 2 x ranks: lets the kernel search the table in two levels; 0 = unknown */,
+                        float* data_epoch, uint32_t* drop_pos, int64_t* step_off);
 int omc_mlp_train_epoch_sharded(omc_ctx* ctx, const float* data_epoch, int64_t n_rows_local, int64_t rows_global,
                                 int64_t batch, int hidden, int layers, float* params, float* adam_m, float* adam_v,
                                 int64_t* step, double lr, double beta1, double beta2, double eps, double weight_decay,

@@ -109,7 +109,7 @@ SIGNATURES = {
     "omc_mlp_train_epoch_batch": (C.c_int, [_P, C.POINTER(MlpJob), _I, _I, _I] + [_D] * 5),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
     "omc_nn_half_counts": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _I, _P]),
-    "omc_mlp_shard_epoch": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _P, _P, _I, _P, _P, _P]),
+    "omc_mlp_shard_epoch": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _P, _P, _I, _I, _P, _P, _P]),
     "omc_mlp_train_epoch_sharded": (C.c_int, [_P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, C.POINTER(C.c_int64)]
                                     + [_D] * 6 + [_U64, _P, _P, C.POINTER(C.c_double)]),
     "omc_lsm_apply_mlp": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, _I, _I, _P, _P, _P, _D, _D, _D, _U64,
@@ -529,7 +529,7 @@ class Context:
         return out
 
     def mlp_shard_epoch(self, data_ptr, n_rows_local, rows_global, batch, shuffle_key, gstart, lstart, data_epoch_ptr,
-                        drop_pos_ptr):
+                        drop_pos_ptr, segs_per_step=0):
         """This rank's rows of the epoch, gathered in epoch order -> step_off (int64 [steps + 1], host)."""
         g = np.ascontiguousarray(gstart, np.int64)
         l_ = np.ascontiguousarray(lstart, np.int64)
@@ -538,7 +538,8 @@ class Context:
         so = np.zeros(steps + 1, np.int64)
         _check(self.lib, self.lib.omc_mlp_shard_epoch(
             self.handle, int(data_ptr) if n_rows_local else None, int(n_rows_local), int(rows_global), int(batch),
-            int(shuffle_key), g.ctypes.data, l_.ctypes.data, int(l_.size), int(data_epoch_ptr) if n_rows_local else None,
+            int(shuffle_key), g.ctypes.data, l_.ctypes.data, int(l_.size), int(segs_per_step),
+            int(data_epoch_ptr) if n_rows_local else None,
             int(drop_pos_ptr) if n_rows_local else None, so.ctypes.data))
         return so
 

@@ -2133,8 +2133,8 @@ int omc_nn_half_counts(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, 
 }
 
 int omc_mlp_shard_epoch(omc_ctx* c, const float* data, int64_t n_rows_local, int64_t rows_global, int64_t batch,
-                        uint64_t shuffle_key, const int64_t* gstart, const int64_t* lstart, int nseg, float* data_epoch,
-                        uint32_t* drop_pos, int64_t* step_off)
+                        uint64_t shuffle_key, const int64_t* gstart, const int64_t* lstart, int nseg, int segs_per_step,
+                        float* data_epoch, uint32_t* drop_pos, int64_t* step_off)
 {
     int rc;
     if ((rc = bind_in(c))) return rc;
@@ -2175,7 +2175,8 @@ int omc_mlp_shard_epoch(omc_ctx* c, const float* data, int64_t n_rows_local, int
         if (at != n_rows_local) return fail(-4, "this rank's segments do not add up to its row count.");
     }
     const int64_t* total_dev = nullptr;
-    HIP_TRY(omc::mlp_shard_select(c->stream, rows_global, shuffle_key, d_g, d_l, nseg, d_scan, sel_row, sel_i, &total_dev));
+    const int group = (segs_per_step > 0 && nseg % segs_per_step == 0) ? segs_per_step : 0;
+    HIP_TRY(omc::mlp_shard_select(c->stream, rows_global, shuffle_key, d_g, d_l, nseg, group, d_scan, sel_row, sel_i, &total_dev));
     HIP_TRY(omc::mlp_shard_gather(c->stream, data, sel_row, sel_i, n_rows_local, batch, steps, data_epoch, drop_pos, d_so));
     int64_t total = -1;
     HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof total, hipMemcpyDeviceToHost, c->stream));

@@ -229,8 +229,8 @@ hipError_t nn_rows_half_counts(hipStream_t st, const LsmProblem& p, int64_t half
 // int64 = how many (must equal the rank's row count).
 size_t mlp_shard_scratch_bytes(int64_t rows_global);
 hipError_t mlp_shard_select(hipStream_t st, int64_t rows_global, uint64_t shuffle_key, const int64_t* gstart,
-                            const int64_t* lstart, int nseg, void* scratch, int64_t* sel_row, int64_t* sel_i,
-                            const int64_t** total_dev);
+                            const int64_t* lstart, int nseg, int group /* segments per time step, 0 = unknown */,
+                            void* scratch, int64_t* sel_row, int64_t* sel_i, const int64_t** total_dev);
 // data_epoch[j] = data[sel_row[j]] (32-byte rows), drop_pos[j] = sel_i[j] mod batch; step_off[k] = first j with
 // sel_i[j] >= k * batch for k = 0 .. steps (device int64 [steps + 1])
 hipError_t mlp_shard_gather(hipStream_t st, const float* data, const int64_t* sel_row, const int64_t* sel_i,

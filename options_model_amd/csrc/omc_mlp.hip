@@ -1838,13 +1838,27 @@ struct ShardSel {
     const int64_t* gstart;  // [nseg + 1]
     const int64_t* lstart;  // [nseg], -1 = not this rank's
     int nseg;
+    int group;              // segments per time step (2 x ranks): the table is searched in two levels -- the step in LDS
+                            // (nseg / group + 1 starts), the segment inside the step's `group` entries; 0: flat search
 };
 constexpr int kSelPerThread = 16, kSelPerBlock = 256 * kSelPerThread;
+constexpr int kSelMaxSteps = 4096;  // step starts staged in LDS (32 KB); longer tables are searched flat
 
-// own row of global row g, or -1
-__device__ __forceinline__ int64_t shard_locate(const ShardSel& s, int64_t g)
+// own row of global row g, or -1: the LAST segment that starts at or before g (empty segments share a start)
+__device__ __forceinline__ int64_t shard_locate(const ShardSel& s, const int64_t* __restrict__ step_start, int nsteps,
+                                                int64_t g)
 {
     int lo = 0, hi = s.nseg;  // gstart[lo] <= g < gstart[hi]
+    if (step_start) {
+        int a = 0, b = nsteps;  // step_start[a] <= g < step_start[b]
+        while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (step_start[mid] <= g) a = mid;
+            else b = mid;
+        }
+        lo = a * s.group;
+        hi = min(lo + s.group, s.nseg);
+    }
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (s.gstart[mid] <= g) lo = mid;
@@ -1854,24 +1868,46 @@ __device__ __forceinline__ int64_t shard_locate(const ShardSel& s, int64_t g)
     return l < 0 ? -1 : l + (g - s.gstart[lo]);
 }
 
-// WRITE = false: cnt[block] = own positions among the block's kSelPerBlock; WRITE = true: the positions themselves,
-// ascending, at offs[block] + rank inside the block
+// Every rank walks ALL epoch positions (ownership is only known after the permutation is evaluated), so this is the one
+// per-rank cost of a sharded epoch that does not shrink with the number of ranks: 16 positions per thread, the
+// time-step starts of the segment table in LDS.  WRITE = false: which of a thread's 16 positions are this rank's ->
+// mask[thread] (a bit each), cnt[block] = their number.  WRITE = true: only the positions with a bit set are evaluated
+// again (1 / ranks of them) and written, ascending, at offs[block] + rank inside the block.
 template <bool WRITE>
-__global__ __launch_bounds__(256) void shard_select_kernel(ShardSel s, int32_t* __restrict__ cnt,
+__global__ __launch_bounds__(256) void shard_select_kernel(ShardSel s, int32_t* __restrict__ cnt, uint16_t* __restrict__ mask,
                                                            const int64_t* __restrict__ offs, int64_t* __restrict__ sel_row,
                                                            int64_t* __restrict__ sel_i)
 {
     __shared__ int scan[256];
+    __shared__ int64_t sh_step[kSelMaxSteps + 1];
     const int tid = threadIdx.x;
-    const uint64_t i0 = (uint64_t)blockIdx.x * kSelPerBlock + (uint64_t)tid * kSelPerThread;
-    int64_t own[kSelPerThread];
-    int n = 0;
-#pragma unroll
-    for (int j = 0; j < kSelPerThread; ++j) {
-        const uint64_t i = i0 + j;
-        own[j] = i < s.sh.n ? shard_locate(s, (int64_t)shuffle_index(s.sh, i)) : -1;
-        n += own[j] >= 0;
+    const int nsteps = s.group > 0 ? s.nseg / s.group : 0;
+    const int64_t* step_start = nullptr;
+    if (nsteps > 0 && nsteps <= kSelMaxSteps && nsteps * s.group == s.nseg) {
+        for (int i = tid; i <= nsteps; i += 256) sh_step[i] = s.gstart[min(i * s.group, s.nseg)];
+        __syncthreads();
+        step_start = sh_step;
     }
+    const uint64_t i0 = (uint64_t)blockIdx.x * kSelPerBlock + (uint64_t)tid * kSelPerThread;
+    const size_t slot = (size_t)blockIdx.x * 256 + tid;
+    if (!WRITE) {
+        unsigned m = 0;
+#pragma unroll 4
+        for (int j = 0; j < kSelPerThread; ++j) {
+            const uint64_t i = i0 + j;
+            if (i < s.sh.n && shard_locate(s, step_start, nsteps, (int64_t)shuffle_index(s.sh, i)) >= 0) m |= 1u << j;
+        }
+        mask[slot] = (uint16_t)m;
+        int n = __builtin_popcount(m);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n += __shfl_down(n, d, 64);
+        if ((tid & 63) == 0) scan[tid >> 6] = n;
+        __syncthreads();
+        if (tid == 0) cnt[blockIdx.x] = scan[0] + scan[1] + scan[2] + scan[3];
+        return;
+    }
+    const unsigned m = mask[slot];
+    const int n = __builtin_popcount(m);
     scan[tid] = n;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {  // inclusive scan of the threads' counts
@@ -1880,16 +1916,12 @@ __global__ __launch_bounds__(256) void shard_select_kernel(ShardSel s, int32_t* 
         scan[tid] += v;
         __syncthreads();
     }
-    if (!WRITE) {
-        if (tid == 255) cnt[blockIdx.x] = scan[255];
-        return;
-    }
     int64_t o = offs[blockIdx.x] + (scan[tid] - n);
-#pragma unroll
-    for (int j = 0; j < kSelPerThread; ++j) {
-        if (own[j] < 0) continue;
-        sel_row[o] = own[j];
-        sel_i[o] = (int64_t)(i0 + j);
+    for (unsigned r = m; r; r &= r - 1) {
+        const int j = __builtin_ctz(r);
+        const uint64_t i = i0 + j;
+        sel_row[o] = shard_locate(s, step_start, nsteps, (int64_t)shuffle_index(s.sh, i));
+        sel_i[o] = (int64_t)i;
         ++o;
     }
 }
@@ -1972,26 +2004,28 @@ hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, 
 size_t mlp_shard_scratch_bytes(int64_t rows_global)
 {
     const size_t nb = (size_t)((rows_global + kSelPerBlock - 1) / kSelPerBlock);
-    return sizeof(int64_t) * (nb + 2) + sizeof(int32_t) * (nb + 2);
+    return sizeof(int64_t) * (nb + 2) + sizeof(int32_t) * (nb + 2) + sizeof(uint16_t) * 256 * (nb + 1) + 64;
 }
 
 hipError_t mlp_shard_select(hipStream_t st, int64_t rows_global, uint64_t shuffle_key, const int64_t* gstart,
-                            const int64_t* lstart, int nseg, void* scratch, int64_t* sel_row, int64_t* sel_i,
+                            const int64_t* lstart, int nseg, int group, void* scratch, int64_t* sel_row, int64_t* sel_i,
                             const int64_t** total_dev)
 {
     const int64_t nb = (rows_global + kSelPerBlock - 1) / kSelPerBlock;
     int64_t* offs = (int64_t*)scratch;
     int32_t* cnt = (int32_t*)(offs + nb + 2);
+    uint16_t* mask = (uint16_t*)(((uintptr_t)(cnt + nb + 2) + 15) & ~(uintptr_t)15);
     *total_dev = offs + nb;
     if (nb == 0 || nseg <= 0) return hipMemsetAsync(offs, 0, sizeof(int64_t) * (size_t)(nb + 1), st);
     ShardSel s;
     s.sh = make_shuffle(rows_global, shuffle_key);
-    s.gstart = gstart; s.lstart = lstart; s.nseg = nseg;
-    hipLaunchKernelGGL(shard_select_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, s, cnt, (const int64_t*)nullptr,
+    s.gstart = gstart; s.lstart = lstart; s.nseg = nseg; s.group = group;
+    hipLaunchKernelGGL(shard_select_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, s, cnt, mask, (const int64_t*)nullptr,
                        (int64_t*)nullptr, (int64_t*)nullptr);
     hipError_t e = nn_scan_counts(st, cnt, nb, offs);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(shard_select_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, s, cnt, (const int64_t*)offs, sel_row, sel_i);
+    hipLaunchKernelGGL(shard_select_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, s, cnt, mask, (const int64_t*)offs,
+                       sel_row, sel_i);
     return hipGetLastError();
 }
 

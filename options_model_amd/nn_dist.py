@@ -126,12 +126,17 @@ def price_american_option_nn_sharded(sp, S0, K, r, sigma, T, n_paths, n_steps, m
             tseed = int(torch.randint(0, 2 ** 62, (1,)).item())  # the same draw on every rank
             best, step = None, 0
             torch.cuda.synchronize(dev)
+            t_sel = t_trn = 0.0
             for epoch in range(int(nn_epochs)):
+                ta = time.perf_counter()
                 so = ctx.mlp_shard_epoch(data.data_ptr(), R_local, R, bs, nr._epoch_key(tseed, epoch), gstart, lstart,
-                                         data_epoch.data_ptr(), drop_pos.data_ptr())
+                                         data_epoch.data_ptr(), drop_pos.data_ptr(), segs_per_step=2 * world)
+                tb = time.perf_counter()
                 avg, step = ctx.mlp_train_epoch_sharded(data_epoch.data_ptr(), R_local, R, bs, params.data_ptr(),
                                                         m.data_ptr(), v.data_ptr(), step, ctl.lr, p_drop, tseed, so,
                                                         drop_pos.data_ptr(), hidden=H, layers=L)
+                t_sel += tb - ta
+                t_trn += time.perf_counter() - tb
                 keep, stop = ctl.step(avg)  # the job's mean loss: the same decision on every rank
                 if keep:
                     best = params.clone()
@@ -142,7 +147,8 @@ def price_american_option_nn_sharded(sp, S0, K, r, sigma, T, n_paths, n_steps, m
             if best is not None:
                 params = best
             info.update(batch=bs, optimizer_steps=step, epochs_run=epoch + 1, best_loss=ctl.best_loss,
-                        best_epoch=ctl.best_epoch, graphed=False)
+                        best_epoch=ctl.best_epoch, graphed=False, seconds_select=t_sel, seconds_train_epochs=t_trn,
+                        rows_local=R_local)
             del data, data_epoch
             t2 = time.perf_counter()
             p2seed = int(torch.randint(0, 2 ** 62, (1,)).item())
