@@ -21,7 +21,8 @@ def pytest_configure(config):
 # alphabetical order between the two groups.
 _FIRST = ["test_gpu_parity.py", "test_gpu_fuzz.py", "test_gpu_nn.py", "test_gpu_nn_full.py", "test_gpu_large.py",
           "test_gpu_api.py", "test_gpu_contnet.py", "test_gpu_calibrator.py", "test_gpu_localvol.py", "test_gpu_mlp.py"]
-_LAST = ["test_gpu_step_multi.py", "test_gpu_dist.py", "test_gpu_multirank.py", "test_gpu_facade_ranks.py"]
+_LAST = ["test_gpu_step_multi.py", "test_gpu_dist.py", "test_gpu_multirank.py", "test_gpu_facade_ranks.py",
+         "test_gpu_nn_dist.py"]
 
 
 def pytest_collection_modifyitems(session, config, items):
