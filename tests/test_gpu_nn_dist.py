@@ -83,13 +83,15 @@ def test_sharded_nn_tiny_and_empty_shards(plain_process, world):
         dict(S0=118.0, K=100.0, T=0.25, n_paths=16 * world, n_steps=4, option_type="put"),  # a few rows; some ranks none
         dict(S0=50.0, K=100.0, T=0.5, n_paths=64, n_steps=5, option_type="call"),        # nothing ever in the money
         dict(S0=100.0, K=100.0, T=1.0, n_paths=3000, n_steps=9, option_type="put"),      # several minibatches of 256
+        dict(S0=100.0, K=100.0, T=1.0, n_paths=2048, n_steps=8, option_type="put", model="Heston"),  # Heston shards
     ]
     pool = plain_process.pool(world, [0] * world)
     for c in cases:
+        model = c.get("model", "GBM")
         kw = dict(S0=c["S0"], K=c["K"], r=0.05, sigma=0.2, T=c["T"], n_paths=c["n_paths"], n_steps=c["n_steps"],
-                  model="GBM", option_type=c["option_type"], heston_params=None, seed=3, stream=1)
+                  model=model, option_type=c["option_type"], heston_params=None, seed=3, stream=1)
         res = pool.call_all("price_american_option_nn", dict(kw, **nn), timeout_s=300)
-        one = price_american_option(c["S0"], c["K"], 0.05, 0.2, c["T"], c["n_paths"], c["n_steps"], model="GBM",
+        one = price_american_option(c["S0"], c["K"], 0.05, 0.2, c["T"], c["n_paths"], c["n_steps"], model=model,
                                     option_type=c["option_type"], regressor="nn", seed=3, stream=1, nn_options=nn)
         assert len({r["price"] for r in res}) == 1, c
         r0 = res[0]
