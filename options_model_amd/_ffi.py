@@ -691,8 +691,25 @@ _default_ctx = {}
 _ctx_lock = threading.Lock()
 
 
-def default_context(device: int = 0) -> Context:
+def resolve_device(device=None) -> int:
+    """Which HIP device a call without an explicit `device` uses.  Default 0.  OMC_DEVICE=<k> picks device k;
+    OMC_DEVICE=auto spreads PROCESSES over the node's GPUs by pid -- the reference's UIs fan the spot values of a curve
+    job over a spawn pool (options_model_2_ui.py:87-133, options_model_3.py:1043-1056): with `auto` those workers,
+    whose pids are consecutive, land on different GPUs without a change to the caller."""
+    if device is not None:
+        return int(device)
+    env = os.environ.get("OMC_DEVICE", "").strip().lower()
+    if not env:
+        return 0
+    if env == "auto":
+        n = device_count()
+        return os.getpid() % n if n > 0 else 0
+    return int(env)
+
+
+def default_context(device=None) -> Context:
     """Lazily created per (process, device) -- safe under spawn'ed worker pools."""
+    device = resolve_device(device)
     key = (os.getpid(), device)
     with _ctx_lock:
         ctx = _default_ctx.get(key)

@@ -101,7 +101,7 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
     if n_gpus < 1:
         raise ValueError("n_gpus must be a positive integer.")
     if device is None and n_gpus == 1:
-        device = 0
+        device = _ffi.resolve_device(None)  # 0, or what OMC_DEVICE says ("auto": spread processes over the GPUs)
     if model_l not in ("gbm", "heston"):
         raise ValueError("model must be 'GBM' or 'Heston'.")
     if semantics not in _SEM:

@@ -119,7 +119,7 @@ class AdvancedOptionPricer:
                  # -- extensions (keyword-only in spirit; the GPU file adds nn_layers/nn_dropout
                  #    the same way, option_model_3_gpu.py:557-561)
                  nn_layers: int = 3, nn_dropout: float = 0.10, regressor: Optional[str] = None,
-                 semantics: str = "two_pass", device: int = 0, n_gpus: Optional[int] = None,
+                 semantics: str = "two_pass", device: Optional[int] = None, n_gpus: Optional[int] = None,
                  devices: Optional[list] = None):
         """Called with the reference's own arguments only, this prices the way the reference does:
         ONE SingleLSMNet(7, nn_hidden, nn_layers) with dropout, trained on the pass-1 rows and applied
@@ -150,7 +150,7 @@ class AdvancedOptionPricer:
         self.use_streaming, self.chunk_size = use_streaming, chunk_size
         self.european_approximation = european_approximation
         self.use_control_variate = use_control_variate
-        self.regressor, self.semantics, self.device = regressor, semantics, device
+        self.regressor, self.semantics, self.device = regressor, semantics, _ffi.resolve_device(device)
         self.n_gpus = int(n_gpus if n_gpus is not None else os.environ.get("OMC_N_GPUS", "1"))
         if self.n_gpus < 1:
             raise ValueError("n_gpus must be a positive integer.")

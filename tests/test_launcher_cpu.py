@@ -148,3 +148,19 @@ def test_advanced_pricer_n_gpus_routes_through_the_facade(monkeypatch):
     assert kw["seed"] == sc_seeds.get_child_seed() and kw["n_paths"] == 10000 and kw["n_steps"] == 50
     monkeypatch.setenv("OMC_N_GPUS", "4")  # the UI cannot pass the argument: the environment can
     assert AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, regressor="poly").n_gpus == 4
+
+
+def test_omc_device_spreads_processes_over_gpus(monkeypatch):
+    """OMC_DEVICE=auto: the reference's UIs fan a curve job's spot values over a spawn pool (options_model_2_ui.py:
+    87-133); each worker process picks a GPU from its pid, so the pool uses the node without a change to the caller."""
+    from options_model_amd import _ffi
+    monkeypatch.delenv("OMC_DEVICE", raising=False)
+    assert _ffi.resolve_device(None) == 0 and _ffi.resolve_device(3) == 3
+    monkeypatch.setenv("OMC_DEVICE", "5")
+    assert _ffi.resolve_device(None) == 5 and _ffi.resolve_device(1) == 1  # an explicit argument wins
+    monkeypatch.setenv("OMC_DEVICE", "auto")
+    monkeypatch.setattr(_ffi, "device_count", lambda: 8)
+    monkeypatch.setattr(os, "getpid", lambda: 4243)
+    assert _ffi.resolve_device(None) == 4243 % 8
+    monkeypatch.setattr(_ffi, "device_count", lambda: 0)
+    assert _ffi.resolve_device(None) == 0
