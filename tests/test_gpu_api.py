@@ -268,3 +268,21 @@ def test_v1_5_class_surface(ctx, monkeypatch):
     assert len(poly) == 6 and poly != recs
     with pytest.raises(ValueError, match="sigma must be positive"):
         compute_curve_worker(100.0, 100.0, 0.05, -0.2, "call", 2, 7, 4, 6, 2000, False)
+
+
+def test_owned_stream_is_ordered_after_the_callers_default_stream(ctx):
+    """include/omc.h, "stream ordering": a context that owns its (non-blocking) stream waits, on entry of a call that
+    borrows a device pointer, for what is pending on the device's default stream -- where torch queues.  Here ~1 GB of
+    fills of the SAME buffer are still queued on torch's stream when the library is asked to write it: the library's
+    result must be what is in the buffer afterwards (round 3's red driver run was this race, lost by a test)."""
+    import torch
+    n = 16_000_003
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    for _ in range(8):
+        out.fill_(-1)  # 8 x 128 MB queued on the default stream; NO synchronize
+    ctx.mlp_shuffle_indices(n, 99, out.data_ptr())
+    got = out.cpu().numpy()
+    assert got.min() == 0 and got.max() == n - 1 and np.unique(got[:2_000_000]).size == 2_000_000
+    assert int(got.sum()) == n * (n - 1) // 2  # a permutation of 0 .. n-1, no -1 left behind
+    # the other direction is the exit contract: the call returned after its stream drained, so torch sees the result
+    assert int(out.sum().item()) == n * (n - 1) // 2
