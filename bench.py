@@ -45,6 +45,7 @@ CONFIGS = {  # BASELINE.json configs[1..3]
     "c3": dict(model="gbm", paths_per_gpu=8_000_000),
     "c3x1": dict(model="gbm", paths_per_gpu=64_000_000),  # ALL of configs[2] on one GPU (65 GB of paths)
     "c4": dict(model="heston", paths_per_gpu=4_000_000),
+    "c5": dict(model="gbm", paths_per_gpu=1_000_000),  # configs[4]: the NN regressor (2 x 64): its own flow, bench_c5()
 }
 MARKET = dict(S0=100.0, K=100.0, r=0.05, sigma=0.2, T=1.0)
 HESTON = dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7)
@@ -131,6 +132,52 @@ def launch_ranks(n: int, deadline_s: float, argv=None) -> int:
                                  who="bench.py", timeout_flag="--rank-timeout")
 
 
+def bench_c5(a) -> int:
+    """BASELINE configs[4] as a bench line of its own: GBM American put, 1M paths x 252 steps, NN continuation-value
+    regressor SingleLSMNet(7, 64, 2) -- rows + normalisers, 25 epochs of the float32-MFMA trainer, the sticky pass 2,
+    all in the library's kernels.  A step is one whole pricing.  The dominant kernel is mlp_train_kernel: its roofline is
+    the float32 matrix-core peak, `achieved` = algorithmic FLOP of the rows trained / the time spent in the training
+    launches (the rocprofv3 averages of the same run are in profiles/r04_c5_kernel_stats.csv)."""
+    import torch
+    from options_model_amd import nn_regressor as nnr
+    M, N = a.paths_per_gpu or CONFIGS["c5"]["paths_per_gpu"], a.n_steps
+    steps, warm = max(1, min(a.steps, 5)), max(1, min(a.warmup, 2))
+    nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, seed=1, nn_epochs=2)
+    for i in range(warm):
+        nnr.price_american_option_nn(MARKET["S0"], MARKET["K"], MARKET["r"], MARKET["sigma"], MARKET["T"], M, N, seed=7 + i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [nnr.price_american_option_nn(MARKET["S0"], MARKET["K"], MARKET["r"], MARKET["sigma"], MARKET["T"], M, N,
+                                         seed=42 + i) for i in range(steps)]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    o = outs[0]
+    flop = 2 * (8 * 64 + 64 * 64 + 64) + 2 * 2 * 64 * 64 + 2 * 8 * 64  # per row: forward, dH1, gW2, gW1
+    tk = sum(x.timings_ms.get("train_kernels", 0.0) for x in outs) * 1e-3
+    rows = sum(x.sum_nitm * x.info.get("epochs_run", 0) for x in outs)
+    tf = rows * flop / tk / 1e12 if tk > 0 else None
+    line = {
+        "metric": "paths x steps / sec (whole American pricing: path-gen + LSM + mean)", "value": M * N / dt,
+        "unit": "path-steps/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"GBM American put, S0=K=100 r=0.05 sigma=0.2 T=1, {M} paths x {N} steps, NN regressor "
+                               f"SingleLSMNet(7, 64, 2), 25 epochs, batch {o.info.get('batch')} (two_pass flow)",
+                   "baseline_config": "c5", "paths_per_gpu": M, "n_steps": N, "parallelism": "single GPU"},
+        "roofline": {"kernel": "mlp_train_kernel", "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": tf / 157.3 if tf else None, "traffic": None, "flop_per_row": flop, "rows_trained": rows,
+                     "kernel_seconds": tk, "note": "float32 products (the reference's precision); the chip holds 2.14 GHz "
+                     "under this load, the peak is quoted at 2.4 GHz (DESIGN.md 6.3)"},
+        "cpu_baseline": {"value": 3500.0, "unit": "path-steps/s", "cores": 8, "kind": "reference",
+                         "sample": "BASELINE.md section 2: the reference's own NN pricer on 10k x 50 (132-153 s); its "
+                                   "settings are infeasible at this size (1.1e7 optimizer steps of batch 256), not re-run here"},
+        "price": o.price, "stderr": o.stderr, "rows": o.sum_nitm, "info": o.info,
+        "timings_ms": {k: round(v, 3) for k, v in o.timings_ms.items()},
+        "price_check": "tests/test_gpu_nn_full.py: rows / normalisers / frozen-net decisions vs the oracle on this config",
+    }
+    print(json.dumps(line))
+    return 0
+
+
 # ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -181,6 +228,11 @@ def main():
         a.no_cpu_baseline = a.no_variants = a.no_sustained = True
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+
+    if a.config == "c5":
+        if a.gpus != 1:
+            raise SystemExit("bench.py --config c5 is a single-GPU line (the sharded NN flow: tools/time_nn_sharded.py)")
+        sys.exit(bench_c5(a))
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus, a.rank_timeout))  # nothing above touched the GPU
