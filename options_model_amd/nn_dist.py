@@ -79,6 +79,9 @@ def price_american_option_nn_sharded(sp, S0, K, r, sigma, T, n_paths, n_steps, m
     from .api import PriceResult, _validate, heston_defaults
     torch = nr._torch()
     ctx, rank, world = sp.ctx, sp.rank, sp.world
+    if ctx.comm_info()[1] != world:
+        raise RuntimeError("the sharded NN regressor needs the library's own communicator on the rank's context "
+                           "(dist.RcclPricer); the torch.distributed hook transport does not carry its host-side sums")
     model_l = str(model).lower()
     _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
     M = int(n_paths) // 2 * 2
