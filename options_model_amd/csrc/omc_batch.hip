@@ -373,7 +373,7 @@ hipError_t batch_lsm(hipStream_t st, const void* table_dev, int n, const BatchEx
             const dim3 g1((unsigned)e.tile_blocks, (unsigned)((Nmax - 1 + 15) / 16), z);
             if (e.vec4) hipLaunchKernelGGL((lsm_pass1_batch_kernel<4>), g1, dim3(kBlock), 0, st, pr);
             else hipLaunchKernelGGL((lsm_pass1_batch_kernel<1>), g1, dim3(kBlock), 0, st, pr);
-            hipLaunchKernelGGL(lsm_reduce_pass1_batch_kernel, dim3(Nmax - 1, 8, z), dim3(kBlock), 0, st, pr);
+            hipLaunchKernelGGL(lsm_reduce_pass1_batch_kernel, dim3(Nmax - 1, 1, z), dim3(kBlock), 0, st, pr);
             hipLaunchKernelGGL(lsm_solve_all_batch_kernel, dim3((Nmax + 255) / 256, 1, z), dim3(256), 0, st, pr);
         }
         const size_t dyn = sizeof(double) * 4 * (size_t)(Nmax + 1);

@@ -63,6 +63,16 @@ __device__ __forceinline__ void normals4(uint64_t pair, uint32_t block, uint32_t
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// ------------------------------------------------------------------ XCD-aware block numbering
+// A launch's workgroups go to the chip's 8 XCDs round robin in launch order (blockIdx.x % 8 for a 1-D grid).
+// xcd_block() renumbers the G blocks of a grid row so that the blocks running on ONE XCD own CONSECUTIVE numbers:
+// a bijection on [0, G) (residue r gets the r-th run, of G/8 or G/8 + 1 numbers).
+__device__ __forceinline__ int xcd_block(int bx, int G)
+{
+    const int r = bx & 7, q = G >> 3, rem = G & 7;
+    return r * q + (r < rem ? r : rem) + (bx >> 3);
+}
+
 // ------------------------------------------------------------------ staging a parameter block into LDS
 // put(i, src[i]) for i in [0, n), 256-thread workgroups.  A plain `for (i = tid; i < n; i += 256) dst[f(i)] = src[i]`
 // compiles to load -> s_waitcnt vmcnt(0) -> ds_write per (pair of) iteration(s): one global round trip after the

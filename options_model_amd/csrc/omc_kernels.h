@@ -79,7 +79,7 @@ struct LsmWorkspace {
     double* gmom;     // [N+1][8] reduced moments per step (row stride `gstride` doubles)
     int gstride = 8;  // K pricings advanced together keep their moments in ONE table [N+1][K][8]: stride 8K
     double* betas;    // [N+1][4] b0,b1,b2,n
-    double* part1;    // two-pass: [N+1][8][ntiles] partial moments of pass 1
+    double* part1;    // two-pass: [N+1][ntiles][8] partial moments of pass 1 (one 64-byte record per step and tile)
     int64_t part1_tiles;
     double* result;   // [8] sum, sumsq, n_exercised, n_zero, sum_nitm, -, -, -
     const float* cont = nullptr;  // per-step sweeps, "values" mode: continuation values [N+1][ldc]

@@ -355,7 +355,7 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
     else if (tpw == 8) launch(integral_constant<int, 4>{}, integral_constant<int, 8>{});
     else launch(integral_constant<int, 4>{}, integral_constant<int, 4>{});
     if (w.ev_p1_end) (void)hipEventRecord(w.ev_p1_end, st);
-    hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1, 8), dim3(kBlock), 0, st, w.part1, w.gmom,
+    hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1), dim3(kBlock), 0, st, w.part1, w.gmom,
                        a.ntiles, p.N);
     return hipGetLastError();
 }

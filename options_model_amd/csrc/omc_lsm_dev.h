@@ -105,7 +105,8 @@ struct StepArgs {
 //   * K pricings per launch (lsm_step_multi_kernel): each pricing gets G = workgroups / K of the chip's
 //     workgroups and workgroup w of a pricing walks slots w, w + G, w + 2G, ...  -- so the K pricings are
 //     co-resident and share ONE launch boundary and ONE cold start per time step, and each of them returns the
-//     bits of its own single launch.
+//     bits of its own single launch.  (Consecutive, XCD-aware runs of slots instead -- what pass 1 gains 3.5 % from
+//     -- change nothing here: 0.758-0.763 against 0.760-0.764 ms per pricing at K = 16, round 4.)
 // Workgroup count per pricing = number of partials every workgroup's wave 0 re-reads in its prologue
 // (kStepMaxBlocks / 64 per lane and quantity, all issued before anything waits).
 constexpr int kStepMaxBlocks = 256;
@@ -429,7 +430,10 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     __shared__ double wl[kBlock / 64][kWaveRedDoubles];
     __shared__ double shD[kBlock / 64][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tg = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    // Tile groups are numbered XCD-aware: the workgroups that run on one XCD walk one contiguous eighth of every row
+    // (measured: pass 1 202 -> 195 us at C2, 1.53 -> 1.47 ms at C3's shard; the same renumbering does nothing for the
+    // generator and pass 2, profiles/r04_xcd_mapping.txt).  Changes no sum: partials are per (step, tile).
+    const int64_t tg = (int64_t)xcd_block((int)blockIdx.x, (int)gridDim.x) * (kBlock / 64) + wave;
     if (tg >= a.ntiles) return;  // whole wave leaves; no workgroup barrier below
     const int64_t base = tg * (64 * VEC * TPW) + (int64_t)lane * VEC;
     // Time chunks are visited LATEST FIRST (workgroups are dispatched in blockIdx order): the generator
@@ -525,7 +529,11 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         acc[6] *= d;
         acc[7] *= d;
         const double s = wave_reduce8(acc, wl[wave]);
-        if ((lane & 7) == 0) a.part1[((size_t)t * 8 + (lane >> 3)) * a.ntiles + tg] = s;
+        // one 64-byte record per (step, tile): the eight result lanes write consecutive doubles, a workgroup's four
+        // waves two whole cache lines -- no line of part1 is shared between workgroups (which run on different XCDs,
+        // i.e. behind different L2s: with the quantity-major layout [t][q][tile] every line was written back piecemeal
+        // from four of them: pass 1 of C3's shard 1.53-1.65 -> 1.48-1.50 ms, profiles/r04_xcd_mapping.txt)
+        if ((lane & 7) == 0) a.part1[((size_t)t * a.ntiles + tg) * 8 + (lane >> 3)] = s;
     };
     // Rows are read with the nontemporal hint (each byte is used once per launch): 253 -> 218 us at
     // C2 (pass 2 reads its rows the same way; on the generator's stores the hint only moves time between kernels).
@@ -569,19 +577,38 @@ __device__ __forceinline__ void lsm_reduce_pass1_body(const double* __restrict__
                                                       int N)
 {
     if ((int)blockIdx.x + 1 >= N) return;  // batched launches are sized for the longest problem
-    // one workgroup per (step, quantity): 8x more workgroups than one per step, each with a
-    // short strided sum -- the slab read is latency-bound, so parallelism is what it needs
-    __shared__ double sh[kBlock / 64];
+    // One workgroup per step: a thread adds the 64-byte records of tiles tid, tid + 256, ... (all eight quantities of
+    // a tile in one contiguous read), then every quantity goes through the same tree -- xor-shuffles inside a wave,
+    // waves paired (0 + 1) + (2 + 3).  Per quantity that is the order of the former one-workgroup-per-(step,
+    // quantity) kernel over the [t][q][tile] layout: same bits.
+    __shared__ double sh[kBlock / 64][8];
     const int tid = threadIdx.x;
-    const int t = blockIdx.x + 1, q = blockIdx.y;
-    const double* pp = part1 + ((size_t)t * 8 + q) * ntiles;
-    double s = 0.0;
-    for (int64_t i = tid; i < ntiles; i += kBlock) s += pp[i];
+    const int t = blockIdx.x + 1;
+    const double2* pp = reinterpret_cast<const double2*>(part1 + (size_t)t * ntiles * 8);
+    double s[8];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    for (int q = 0; q < 8; ++q) s[q] = 0.0;
+    for (int64_t i = tid; i < ntiles; i += kBlock) {
+        double2 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = pp[i * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[2 * k] += r[k].x;
+            s[2 * k + 1] += r[k].y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s[q] += __shfl_xor(s[q], off);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sh[tid >> 6][q] = s[q];
+    }
     __syncthreads();
-    if (tid == 0) gmom[(size_t)t * 8 + q] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (tid < 8) gmom[(size_t)t * 8 + tid] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
 }
 
 __device__ __forceinline__ void lsm_solve_all_body(const double* __restrict__ gmom, double* __restrict__ betas,
