@@ -71,6 +71,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    for f in os.listdir(LIBDIR):  # objects of sources that no longer exist must not travel to the GPU box
+        if f.endswith(".o") and os.path.join(LIBDIR, f) not in objs:
+            os.remove(os.path.join(LIBDIR, f))
     link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(link), flush=True)

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
 MODELS = {"gbm": 0, "heston": 1}
@@ -108,6 +108,8 @@ SIGNATURES = {
     "omc_mlp_train_batch_supported": (C.c_int, [_I, _I, _I64]),
     "omc_mlp_train_epoch_batch": (C.c_int, [_P, C.POINTER(MlpJob), _I, _I, _I] + [_D] * 5),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
+    "omc_mlp_train_variant": (C.c_int, [C.c_int, C.c_int, _I64]),
+    "omc_mlp_dropout_masks": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _I64, _P, C.c_uint32, _U64, C.c_double, _P]),
     "omc_nn_half_counts": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _I, _P]),
     "omc_mlp_shard_epoch": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _P, _P, _I, _I, _P, _P, _P]),
     "omc_mlp_train_epoch_sharded": (C.c_int, [_P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, C.POINTER(C.c_int64)]
@@ -610,6 +612,17 @@ class Context:
         _check(self.lib, self.lib.omc_nn_feature_stats(self.handle, int(x_ptr), int(t_ptr), int(y_ptr),
                                                        int(n_rows), float(T), float(dt), out.ctypes.data))
         return out[:7].copy(), out[8:15].copy()
+
+    def mlp_dropout_masks(self, variant, hidden, layers, n_rows, step, seed, dropout, keys=None):
+        """keep (True) / drop of every hidden activation as kernel `variant` draws it -> bool [layers, n_rows, hidden]
+        (variant 0: pass 2, keys = path columns, step = time step; 1 / 2 / 3: omc_mlp_train_variant)."""
+        out = np.zeros((int(layers), int(n_rows), int(hidden)), np.uint8)
+        k = None if keys is None else np.ascontiguousarray(keys, np.uint32)
+        assert k is None or k.size == n_rows
+        _check(self.lib, self.lib.omc_mlp_dropout_masks(self.handle, int(variant), int(hidden), int(layers), int(n_rows),
+                                                         k.ctypes.data if k is not None else None, int(step),
+                                                         int(seed) & (2 ** 64 - 1), float(dropout), out.ctypes.data))
+        return out.astype(bool)
 
     def mlp_shuffle_indices(self, n_rows, shuffle_key, out_ptr):
         _check(self.lib, self.lib.omc_mlp_shuffle_indices(self.handle, int(n_rows), int(shuffle_key), int(out_ptr)))

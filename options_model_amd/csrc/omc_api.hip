@@ -2069,6 +2069,33 @@ int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const do
     return 0;
 }
 
+int omc_mlp_train_variant(int hidden, int layers, int64_t batch)
+{
+    return omc::mlp_train_kernel_choice(hidden, layers, batch);
+}
+
+int omc_mlp_dropout_masks(omc_ctx* c, int variant, int hidden, int layers, int64_t n_rows, const uint32_t* keys,
+                          uint32_t step, uint64_t seed, double dropout, uint8_t* out)
+{
+    int rc = bind_in(c);
+    if (rc) return rc;
+    if (variant < 0 || variant > 3) return fail(-4, "variant must be 0 (pass 2) or 1, 2, 3 (omc_mlp_train_variant).");
+    const bool shape_ok = variant == 3 ? (hidden == 32 || hidden == 64 || hidden == 128)
+                        : variant == 1 ? hidden == 64 : (hidden == 64 || hidden == 128);
+    if (!shape_ok || layers < 1 || layers > 3) return fail(-9, "this kernel does not exist for that network shape.");
+    if (n_rows <= 0 || !out) return fail(-3, "n_rows must be positive, out non-null.");
+    if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
+    const size_t nout = (size_t)layers * (size_t)n_rows * (size_t)hidden, nkey = keys ? sizeof(uint32_t) * (size_t)n_rows : 0;
+    if ((rc = c->scratch.ensure(nout + nkey + 16))) return rc;
+    uint8_t* dout = (uint8_t*)c->scratch.p;
+    uint32_t* dkeys = keys ? (uint32_t*)(dout + ((nout + 15) & ~(size_t)15)) : nullptr;
+    if (keys) HIP_TRY(hipMemcpyAsync(dkeys, keys, nkey, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(omc::mlp_dropout_masks(c->stream, variant, hidden, layers, n_rows, dkeys, step, seed, dropout, dout));
+    HIP_TRY(hipMemcpyAsync(out, dout, nout, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int omc_mlp_shuffle_indices(omc_ctx* c, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device)
 {
     int rc = bind_in(c);

@@ -191,6 +191,10 @@ size_t mlp_partial_bytes(int hidden, int layers, int64_t batch);
 size_t mlp_wt_bytes(int hidden, int layers);
 int mlp_train_param_count(int hidden, int layers);               // -1: shape not covered by a trainer
 int mlp_train_kernel_choice(int hidden, int layers, int64_t batch);  // 0: this batch size is not covered
+// keep (1) / drop (0) of every hidden activation as kernel `variant` draws it (0: pass 2, 1 / 2 / 3: the trainers, the
+// values of mlp_train_kernel_choice) -> out [layers][n_rows][hidden] (device); keys: per-row dropout key or null (= row)
+hipError_t mlp_dropout_masks(hipStream_t st, int variant, int hidden, int layers, int64_t n_rows, const uint32_t* keys,
+                             uint32_t step, uint64_t seed, double dropout, uint8_t* out);
 // pass 2 of the NN flow: sticky sweep with the network as continuation value -> (sx, tex)
 // hidden in {64, 128}, layers (hidden layers) in {2, 3}; mlp_apply_param_count: floats, -1 otherwise
 int mlp_apply_param_count(int hidden, int layers);

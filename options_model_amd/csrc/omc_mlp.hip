@@ -1993,6 +1993,82 @@ size_t mlp_partial_bytes(int hidden, int layers, int64_t batch)
 
 size_t mlp_wt_bytes(int hidden, int layers) { return sizeof(float) * (size_t)(layers - 1) * hidden * hidden; }
 
+// ---- which units does dropout keep?  (omc_mlp_dropout_masks: the device half of the mask oracle's known-answer test)
+// Runs the very device functions the trainers and pass 2 call -- relu_dropout / _t / _n / _1 -- on activations of 1.0
+// with each kernel's tags and its register -> hidden-unit map, and writes keep / drop per (layer, row, unit).
+// variant 0: mlp_apply_kernel (key = path column, step = time step), 1: mlp_train_kernel, 2: mlp_train_tile_kernel,
+// 3: mlp_train_quad_kernel (key = position in the minibatch, step = optimizer step).
+namespace {
+template <int H>
+__global__ __launch_bounds__(64) void mlp_mask_probe_kernel(int variant, int layers, int64_t n_rows, const uint32_t* keys,
+                                                            uint32_t step, uint32_t keep16, float inv_keep, uint32_t k0,
+                                                            uint32_t k1, uint8_t* __restrict__ out)
+{
+    constexpr int NT = H / 32;
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * 32 + c;
+    if (row >= n_rows) return;
+    const uint32_t key = keys ? keys[row] : (uint32_t)row;
+    auto rho = [&](int r) { return (r >> 2) * 8 + 4 * h + (r & 3); };
+    for (int j = 0; j < layers; ++j) {
+        uint8_t* o = out + ((size_t)j * (size_t)n_rows + (size_t)row) * H;
+        v16f z[NT];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[mt][r] = 1.0f;
+        if (variant == 3) {
+#pragma unroll
+            for (int w = 0; w < NT; ++w) {
+                relu_dropout_1(z[w], key, step, 0x100u * (uint32_t)(j + 1) + 0x10u * (uint32_t)w + (uint32_t)h, keep16,
+                               inv_keep, k0, k1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[32 * w + rho(r)] = z[w][r] != 0.0f;
+            }
+            continue;
+        }
+        if constexpr (NT >= 2) {
+            if (variant == 2) {
+                relu_dropout_t<NT, true>(z, key, step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, keep16, inv_keep, k0, k1);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[NT * rho(r) + mt] = z[mt][r] != 0.0f;
+            } else if (variant == 1) {
+                if constexpr (NT == 2) {
+                    relu_dropout<false>(z, key, step, 0x100u * (uint32_t)(j + 1) + (uint32_t)h, keep16, inv_keep, k0, k1);
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[unit_of(mt, r, h)] = z[mt][r] != 0.0f;
+                }
+            } else {
+                const uint32_t tag = (j == 0 ? 0x300u : 0x400u + 0x100u * (uint32_t)(j - 1)) + (uint32_t)h;
+                relu_dropout_n<NT>(z, key, step, tag, keep16, inv_keep, k0, k1);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[unit_of(mt, r, h)] = z[mt][r] != 0.0f;
+            }
+        }
+    }
+}
+}  // namespace
+
+hipError_t mlp_dropout_masks(hipStream_t st, int variant, int hidden, int layers, int64_t n_rows, const uint32_t* keys,
+                             uint32_t step, uint64_t seed, double dropout, uint8_t* out)
+{
+    const uint32_t keep16 = dropout > 0.0 ? (uint32_t)llround((1.0 - dropout) * 65536.0) : 65536u;
+    const float inv_keep = keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)keep16);
+    const dim3 grid((unsigned)((n_rows + 31) / 32)), block(64);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (hidden == 32) hipLaunchKernelGGL(mlp_mask_probe_kernel<32>, grid, block, 0, st, variant, layers, n_rows, keys, step, keep16, inv_keep, k0, k1, out);
+    else if (hidden == 64) hipLaunchKernelGGL(mlp_mask_probe_kernel<64>, grid, block, 0, st, variant, layers, n_rows, keys, step, keep16, inv_keep, k0, k1, out);
+    else if (hidden == 128) hipLaunchKernelGGL(mlp_mask_probe_kernel<128>, grid, block, 0, st, variant, layers, n_rows, keys, step, keep16, inv_keep, k0, k1, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out)
 {
     if (n <= 0) return hipSuccess;

@@ -277,12 +277,13 @@ def lsm_two_pass(S, K, r, T, is_put, regress, predict):
         itm = (pay > 0) & ~ex
         if not itm.any():
             continue
-        cont = predict(model, t, S[t, itm])
+        cols = np.where(itm)[0]
+        cont = predict(model, t, S[t, itm], cols) if getattr(predict, "wants_cols", False) else predict(model, t, S[t, itm])
         if cont is None:
             continue
         imm = pay[itm]
         doex = imm > cont
-        idx = np.where(itm)[0][doex]
+        idx = cols[doex]
         cf[idx] = imm[doex]
         ex[idx] = True
     return cf, ex, model
@@ -342,16 +343,25 @@ def mlp_forward(state, x):
     return h
 
 
-def two_pass_frozen_mlp_regressor(K, T, N, state, fm, fs, Y_mean, Y_std):
-    """Pass 2 with given (already trained) weights, float32 cast as options_model_3.py:638."""
+def two_pass_frozen_mlp_regressor(K, T, N, state, fm, fs, Y_mean, Y_std, dropout=None):
+    """Pass 2 with given (already trained) weights, float32 cast as options_model_3.py:638.
+    dropout=None: the net in eval mode.  dropout=dict(p=, seed=, hidden=, layers=[, col_of=]): the net as the reference
+    runs it (:637-640, no .eval(): nn.Dropout active), with the build's mask definition (oracle/dropout.py) keyed by
+    (path column, time step); col_of maps a column of S to its column in the unsharded matrix (default: identity)."""
     dt = T / N
 
     def regress(rows):
         return None
 
-    def predict(_, t, s):
+    def predict(_, t, s, cols=None):
         f = regression_features(s, K, T, t * dt)
         fn = ((f - fm) / fs).astype(np.float32)
-        return mlp_forward(state, fn).ravel() * Y_std + Y_mean
+        if dropout is None:
+            return mlp_forward(state, fn).ravel() * Y_std + Y_mean
+        from . import dropout as dr
+        key = cols if dropout.get("col_of") is None else dropout["col_of"](cols)
+        masks = dr.apply_masks(dropout["hidden"], dropout["layers"], key, t, dropout["seed"], dropout["p"])
+        return dr.mlp_forward_masked(state, fn, masks, dropout["p"]).ravel() * Y_std + Y_mean
 
+    predict.wants_cols = dropout is not None
     return regress, predict
