@@ -328,16 +328,17 @@ int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t
                         double lr, double beta1, double beta2, double eps, double weight_decay,
                         double dropout, uint64_t seed, uint64_t shuffle_key, double* mean_loss);
 int omc_mlp_shuffle_indices(omc_ctx* ctx, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device);
-/* Which of the three trainer kernels omc_mlp_train_epoch runs for this shape at this minibatch size: 1 = one
- * workgroup per 128 rows with the weights in LDS (64 units, more than 32 tiles of 32 rows), 2 = one tile per wave,
- * 3 = one tile per workgroup (the reference's own minibatch of 256 rows), 0 = not covered.  The kernels hold the
- * hidden units in different register orders, so WHICH units dropout drops for a given (seed, step, row) depends on it. */
+/* Which of the four trainer kernels omc_mlp_train_epoch runs for this shape at this minibatch size: 1 = one
+ * workgroup per 128 rows with the weights in LDS (64 units, more than 32 tiles of 32 rows), 2 = one 32-row tile per
+ * wave, 3 = one 32-row tile per workgroup, 4 = one 16-row tile per workgroup (minibatches of up to 1,024 rows: the
+ * reference's own min(256, R)), 0 = not covered.  The kernels hold the hidden units in different register orders, so
+ * WHICH units dropout drops for a given (seed, step, row) depends on it. */
 int omc_mlp_train_variant(int hidden, int layers, int64_t batch);
 /* Inspection: the dropout masks themselves.  nn.Dropout's random stream in the reference is torch's global generator
  * (options_model_3.py:455, 85-103); here a unit's 16 random bits come from Philox4x32-10 keyed by `seed` with counter
  * (row key, step, layer / half-tile tag, constant), stretched by a multiply-with-carry stream (csrc/omc_mlp.hip
  * relu_dropout).  out (host, [layers][n_rows][hidden] bytes): 1 = kept, 0 = dropped, as kernel `variant` draws them
- * (0 = pass 2, omc_lsm_apply_mlp: row key = path column, step = time step t; 1 / 2 / 3 = omc_mlp_train_variant: row key
+ * (0 = pass 2, omc_lsm_apply_mlp: row key = path column, step = time step t; 1 .. 4 = omc_mlp_train_variant: row key
  * = position in the minibatch, step = optimizer step counted from 1).  keys (host, n_rows, may be NULL = 0, 1, 2, ...).
  * oracle/dropout.py restates the definition in numpy; tests compare the two bit for bit and then compare training and
  * pass 2 with the float32 / float64 restatement of the reference's arithmetic under these masks. */

@@ -129,7 +129,7 @@ struct omc_ctx {
     // main stream generates the paths of pricing k+1 into the second path buffer
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_moments[2] = {nullptr, nullptr}, ev_reduced[2] = {nullptr, nullptr};
-    DevBuf S2, seq_local, part1b, gmomb;
+    DevBuf S2, seq_local, part1b, gmomb, seq_vote;
     int seq_overlap = -1;  // -1: default (on when the communicator has more than one rank), 0 off, 1 on
     bool defer_result_allreduce = false;  // inside omc_price_american_seq: one collective for all result sums
     // captured per-step sweep (N launches + valuation + finalize), replayed for every pricing of the
@@ -551,7 +551,7 @@ int omc_ctx_destroy(omc_ctx* c)
     c->p2p = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->sweep_args, &c->bslab, &c->btable, &c->bres, &c->bdisc,
-                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->mlp_gred, &c->shard, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
+                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->mlp_gred, &c->shard, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->seq_vote, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
                       &c->mS, &c->mstate, &c->mtable, &c->mb_slab, &c->mb_table, &c->mb_bc})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
@@ -1381,7 +1381,9 @@ static int enqueue_seq_overlapped(omc_ctx* c, const omc_params* p, int n, double
 // GPUs the K moment vectors of a step travel in ONE all-reduce of 8K doubles.  Per pricing the arithmetic and
 // the order of every sum are those of its own launches (lsm_step_body), so res[i] keeps the bits of
 // omc_price_american(p[i]).
-static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
+// What the sequence itself allows: depends on the pricings, the context's settings and the environment only -- never on
+// this card's free memory -- so every rank of a job computes the same number (they are handed the same sequence).
+static int seq_multi_ideal(const omc_ctx* c, const omc_params* p, int n)
 {
     if (n < 2) return 1;
     static const int env_k = getenv("OMC_SEQ_STEP_K") ? atoi(getenv("OMC_SEQ_STEP_K")) : -1;
@@ -1403,10 +1405,17 @@ static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
         if (p[i].semantics != p[0].semantics || p[i].n_paths != p[0].n_paths || p[i].n_steps != p[0].n_steps ||
             p[i].r != p[0].r || p[i].T != p[0].T)
             return 1;
-    // K path matrices stay resident: bounded by a byte budget -- at most 64 GB of the 288 (OMC_SEQ_STEP_BYTES), and
-    // never more than 80 % of what is free on THIS card right now plus what the context already holds for them (a
-    // card shared with torch or with other ranks has less; omc_price_american_seq also halves K when the allocation
-    // fails all the same)
+    if (k > n) k = n;
+    if (k > 32) k = 32;
+    return k < 2 ? 1 : k;
+}
+
+// What THIS card has room for (rank-dependent).  K path matrices stay resident: bounded by a byte budget -- at most 64 GB
+// of the 288 (OMC_SEQ_STEP_BYTES), and never more than 80 % of what is free on this card right now plus what the context
+// already holds for them (a card shared with torch or with other ranks has less; seq_multi_reserve also halves K when
+// the allocation fails all the same).
+static int seq_multi_fit(const omc_ctx* c, const omc_params* p, int k)
+{
     static const double cap = getenv("OMC_SEQ_STEP_BYTES") ? atof(getenv("OMC_SEQ_STEP_BYTES")) : 64e9;
     double budget = cap;
     size_t free_b = 0, total_b = 0;
@@ -1421,9 +1430,14 @@ static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
     const double sbytes = 4.0 * (double)ld * (double)(p[0].n_steps + 1);
     const int fit = (int)(budget / sbytes);
     if (k > fit) k = fit;
-    if (k > n) k = n;
-    if (k > 32) k = 32;
     return k < 2 ? 1 : k;
+}
+
+// this rank's own estimate (omc_seq_step_width; a job agrees on the smallest in seq_multi_reserve)
+static int seq_multi_width(const omc_ctx* c, const omc_params* p, int n)
+{
+    const int k = seq_multi_ideal(c, p, n);
+    return k < 2 ? 1 : seq_multi_fit(c, p, k);
 }
 
 // Device memory of the K-pricings-per-launch sweep (K path matrices + per-pricing state).  -> 0, or the HIP error.
@@ -1442,26 +1456,45 @@ static int seq_multi_alloc(omc_ctx* c, int64_t M, int N, int K)
 }
 
 // Reserve for K pricings per launch; when the card has no room (shared with torch, several ranks on one device, a
-// smaller card) halve K down to one pricing at a time instead of failing the sequence.  Ranks of one job must agree
-// on K (their per-step collectives carry 8K doubles): with a communicator they take the smallest K any rank got.
-static int seq_multi_reserve(omc_ctx* c, const omc_params* p, int K, int* K_out)
+// smaller card) halve K down to one pricing at a time instead of failing the sequence.
+// Ranks of one job must agree on K (their per-step collectives carry 8K doubles, their direct exchanges K jobs), and a
+// rank must never skip a collective its peers enter.  So: whether a vote takes place depends on seq_multi_ideal alone
+// (the same on every rank); when it does, EVERY rank votes -- also one whose own K came out as 1, also one whose
+// allocation failed for another reason than memory -- through the context's generic all-reduce (communicator or
+// hook): a one-hot vector of 33 counters plus an error counter, summed; the job takes the smallest K anybody voted
+// for, and fails everywhere if anybody reported an error.
+static int seq_multi_reserve(omc_ctx* c, const omc_params* p, int n, int* K_out)
 {
-    int rc = 0;
+    *K_out = 1;
+    const int ideal = seq_multi_ideal(c, p, n);
+    if (ideal < 2) return 0;  // (every rank takes this branch together)
+    int K = seq_multi_fit(c, p, ideal), rc = 0, err = 0;
+    std::string err_text;
     while (K >= 2 && (rc = seq_multi_alloc(c, p[0].n_paths, p[0].n_steps, K)) != 0) {
-        if (rc != (int)hipErrorOutOfMemory && rc != (int)hipErrorMemoryAllocation) return rc;
+        if (rc != (int)hipErrorOutOfMemory && rc != (int)hipErrorMemoryAllocation) {
+            err = rc;
+            err_text = g_err;
+            break;
+        }
         K /= 2;
     }
-    if (K < 2) K = 1;
-    if (c->comm && omc::comm_world(c->comm) > 1) {
-        if ((rc = c->result.ensure(sizeof(double) * 8))) return rc;
-        double neg = -(double)K;
-        double* d = (double*)c->result.p;
-        HIP_TRY(hipMemcpyAsync(d, &neg, sizeof neg, hipMemcpyHostToDevice, c->stream));
-        std::string err;
-        if ((rc = omc::comm_allreduce_f64(c->comm, d, 1, 1 /* max */, c->stream, &err))) return fail(rc, err.c_str());
-        HIP_TRY(hipMemcpyAsync(&neg, d, sizeof neg, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        K = (int)llround(-neg);
+    if (K < 2 || err) K = 1;
+    if (c->distributed()) {
+        constexpr int kVote = 34;  // K = 1 .. 32 one-hot (slot K), slot 33 = ranks in trouble
+        double vote[kVote] = {0};
+        vote[K] = 1.0;
+        vote[33] = err ? 1.0 : 0.0;
+        if ((rc = c->seq_vote.ensure(sizeof vote))) return rc;  // (a failure HERE leaves the peers waiting: 272 bytes)
+        if ((rc = allreduce_host(c, (double*)c->seq_vote.p, vote, kVote))) return rc;
+        if (vote[33] > 0.0) {
+            if (err) return fail(err, err_text.c_str());
+            return fail(3101, "another rank of the job could not reserve memory for the sequence of pricings.");
+        }
+        K = 1;
+        for (int k = 1; k <= 32; ++k)
+            if (vote[k] > 0.0) { K = k; break; }
+    } else if (err) {
+        return fail(err, err_text.c_str());
     }
     *K_out = K < 2 ? 1 : K;
     return 0;
@@ -1583,8 +1616,8 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
     if (!c->ev_seq) HIP_TRY(hipEventCreate(&c->ev_seq));
     ev_end = c->ev_seq;
     const bool overlapped = seq_can_overlap(c, p, n);
-    int multi = overlapped ? 1 : seq_multi_width(c, p, n);
-    if (multi > 1 && (rc = seq_multi_reserve(c, p, multi, &multi))) return rc;
+    int multi = 1;
+    if (!overlapped && (rc = seq_multi_reserve(c, p, n, &multi))) return rc;
     if (overlapped && (rc = enqueue_seq_overlapped(c, p, n, c->seq_pin))) return rc;
     // across GPUs the sums stay in device memory (one slot per pricing) and are all-reduced together after
     // the last pricing -- the hook / communicator sees ONE call with 8n doubles -- then copied out
@@ -2079,7 +2112,7 @@ int omc_mlp_dropout_masks(omc_ctx* c, int variant, int hidden, int layers, int64
 {
     int rc = bind_in(c);
     if (rc) return rc;
-    if (variant < 0 || variant > 3) return fail(-4, "variant must be 0 (pass 2) or 1, 2, 3 (omc_mlp_train_variant).");
+    if (variant < 0 || variant > 4) return fail(-4, "variant must be 0 (pass 2) or 1 .. 4 (omc_mlp_train_variant).");
     const bool shape_ok = variant == 3 ? (hidden == 32 || hidden == 64 || hidden == 128)
                         : variant == 1 ? hidden == 64 : (hidden == 64 || hidden == 128);
     if (!shape_ok || layers < 1 || layers > 3) return fail(-9, "this kernel does not exist for that network shape.");

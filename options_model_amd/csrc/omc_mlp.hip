@@ -1347,6 +1347,286 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_kernel(MlpQuadArgs a)
     mlp_train_quad_body<H, L>(a, blockIdx.x);
 }
 
+// ------------------------------------------------------------------ 16-row tiles: the reference's own minibatch
+// The reference trains on minibatches of min(256, R) rows (options_model_3.py:574): 22,000 optimizer steps of 256 rows
+// at its default call.  In 32-row tiles that is 8 workgroups on a 256-CU chip, each running ~390 float32 MFMAs of 64
+// cycles behind one another and waiting for every block of weights to come back from L2 (round 5 profile: 23.7 us
+// per step at 3 x 128, of which 10 us are MFMA issue).  This kernel halves the serial part and takes the weight
+// fetches off the critical path:
+//   * a workgroup owns a 16-row tile and runs v_mfma_f32_16x16x4_f32 (the same multiply-adds per cycle as 32x32x2):
+//     twice the workgroups, half the MFMA cycles each;
+//   * ALL A operands of a 128 x 128 product (64 registers per lane) are requested a whole product ahead -- the forward
+//     products' at kernel entry, each backward product's as soon as the forward product that used the same registers
+//     is done -- so a product never waits for L2 (one wave per SIMD: 512 registers are there);
+//   * activations go through LDS in [k / 4][row][k % 4] order: the B operands of four k-steps are ONE 16-byte read.
+// Wave w owns hidden units 32 w .. 32 w + 31 of every layer, as two 16-row MFMA blocks ub = 0, 1 holding the even and
+// the odd units (output row m of block ub <-> unit 32 w + 2 m + ub: the two blocks' weights are one 8-byte load).
+// After an MFMA lane (row j = lane % 16, g = lane / 16) holds, for its row, the EIGHT CONSECUTIVE units 32 w + 8 g + e,
+// e = 2 r + ub (register r of block ub): dropout draws one Philox block (8 x 16 bits) per lane and layer.
+// k-step (q, t) of a product contracts k = 16 q + 4 g + t in lane group g -- any order is fine as long as A and B agree.
+typedef float v4f16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f16 mfma16(float a, float b, v4f16 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ReLU + inverted dropout on a lane's eight consecutive units (z[ub][r] <-> unit offset e = 2 r + ub): 16 bits per unit
+// straight from one Philox block -- word e / 2, half e % 2.  tag = 0x100 * (layer + 1) + (first unit / 8).
+__device__ __forceinline__ void relu_dropout_q16(v4f16 (&z)[2], uint32_t row, uint32_t step, uint32_t tag, uint32_t keep16,
+                                                 float inv_keep, uint32_t k0, uint32_t k1)
+{
+    if (keep16 >= 65536u) {
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[ub][r] = fmaxf(z[ub][r], 0.0f);
+        return;
+    }
+    const U4 o = philox4x32_10(row, step, tag, 0x4d4c5138u, k0, k1);
+    const uint32_t wd[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v0 = z[0][r], v1 = z[1][r];
+        z[0][r] = (v0 > 0.0f && (wd[r] & 0xffffu) < keep16) ? v0 * inv_keep : 0.0f;
+        z[1][r] = (v1 > 0.0f && (wd[r] >> 16) < keep16) ? v1 * inv_keep : 0.0f;
+    }
+}
+
+template <int H, int L>
+__global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
+{
+    constexpr int W = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H, NQ = H / 16, KS = H / 4;
+    __shared__ __attribute__((aligned(16))) float sAct[L][H * 16];  // H_j, [k / 4][16 rows][k % 4]
+    __shared__ __attribute__((aligned(16))) float sDz[H * 16];      // dZ_j of the layer being back-propagated, same order
+    __shared__ float sX[8 * 16];                                    // inputs [in][row] (row 7 = the bias column of ones)
+    __shared__ float sO[W * 16];                                    // per-wave partial outputs
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    float* out = a.partial + (size_t)tile * a.pstride;
+    const float* Wo = a.params + H * 8 + (L - 1) * CONN;
+
+    // A operands of one H x H product: row k of `src` is the contraction index, this wave's 32 columns 32 w + 2 j, + 1
+    auto fetch_w = [&](const float* __restrict__ src, float2 (&dst)[KS]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dst[4 * q + t] = *reinterpret_cast<const float2*>(src + (size_t)(16 * q + 4 * g + t) * H + 32 * w + 2 * j);
+    };
+    // acc[ub] += A (registers) x B (LDS image of the previous layer / of dZ)
+    auto product = [&](const float2 (&wa)[KS], const float* Bsrc, v4f16 (&acc)[2]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(Bsrc + (4 * q + g) * 64 + j * 4);
+            const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0] = mfma16(wa[4 * q + t].x, bv[t], acc[0]);
+                acc[1] = mfma16(wa[4 * q + t].y, bv[t], acc[1]);
+            }
+        }
+    };
+    // a lane's eight units of its row -> LDS in [k / 4][row][k % 4] order (two 16-byte stores)
+    auto put = [&](float* dst, const v4f16 (&v)[2]) {
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+            *reinterpret_cast<float4*>(dst + (8 * w + 2 * g + rh) * 64 + j * 4) =
+                make_float4(v[0][2 * rh], v[1][2 * rh], v[0][2 * rh + 1], v[1][2 * rh + 1]);
+    };
+    // sum over the tile's 16 rows (the lanes of a group of 16)
+    auto rowsum = [&](float x) {
+        x += __shfl_xor(x, 1, 64);
+        x += __shfl_xor(x, 2, 64);
+        x += __shfl_xor(x, 4, 64);
+        x += __shfl_xor(x, 8, 64);
+        return x;
+    };
+
+    float2 wbuf[L - 1][KS];  // connection c: first its transposed copy (forward), then the canonical matrix (dH)
+#pragma unroll
+    for (int c = 0; c < L - 1; ++c) fetch_w(a.wt + (size_t)c * H * H, wbuf[c]);
+
+    const int64_t row = (int64_t)tile * 16 + j;
+    const uint32_t drow = (a.drop_pos && a.keep16 < 65536u && row < a.nrows) ? a.drop_pos[row] : (uint32_t)row;
+    const bool live = row < a.nrows;
+    float xa = 0.0f, xb = 0.0f;  // inputs g and 4 + g of the lane's row
+    if (live) {
+        const float* xr = a.data + shuffle_index(a.shuf, (uint64_t)(a.row0 + row)) * 8;
+        xa = xr[g];
+        xb = xr[4 + g];
+    }
+    const float y = __shfl(xb, 48 + j, 64);  // column 7 is the target ...
+    if (g == 3) xb = 1.0f;                   // ... and its slot carries the bias input
+    if (w == 0) {
+        sX[g * 16 + j] = xa;
+        sX[(4 + g) * 16 + j] = xb;
+    }
+
+    // ---- layer 0: own 32 units x 8 inputs, k-steps s = 0, 1 <-> inputs 4 s + g
+    v4f16 hreg[L][2];
+    {
+        v4f16 acc[2];
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+            acc[ub] = v4f16{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* wr = a.params + (32 * w + 2 * j + ub) * 8 + g;
+            acc[ub] = mfma16(wr[0], xa, acc[ub]);
+            acc[ub] = mfma16(wr[4], xb, acc[ub]);
+        }
+        relu_dropout_q16(acc, drow, a.step, 0x100u + (uint32_t)(4 * w + g), a.keep16, a.inv_keep, a.k0, a.k1);
+        hreg[0][0] = acc[0];
+        hreg[0][1] = acc[1];
+        put(sAct[0], acc);
+    }
+    __syncthreads();
+
+    // ---- layers 1 .. L-1
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        const float* bj = a.params + H * 8 + (size_t)(l - 1) * CONN + H * H + 32 * w + 8 * g;
+        const float4 b0 = *reinterpret_cast<const float4*>(bj), b1 = *reinterpret_cast<const float4*>(bj + 4);
+        v4f16 acc[2] = {v4f16{b0.x, b0.z, b1.x, b1.z}, v4f16{b0.y, b0.w, b1.y, b1.w}};  // unit offset e = 2 r + ub
+        product(wbuf[l - 1], sAct[l - 1], acc);
+        fetch_w(a.params + H * 8 + (size_t)(l - 1) * CONN, wbuf[l - 1]);  // the same connection, canonical: for dH
+        relu_dropout_q16(acc, drow, a.step, 0x100u * (uint32_t)(l + 1) + (uint32_t)(4 * w + g), a.keep16, a.inv_keep,
+                         a.k0, a.k1);
+        hreg[l][0] = acc[0];
+        hreg[l][1] = acc[1];
+        put(sAct[l], acc);
+        __syncthreads();
+    }
+
+    // ---- output, loss, d(loss)/d(out): every wave ends with the same numbers
+    float wo[2][4];
+    {
+        const float4 w0 = *reinterpret_cast<const float4*>(Wo + 32 * w + 8 * g),
+                     w1 = *reinterpret_cast<const float4*>(Wo + 32 * w + 8 * g + 4);
+        wo[0][0] = w0.x; wo[1][0] = w0.y; wo[0][1] = w0.z; wo[1][1] = w0.w;
+        wo[0][2] = w1.x; wo[1][2] = w1.y; wo[0][3] = w1.z; wo[1][3] = w1.w;
+        float o = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o = __builtin_fmaf(wo[0][r], hreg[L - 1][0][r], o);
+            o = __builtin_fmaf(wo[1][r], hreg[L - 1][1][r], o);
+        }
+        o += __shfl_xor(o, 16, 64);
+        o += __shfl_xor(o, 32, 64);
+        if (g == 0) sO[w * 16 + j] = o;
+    }
+    __syncthreads();
+    float o = Wo[H];
+#pragma unroll
+    for (int ww = 0; ww < W; ++ww) o += sO[ww * 16 + j];
+    const float diff = live ? o - y : 0.0f;
+    const float dout = diff * a.two_over_b;
+    v4f16 dz[2];
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz[ub][r] = hreg[L - 1][ub][r] > 0.0f ? wo[ub][r] * dout * a.inv_keep : 0.0f;
+    // output-weight gradient of the lane group's eight units: sum over rows of dout * H_{L-1}
+    {
+        float gw[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gw[2 * r] = rowsum(hreg[L - 1][0][r] * dout);
+            gw[2 * r + 1] = rowsum(hreg[L - 1][1][r] * dout);
+        }
+        if (j == 0) {
+            float4* po = reinterpret_cast<float4*>(out + H * 8 + (L - 1) * CONN + 32 * w + 8 * g);
+            po[0] = make_float4(gw[0], gw[1], gw[2], gw[3]);
+            po[1] = make_float4(gw[4], gw[5], gw[6], gw[7]);
+        }
+    }
+
+#pragma unroll
+    for (int l = L - 1; l >= 1; --l) {
+        float* gWl = out + H * 8 + (size_t)(l - 1) * CONN;
+        put(sDz, dz);
+        {   // bias gradient: row sums of dZ_l
+            float gb[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gb[2 * r] = rowsum(dz[0][r]);
+                gb[2 * r + 1] = rowsum(dz[1][r]);
+            }
+            if (j == 0) {
+                float4* po = reinterpret_cast<float4*>(gWl + H * H + 32 * w + 8 * g);
+                po[0] = make_float4(gb[0], gb[1], gb[2], gb[3]);
+                po[1] = make_float4(gb[4], gb[5], gb[6], gb[7]);
+            }
+        }
+        __syncthreads();
+        // ---- gW_l rows = own units, all H columns: contraction over the 16 rows, k-step s <-> rows 4 s + g
+        {
+            v4f16 acc[2][NQ];
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                for (int kb = 0; kb < NQ; ++kb) acc[ub][kb] = v4f16{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                // A: dZ_l of units 32 w + 2 j, + 1 at row 4 s + g (here j is the MFMA's output-row index)
+                const float2 av = *reinterpret_cast<const float2*>(sDz + (8 * w + (j >> 1)) * 64 + (4 * s2 + g) * 4 + 2 * (j & 1));
+#pragma unroll
+                for (int kb = 0; kb < NQ; ++kb) {
+                    // B: H_{l-1} of unit 16 kb + j at row 4 s + g (here j is the output-column index)
+                    const float bv = sAct[l - 1][(4 * kb + (j >> 2)) * 64 + (4 * s2 + g) * 4 + (j & 3)];
+                    acc[0][kb] = mfma16(av.x, bv, acc[0][kb]);
+                    acc[1][kb] = mfma16(av.y, bv, acc[1][kb]);
+                }
+            }
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                for (int kb = 0; kb < NQ; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        gWl[(size_t)(32 * w + 2 * (4 * g + r) + ub) * H + 16 * kb + j] = acc[ub][kb][r];
+        }
+        // ---- dH_{l-1} of the own units = W_l^T dZ_l, then through the ReLU / dropout mask of H_{l-1}
+        {
+            v4f16 d[2] = {v4f16{0.0f, 0.0f, 0.0f, 0.0f}, v4f16{0.0f, 0.0f, 0.0f, 0.0f}};
+            product(wbuf[l - 1], sDz, d);
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz[ub][r] = hreg[l - 1][ub][r] > 0.0f ? d[ub][r] * a.inv_keep : 0.0f;
+        }
+        __syncthreads();  // every wave is done with sDz
+    }
+
+    // ---- gW1 (own units x 8 inputs, bias in column 7): one more contraction over the rows, columns = inputs
+    put(sDz, dz);
+    __syncthreads();
+    {
+        v4f16 acc[2] = {v4f16{0.0f, 0.0f, 0.0f, 0.0f}, v4f16{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const float2 av = *reinterpret_cast<const float2*>(sDz + (8 * w + (j >> 1)) * 64 + (4 * s2 + g) * 4 + 2 * (j & 1));
+            const float bv = j < 8 ? sX[j * 16 + 4 * s2 + g] : 0.0f;
+            acc[0] = mfma16(av.x, bv, acc[0]);
+            acc[1] = mfma16(av.y, bv, acc[1]);
+        }
+        if (j < 8) {
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(32 * w + 2 * (4 * g + r) + ub) * 8 + j] = acc[ub][r];
+        }
+    }
+    if (w == 0) {
+        float gbo = g == 0 ? dout : 0.0f, loss = g == 0 ? diff * diff : 0.0f;
+        gbo = rowsum(gbo);
+        loss = rowsum(loss);
+        if (lane == 0) {
+            out[NP - 1] = gbo;
+            out[NP] = loss;
+        }
+    }
+}
+
 // ---- many small networks trained side by side (the curve entry points: one net per curve point) ----------------
 // One table row per problem; blockIdx.y = problem, the step index within the epoch is a kernel argument.  A
 // workgroup builds its problem's argument block exactly as quad_steps() does on the host (same float conversions:
@@ -1961,7 +2241,8 @@ __global__ __launch_bounds__(256) void shard_step_off_kernel(const int64_t* __re
 // any batch), 0 = neither.
 // 1: workgroup kernel (64 units, large batches); 2: tile-per-wave kernel; 3: tile-per-workgroup kernel
 // (minibatches of at most kMlpMaxGroups tiles: the reference's batch of 256 rows is 8)
-int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
+// the kernel before the 16-row tiles existed -- what the side-by-side (batched) trainers still run
+static int mlp_train_kernel_choice32(int hidden, int layers, int64_t batch)
 {
     if (layers != 2 && layers != 3) return 0;
     const int64_t tiles = (batch + 31) / 32;
@@ -1970,6 +2251,17 @@ int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
     if (hidden == 128) return (quad && tiles <= kMlpMaxGroups) ? 3 : 2;
     if (hidden == 32 && layers == 2) return 3;  // the per-step ContNet of omc_contnet.hip: any number of tiles
     return 0;
+}
+
+int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
+{
+    const int c = mlp_train_kernel_choice32(hidden, layers, batch);
+    // 16-row tiles while a minibatch leaves most of the chip idle (kMlpQ16MaxRows rows = 64 workgroups): the reference's
+    // own min(256, R).  OMC_MLP_Q16=0 switches them off, =N moves the limit to N rows (A/B measurements).
+    static const int q16 = getenv("OMC_MLP_Q16") ? atoi(getenv("OMC_MLP_Q16")) : -1;
+    const int64_t lim = q16 < 0 ? kMlpQ16MaxRows : q16;
+    if (c == 3 && (hidden == 64 || hidden == 128) && batch <= lim) return 4;
+    return c;
 }
 
 int mlp_train_param_count(int hidden, int layers)
@@ -1983,6 +2275,7 @@ size_t mlp_partial_bytes(int hidden, int layers, int64_t batch)
 {
     const int choice = mlp_train_kernel_choice(hidden, layers, batch);
     if (choice == 1) return sizeof(float) * (size_t)kMlpMaxGroups * kMlpPartialStride3;
+    if (choice == 4) return sizeof(float) * (size_t)((batch + 15) / 16) * tile_pstride(hidden, layers);
     if (choice == 2 || choice == 3) {
         const int64_t tiles = (batch + 31) / 32, cap = tile_waves_max(hidden);
         // 32 units: one partial per tile however many (the kernel never accumulates across tiles)
@@ -2017,6 +2310,21 @@ __global__ __launch_bounds__(64) void mlp_mask_probe_kernel(int variant, int lay
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[mt][r] = 1.0f;
+        if (variant == 4) {  // 16-row tiles: lane (j, g) of wave w holds units 32 w + 8 g + 2 r + ub; here c <-> j, 16 rows per half-wave h
+#pragma unroll
+            for (int oct = 0; oct < H / 8; ++oct) {
+                v4f16 zz[2] = {v4f16{1.0f, 1.0f, 1.0f, 1.0f}, v4f16{1.0f, 1.0f, 1.0f, 1.0f}};
+                relu_dropout_q16(zz, key, step, 0x100u * (uint32_t)(j + 1) + (uint32_t)oct, keep16, inv_keep, k0, k1);
+                if (h == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[8 * oct + 2 * r] = zz[0][r] != 0.0f;
+                        o[8 * oct + 2 * r + 1] = zz[1][r] != 0.0f;
+                    }
+                }
+            }
+            continue;
+        }
         if (variant == 3) {
 #pragma unroll
             for (int w = 0; w < NT; ++w) {
@@ -2283,10 +2591,12 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
     return hipGetLastError();
 }
 
-// minibatches of at most kMlpMaxGroups tiles: one workgroup per tile (mlp_train_quad_kernel)
-template <int H, int L>
+// minibatches of at most kMlpMaxGroups tiles: one workgroup per tile (mlp_train_quad_kernel: 32-row tiles;
+// mlp_train_q16_kernel: 16-row tiles)
+template <int H, int L, bool Q16 = false>
 static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
 {
+    constexpr int kTileRows = Q16 ? 16 : 32;
     if (!t.wt_current) hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
     const Shuffle sh = plan_shuffle(t);
     int64_t step = t.first_step;
@@ -2303,7 +2613,7 @@ static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
         a.row0 = o;
         a.nrows = nb;
         a.shuf = sh;
-        a.ntiles = (int)((nb + 31) / 32);
+        a.ntiles = (int)((nb + kTileRows - 1) / kTileRows);
         a.pstride = tile_pstride(H, L);
         a.two_over_b = (float)(2.0 / (double)sp.global);
         a.drop_pos = t.drop_pos ? t.drop_pos + o : nullptr;
@@ -2312,7 +2622,11 @@ static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
         a.step = (uint32_t)step;
         a.k0 = (uint32_t)t.seed;
         a.k1 = (uint32_t)(t.seed >> 32);
-        if (a.ntiles > 0) hipLaunchKernelGGL((mlp_train_quad_kernel<H, L>), dim3(a.ntiles), dim3(H * 2), 0, st, a);
+        if constexpr (Q16) {
+            if (a.ntiles > 0) hipLaunchKernelGGL((mlp_train_q16_kernel<H, L>), dim3(a.ntiles), dim3(H * 2), 0, st, a);
+        } else {
+            if (a.ntiles > 0) hipLaunchKernelGGL((mlp_train_quad_kernel<H, L>), dim3(a.ntiles), dim3(H * 2), 0, st, a);
+        }
         MlpAdamArgs b;
         b.params = t.params;
         b.m = t.adam_m;
@@ -2357,6 +2671,10 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         if (t.hidden == 64) return t.layers == 2 ? quad_steps<64, 2>(st, t) : quad_steps<64, 3>(st, t);
         return t.layers == 2 ? quad_steps<128, 2>(st, t) : quad_steps<128, 3>(st, t);
     }
+    if (choice == 4) {
+        if (t.hidden == 64) return t.layers == 2 ? quad_steps<64, 2, true>(st, t) : quad_steps<64, 3, true>(st, t);
+        return t.layers == 2 ? quad_steps<128, 2, true>(st, t) : quad_steps<128, 3, true>(st, t);
+    }
     return hipErrorInvalidValue;
 }
 
@@ -2365,7 +2683,7 @@ size_t mlp_batch_table_bytes(int n) { return sizeof(MlpBatchProb) * (size_t)n; }
 
 bool mlp_batch_supported(int hidden, int layers, int64_t batch)
 {
-    return mlp_train_kernel_choice(hidden, layers, batch) == 3;  // the one-tile-per-workgroup trainer
+    return mlp_train_kernel_choice32(hidden, layers, batch) == 3;  // the one-tile-per-workgroup trainer (32-row tiles)
 }
 
 void mlp_batch_table_image(const MlpBatchJob* jobs, int n, int hidden, int layers, double beta1, double beta2, double eps,

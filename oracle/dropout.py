@@ -35,6 +35,9 @@ Definition (the build's; csrc/omc_mlp.hip `relu_dropout`, `relu_dropout_1`, and 
   stream B the second.
 * SINGLE generator (one tile per Philox block; the one-tile-per-workgroup trainer): ctr = (row, step, tag, 0x4d4c5134),
   one stream started at ((x ^ z) << 32) | ((y ^ w) | 1), same advance.
+* OCTET generator (the 16-row-tile trainer, `relu_dropout_q16`): no stretching -- one Philox block per eight consecutive
+  hidden units, ctr = (row, step, 0x100 * (layer + 1) + unit // 8, 0x4d4c5138); unit u takes half (u & 1) of word
+  (u & 7) >> 1 (low half first).
 * tag, row, step and the slot -> hidden-unit map per kernel: see `TRAIN_VARIANTS` and `apply_masks`.
 """
 from __future__ import annotations
@@ -47,10 +50,12 @@ PAIR_WORD = 0x4D4C5031
 SINGLE_WORD = 0x4D4C5134
 
 # trainer kernels (csrc/omc_mlp.hip mlp_train_kernel_choice): the library picks one per (hidden, batch)
-GROUP, TILE, QUAD = 1, 2, 3
+GROUP, TILE, QUAD, Q16 = 1, 2, 3, 4
 TRAIN_VARIANTS = {GROUP: "mlp_train_kernel<L> (64 units, > 32 tiles)",
                   TILE: "mlp_train_tile_kernel<H,L> (one tile per wave)",
-                  QUAD: "mlp_train_quad_kernel<H,L> (one tile per workgroup)"}
+                  QUAD: "mlp_train_quad_kernel<H,L> (one 32-row tile per workgroup)",
+                  Q16: "mlp_train_q16_kernel<H,L> (one 16-row tile per workgroup: the reference's minibatch of 256 rows)"}
+Q16_WORD = 0x4D4C5138
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -163,6 +168,11 @@ def train_bits(variant, hidden, layers, rows, step, seed):
                     for r in range(16):
                         b[:, w, _slot(r, h)] = bits[:, r]
             out[j] = _tiles_to_units(b, hidden, lambda tile, s: 32 * tile + s)
+        elif variant == Q16:      # one Philox block per eight consecutive units, 16 bits each, no stretching
+            for oct_ in range(hidden // 8):
+                wd = philox4x32_10(rows, step, base + oct_, Q16_WORD, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+                for e in range(8):
+                    out[j, :, 8 * oct_ + e] = (wd[e >> 1] >> np.uint32(16 * (e & 1))) & np.uint32(0xFFFF)
         else:
             raise ValueError("variant")
     return out

@@ -37,7 +37,7 @@ def test_keep_threshold_and_scale():
 
 
 @pytest.mark.parametrize("variant,hidden", [(dr.GROUP, 64), (dr.TILE, 64), (dr.TILE, 128), (dr.QUAD, 32), (dr.QUAD, 64),
-                                            (dr.QUAD, 128)])
+                                            (dr.QUAD, 128), (dr.Q16, 64), (dr.Q16, 128)])
 def test_every_unit_gets_its_own_draw(variant, hidden):
     """The 16-bit draws of one row: hidden * layers values from distinct (block, stream, advance, half) positions -- no
     two units of a layer share a draw (a shared draw shows up as equal 16-bit values far beyond the birthday rate)."""
@@ -62,7 +62,7 @@ def test_masks_are_bernoulli_and_independent():
         assert np.abs(a.mean(axis=(0, 1)) - q).max() < 6 * np.sqrt(q * (1 - q) / (3 * rows.size))  # per unit
         agree = q * q + (1 - q) * (1 - q)
         others = [dr.train_masks(dr.QUAD, 128, 3, rows, 2, 42, p), dr.train_masks(dr.QUAD, 128, 3, rows, 1, 43, p),
-                  dr.train_masks(dr.TILE, 128, 3, rows, 1, 42, p), a[[1, 2, 0]], a[:, ::-1], a[:, :, ::-1],
+                  dr.train_masks(dr.TILE, 128, 3, rows, 1, 42, p), dr.train_masks(dr.Q16, 128, 3, rows, 1, 42, p), a[[1, 2, 0]], a[:, ::-1], a[:, :, ::-1],
                   np.roll(a, 1, axis=2), np.roll(a, 4, axis=2), np.roll(a, 32, axis=2), np.roll(a, 1, axis=1)]
         for b in others:
             assert abs((a == b).mean() - agree) < 6 * np.sqrt(agree * (1 - agree) / a.size)

@@ -38,7 +38,7 @@ def env(ctx):
 
 # ---------------------------------------------------------------- 1. the masks themselves
 @pytest.mark.parametrize("variant,hidden", [(dr.GROUP, 64), (dr.TILE, 64), (dr.TILE, 128), (dr.QUAD, 32), (dr.QUAD, 64),
-                                            (dr.QUAD, 128)])
+                                            (dr.QUAD, 128), (dr.Q16, 64), (dr.Q16, 128)])
 @pytest.mark.parametrize("p_drop", [0.1, 0.5])
 def test_trainer_masks_on_the_device_equal_the_oracle(ctx, variant, hidden, p_drop):
     layers = 2 if hidden == 32 else 3
@@ -138,8 +138,9 @@ def _check_one_step(env, ctx, hidden, layers, rows, p_drop, variant, first_step=
 
 @pytest.mark.parametrize("p_drop", [0.1, 0.5])
 @pytest.mark.parametrize("hidden,layers,rows,variant", [
-    (64, 2, 32, dr.QUAD), (64, 2, 100, dr.QUAD), (64, 3, 1000, dr.QUAD), (64, 3, 1024, dr.QUAD),
-    (128, 3, 256, dr.QUAD), (128, 2, 1000, dr.QUAD), (128, 3, 4096, dr.QUAD), (128, 3, 8192, dr.QUAD),
+    (64, 2, 16, dr.Q16), (64, 2, 100, dr.Q16), (64, 3, 1000, dr.Q16), (64, 3, 1024, dr.Q16),
+    (128, 3, 1, dr.Q16), (128, 3, 17, dr.Q16), (128, 3, 256, dr.Q16), (128, 2, 1000, dr.Q16), (128, 2, 1024, dr.Q16),
+    (128, 3, 1025, dr.QUAD), (128, 3, 4096, dr.QUAD), (128, 2, 8192, dr.QUAD),
     (64, 2, 1025, dr.GROUP), (64, 2, 4096, dr.GROUP), (64, 3, 4096, dr.GROUP), (64, 2, 50_000, dr.GROUP),
     (64, 3, 100_000, dr.GROUP), (64, 2, 1 << 17, dr.GROUP),
     (128, 3, 8193, dr.TILE), (128, 2, 20_000, dr.TILE), (128, 3, 50_000, dr.TILE),
@@ -148,14 +149,14 @@ def test_masked_gradients_and_loss_match_autograd(env, ctx, hidden, layers, rows
     _check_one_step(env, ctx, hidden, layers, rows, p_drop, variant)
 
 
-@pytest.mark.parametrize("hidden,layers,rows,variant", [(128, 3, 256, dr.QUAD), (64, 2, 4096, dr.GROUP),
+@pytest.mark.parametrize("hidden,layers,rows,variant", [(128, 3, 256, dr.Q16), (128, 3, 2048, dr.QUAD), (64, 2, 4096, dr.GROUP),
                                                         (128, 3, 10_000, dr.TILE)])
 def test_a_later_optimizer_step_draws_its_own_masks(env, ctx, hidden, layers, rows, variant):
     """`step` counts over the whole run (first_step + k): step 22,000 of the reference's default call."""
     _check_one_step(env, ctx, hidden, layers, rows, 0.1, variant, first_step=21_999, seed=2 ** 61 + 12345)
 
 
-@pytest.mark.parametrize("hidden,layers,bs,variant", [(128, 3, 256, dr.QUAD), (64, 2, 2048, dr.GROUP)])
+@pytest.mark.parametrize("hidden,layers,bs,variant", [(128, 3, 256, dr.Q16), (128, 2, 2048, dr.QUAD), (64, 2, 2048, dr.GROUP)])
 def test_several_steps_track_torch_adam_under_the_same_masks(env, ctx, hidden, layers, bs, variant):
     """Ten optimizer steps of an epoch (masks of steps 1..10, rows in storage order) against torch.optim.Adam fed the
     masked losses: the weights stay together as in the dropout-free test (test_gpu_mlp.py), i.e. masks, 1 / keep and
@@ -186,8 +187,8 @@ def test_several_steps_track_torch_adam_under_the_same_masks(env, ctx, hidden, l
     assert float(diff.max()) <= 2.5e-3 and float(diff.mean()) <= 2e-5  # the dropout-free test's bounds
 
 
-@pytest.mark.parametrize("hidden,layers,batch,variant_local", [(64, 2, 8192, dr.GROUP), (128, 3, 256, dr.QUAD),
-                                                               (64, 2, 1500, dr.QUAD)])
+@pytest.mark.parametrize("hidden,layers,batch,variant_local", [(64, 2, 8192, dr.GROUP), (128, 3, 256, dr.Q16),
+                                                               (64, 2, 1500, dr.Q16), (128, 3, 4096, dr.QUAD)])
 def test_sharded_step_draws_the_masks_of_the_global_minibatch(env, ctx, hidden, layers, batch, variant_local):
     """One rank's part of a global minibatch (omc_mlp_train_epoch_sharded without a communicator = the sum of one
     rank): its rows carry their positions in the GLOBAL minibatch as dropout keys, the loss is scaled by the global
@@ -225,8 +226,8 @@ def test_sharded_step_draws_the_masks_of_the_global_minibatch(env, ctx, hidden, 
     assert np.abs(_flat_grads(torch, nnr, net).cpu().numpy() - gref).max() > 50 * 2e-5 * scale
 
 
-_TILE64_SCRIPT = r"""
-import sys
+_CHILD_SCRIPT = r"""
+import json, os, sys
 sys.path.insert(0, {root!r})
 import numpy as np, torch
 from options_model_amd import _ffi, nn_regressor as nnr
@@ -235,20 +236,28 @@ sys.path.insert(0, {root!r} + "/tests")
 import test_gpu_dropout as T
 ctx = _ffi.Context(0)
 env = (torch, nnr, torch.device("cuda", 0))
-for layers, rows, p in ((2, 100, 0.1), (3, 1000, 0.5), (2, 1024, 0.1)):
-    assert ctx.lib.omc_mlp_train_variant(64, layers, rows) == dr.TILE
-    T._check_one_step(env, ctx, 64, layers, rows, p, dr.TILE)
-print("tile64 ok")
+for hidden, layers, rows, p, variant in json.loads(os.environ["CASES"]):
+    assert ctx.lib.omc_mlp_train_variant(hidden, layers, rows) == variant, (hidden, layers, rows, variant)
+    T._check_one_step(env, ctx, hidden, layers, rows, p, variant)
+print("child ok")
 """
 
 
-def test_tile_per_wave_kernel_at_64_units_under_masks(env):
-    """mlp_train_tile_kernel<64, L> is what small minibatches ran before the one-tile-per-workgroup kernel existed; it
-    stays selectable (OMC_MLP_QUAD=0, read once per process) -- hence a child process (started, never exec'd into)."""
-    e = dict(os.environ, OMC_MLP_QUAD="0", PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, "-c", _TILE64_SCRIPT.format(root=ROOT)], env=e, capture_output=True, text=True,
+@pytest.mark.parametrize("knobs,cases", [
+    (dict(OMC_MLP_Q16="0"), [(64, 2, 100, 0.1, dr.QUAD), (64, 3, 1000, 0.5, dr.QUAD), (128, 3, 256, 0.1, dr.QUAD), (128, 2, 31, 0.5, dr.QUAD)]),
+    (dict(OMC_MLP_Q16="0", OMC_MLP_QUAD="0"), [(64, 2, 100, 0.1, dr.TILE), (64, 3, 1000, 0.5, dr.TILE), (64, 2, 1024, 0.1, dr.TILE),
+                                               (128, 3, 256, 0.1, dr.TILE)]),
+    (dict(OMC_MLP_Q16="4096"), [(128, 3, 4096, 0.1, dr.Q16), (128, 2, 2000, 0.5, dr.Q16)]),
+])
+def test_kernels_behind_the_environment_switches_under_masks(env, knobs, cases):
+    """Small minibatches ran the 32-row one-tile-per-workgroup kernel before the 16-row tiles existed, and the
+    one-tile-per-wave kernel before that; both stay selectable (OMC_MLP_Q16 / OMC_MLP_QUAD, read once per process) and
+    the batched trainers still run the 32-row kernel -- hence child processes (started, never exec'd into)."""
+    import json
+    e = dict(os.environ, PYTHONPATH=ROOT, CASES=json.dumps(cases), **knobs)
+    r = subprocess.run([sys.executable, "-c", _CHILD_SCRIPT.format(root=ROOT)], env=e, capture_output=True, text=True,
                        timeout=600)
-    assert r.returncode == 0 and "tile64 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 # ---------------------------------------------------------------- 3. pass 2 with dropout on
@@ -321,7 +330,8 @@ def test_shard_keys_give_a_shard_the_masks_of_the_unsharded_matrix(env, golden):
     hidden = int(hidden)
     S = torch.from_numpy(nn[f"{tag}_S"]).float().cuda().contiguous()
     N, M = S.shape[0] - 1, S.shape[1]
-    P, m = M // 2, 1000
+    P, m = M // 2, 200
+    assert m <= P  # (the fixture holds 1,024 paths: columns [0, 200) and [512, 712))
     net = _load_net(torch, nn, tag, hidden)
     fm, fs = nn[f"{tag}_feat_mean"], nn[f"{tag}_feat_std"]
     ym, ysd = (float(v) for v in nn[f"{tag}_Y_mean_std"])
@@ -331,6 +341,7 @@ def test_shard_keys_give_a_shard_the_masks_of_the_unsharded_matrix(env, golden):
     whole = c.lsm_apply_mlp(S.data_ptr(), S.stride(0), M, N, K, r, T, True, params.data_ptr(), fm, fs, ym, ysd, 0.1, 123,
                             want_state=True, hidden=hidden, layers=3)
     cols = np.concatenate([np.arange(m), np.arange(P, P + m)])
+    assert cols.max() < M
     Sp = S[:, torch.from_numpy(cols).to(dev)].contiguous()
     torch.cuda.synchronize()
     part = c.lsm_apply_mlp(Sp.data_ptr(), Sp.stride(0), 2 * m, N, K, r, T, True, params.data_ptr(), fm, fs, ym, ysd, 0.1,

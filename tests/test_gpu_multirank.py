@@ -207,6 +207,73 @@ def test_direct_exchange_bitwise_equals_collective_in_process(standin, tmp_path)
     assert got[0]["status"] == [True, 2, 0]
 
 
+_TIGHT = r"""
+import json, os, sys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if rank == 1:
+    os.environ["OMC_SEQ_STEP_BYTES"] = "1"       # this rank's card "has no room": its own K comes out as 1
+sys.path.insert(0, %r)
+from options_model_amd import _ffi
+kw = dict(semantics="reference", n_steps=30, seed=9)
+if os.environ.get("TIGHT_TRANSPORT") == "hook":
+    import torch, torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from options_model_amd.dist import ShardedPricer
+    sp = ShardedPricer(0)
+else:
+    from options_model_amd.dist import RcclPricer
+    sp = RcclPricer(0, rank, world)
+p1 = _ffi.make_params(n_paths=120_000, n_steps=30, semantics="reference", seed=9)
+local_width = sp.ctx.lib.omc_seq_step_width(sp.ctx.handle, (type(p1) * 5)(*[p1] * 5), 5)
+seq = sp.price_american_seq(120_000 * world, [2, 3, 4, 5, 6], **kw)
+if os.environ.get("TIGHT_TRANSPORT") != "hook":
+    assert sp.enable_p2p()
+    seq_p2p = sp.price_american_seq(120_000 * world, [2, 3, 4, 5, 6], **kw)
+else:
+    seq_p2p = seq
+one = [sp.price_american(120_000 * world, stream=s, **kw) for s in (2, 3, 4, 5, 6)]
+keys = ("price", "sumsq", "n_exercised", "sum_nitm")
+same = all(a[k] == b[k] == c[k] for a, b, c in zip(seq, one, seq_p2p) for k in keys)
+print("RESULT" + str(rank) + " " + json.dumps(dict(same=same, width=local_width, prices=[r["price"] for r in seq])))
+sp.close()
+"""
+
+
+@pytest.mark.parametrize("transport", ["comm", "hook"])
+def test_a_memory_tight_rank_votes_the_whole_job_down(ctx, standin, tmp_path, transport):
+    """the number of pricings per launch is bounded by each rank's free memory, so it is
+    rank-dependent.  Rank 1 here has a budget of one byte (its own estimate: 1 pricing per launch), rank 0 plenty
+    (5).  Every rank votes -- also the one whose K is 1 -- through the context's generic all-reduce, native
+    communicator or hook alike, and the job runs at the smallest K: no rank skips a collective its peer enters (the
+    hang this test used to be), the per-step collectives carry the same 8K doubles everywhere, the direct exchange the
+    same K jobs, and the results are the bits of one pricing after the other."""
+    from options_model_amd import _ffi
+    script = tmp_path / "tight.py"
+    script.write_text(_TIGHT % ROOT)
+    port = 29800 + os.getpid() % 90 + (7 if transport == "hook" else 0)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMC_RCCL_LIB=standin, OMC_RDZV_NONCE=f"tight{transport}{os.getpid()}",
+                   TIGHT_TRANSPORT=transport)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    try:
+        outs = [p.communicate(timeout=200) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    got = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2500:]
+        got.append(json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT")][0].split(" ", 1)[1]))
+    assert got[0]["same"] and got[1]["same"] and got[0]["prices"] == got[1]["prices"]
+    assert got[0]["width"] == 5 and got[1]["width"] == 1          # the ranks' own estimates DO differ
+    ref = ctx.price_american(_ffi.make_params(semantics="reference", n_paths=240_000, n_steps=30, seed=9, stream=2))
+    assert got[0]["prices"][0] == pytest.approx(ref["price"], rel=1e-12)
+
+
 def test_the_drivers_launch_form_torchrun_native_communicator(ctx, standin):
     """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...`: the ranks are torchrun's children (common parent = its agent, which names

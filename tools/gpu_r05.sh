@@ -25,6 +25,22 @@ dropout)
   prof default_pricer "$R/tools/prof_default_pricer.py" || exit 1
   cat gpurun_out/${TAG}_default_pricer_under_rocprof.json
   ;;
+q16)
+  timeout -k 10 900 python -m pytest tests/test_gpu_dropout.py tests/test_gpu_mlp.py -x -q --durations=8 > gpurun_out/${TAG}_q16_tests.log 2>&1; rc=$?
+  tail -15 gpurun_out/${TAG}_q16_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
+  [ $rc -eq 0 ] || exit 1
+  for Q in 0 -1; do
+    for B in 256 512 1024 2048; do
+      OMC_MLP_Q16=$Q timeout -k 10 200 python tools/bench_mlp.py 225057 $B 4 0.1 3 128 >> gpurun_out/${TAG}_q16_sweep.jsonl 2>> gpurun_out/${TAG}_q16_sweep.err; rc=$?
+      ok $rc || exit 1
+    done
+    OMC_MLP_Q16=$Q timeout -k 10 200 python tools/bench_mlp.py 225057 256 4 0.1 2 64 >> gpurun_out/${TAG}_q16_sweep.jsonl 2>> gpurun_out/${TAG}_q16_sweep.err
+  done
+  cat gpurun_out/${TAG}_q16_sweep.jsonl
+  timeout -k 10 300 python tools/time_default_pricer.py > gpurun_out/${TAG}_default_pricer.txt 2>&1; rc=$?
+  cat gpurun_out/${TAG}_default_pricer.txt; ok $rc || exit 1
+  prof default_pricer "$R/tools/prof_default_pricer.py" || exit 1
+  ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
   tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
