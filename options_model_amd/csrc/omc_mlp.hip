@@ -27,6 +27,18 @@ namespace omc {
 
 namespace {
 
+#ifndef OMC_Q16_EXP
+#define OMC_Q16_EXP 0  // experiment builds only (tools/gpu_r05.sh q16exp): 1 no gradient stores, 2 no weight fetches, 4 no MFMA, 8 no row sums, 64 time stamps
+#endif
+#if (OMC_Q16_EXP & 64)
+// one optimizer step on the 100 MHz wall clock: phases of tile 0's wave 0, the Adam kernel's first and last workgroup,
+// the next step's entry (read back by omc_debug_q16_stamps; experiment builds only)
+__device__ unsigned long long g_q16_stamps[32];
+__device__ int g_q16_flag = 0;
+#define Q16_STAMP(i) do { if (stamp) g_q16_stamps[i] = wall_clock64(); } while (0)
+#else
+#define Q16_STAMP(i) do { } while (0)
+#endif
 constexpr int kH = 64;                 // hidden width
 constexpr int kLdW1 = 9, kLdW2 = 65;   // LDS leading dimensions (odd: conflict-free column walks)
 // Staging patches are [unit][32 rows] without padding; the row index is XOR-swizzled per unit in
@@ -529,6 +541,13 @@ __device__ __forceinline__ void mlp_adam_body(const MlpAdamArgs& a)
     __shared__ float red[16][17];
     const int j = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int p = blockIdx.x * 16 + j;
+    // the parameter and its moments travel together with the partials (one memory latency per launch, not two)
+    float w0 = 0.0f, m0 = 0.0f, v0 = 0.0f;
+    if (slice == 0 && p < a.nparams) {
+        w0 = a.params[p];
+        m0 = a.m[p];
+        v0 = a.v[p];
+    }
     float g = 0.0f;
     if (p <= a.nparams) {
 #pragma unroll 16
@@ -544,10 +563,9 @@ __device__ __forceinline__ void mlp_adam_body(const MlpAdamArgs& a)
         *a.loss_acc += (double)g * (double)a.inv_b;
         return;
     }
-    const float w0 = a.params[p];
     g = __builtin_fmaf(a.wd, w0, g);
-    const float m = __builtin_fmaf(a.beta1, a.m[p], (1.0f - a.beta1) * g);
-    const float v = __builtin_fmaf(a.beta2, a.v[p], (1.0f - a.beta2) * g * g);
+    const float m = __builtin_fmaf(a.beta1, m0, (1.0f - a.beta1) * g);
+    const float v = __builtin_fmaf(a.beta2, v0, (1.0f - a.beta2) * g * g);
     a.m[p] = m;
     a.v[p] = v;
     const float denom = __builtin_amdgcn_sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
@@ -604,7 +622,22 @@ __device__ __forceinline__ void mlp_adam_body_flat(const MlpAdamArgs& a, const i
     }
 }
 
-__global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a) { mlp_adam_body(a); }
+__global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a)
+{
+#if (OMC_Q16_EXP & 64)
+    const bool stamp = threadIdx.x == 0 && g_q16_flag == 1 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    const int slot = blockIdx.x == 0 ? 16 : 18;
+    Q16_STAMP(slot);
+    mlp_adam_body(a);
+    if (stamp) {
+        __builtin_amdgcn_s_waitcnt(0);
+        g_q16_stamps[slot + 1] = wall_clock64();
+        if (blockIdx.x == gridDim.x - 1) g_q16_flag = 2;
+    }
+#else
+    mlp_adam_body(a);
+#endif
+}
 
 // Sharded training.  (1) this rank's gradient sums of the step, partials added in mlp_adam_body's order, as doubles
 // (the loss sum rides in slot nparams) -> (2) the host enqueues the all-reduce over the ranks -> (3) Adam from the
@@ -1367,6 +1400,10 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_kernel(MlpQuadArgs a)
 typedef float v4f16 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4f16 mfma16(float a, float b, v4f16 c)
 {
+    if constexpr ((OMC_Q16_EXP & 4) != 0) {
+        c[0] = __builtin_fmaf(a, b, c[0]);
+        return c;
+    }
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
@@ -1405,14 +1442,27 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
     if (tile >= a.ntiles) return;
     float* out = a.partial + (size_t)tile * a.pstride;
     const float* Wo = a.params + H * 8 + (L - 1) * CONN;
+#if (OMC_Q16_EXP & 64)
+    const bool stamp = tile == 0 && tid == 0 && a.step == 2000u;
+    if (tile == 0 && tid == 0 && g_q16_flag == 2) {
+        g_q16_stamps[24] = wall_clock64();
+        g_q16_flag = 3;
+    }
+    Q16_STAMP(0);
+#endif
 
     // A operands of one H x H product: row k of `src` is the contraction index, this wave's 32 columns 32 w + 2 j, + 1
     auto fetch_w = [&](const float* __restrict__ src, float2 (&dst)[KS]) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                if constexpr ((OMC_Q16_EXP & 2) != 0) {
+                    dst[4 * q + t] = make_float2(1e-3f * (float)(q + t + lane), -1e-3f * (float)(q - t));
+                    continue;
+                }
                 dst[4 * q + t] = *reinterpret_cast<const float2*>(src + (size_t)(16 * q + 4 * g + t) * H + 32 * w + 2 * j);
+            }
     };
     // acc[ub] += A (registers) x B (LDS image of the previous layer / of dZ)
     auto product = [&](const float2 (&wa)[KS], const float* Bsrc, v4f16 (&acc)[2]) {
@@ -1434,21 +1484,14 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
             *reinterpret_cast<float4*>(dst + (8 * w + 2 * g + rh) * 64 + j * 4) =
                 make_float4(v[0][2 * rh], v[1][2 * rh], v[0][2 * rh + 1], v[1][2 * rh + 1]);
     };
-    // sum over the tile's 16 rows (the lanes of a group of 16)
-    auto rowsum = [&](float x) {
-        x += __shfl_xor(x, 1, 64);
-        x += __shfl_xor(x, 2, 64);
-        x += __shfl_xor(x, 4, 64);
-        x += __shfl_xor(x, 8, 64);
-        return x;
+    // units 32 w + 2 j, + 1 of an LDS image at row 4 s + g: the operand of the products that contract over the rows
+    auto own_pair = [&](const float* src, int s2) {
+        return *reinterpret_cast<const float2*>(src + (8 * w + (j >> 1)) * 64 + (4 * s2 + g) * 4 + 2 * (j & 1));
     };
 
-    float2 wbuf[L - 1][KS];  // connection c: first its transposed copy (forward), then the canonical matrix (dH)
-#pragma unroll
-    for (int c = 0; c < L - 1; ++c) fetch_w(a.wt + (size_t)c * H * H, wbuf[c]);
-
+    // ---- every small load first, then the big ones: loads return in order, and each of these would otherwise expose
+    // one L2-miss latency on the step's critical path (the parameters were just rewritten by the Adam kernel)
     const int64_t row = (int64_t)tile * 16 + j;
-    const uint32_t drow = (a.drop_pos && a.keep16 < 65536u && row < a.nrows) ? a.drop_pos[row] : (uint32_t)row;
     const bool live = row < a.nrows;
     float xa = 0.0f, xb = 0.0f;  // inputs g and 4 + g of the lane's row
     if (live) {
@@ -1456,6 +1499,29 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
         xa = xr[g];
         xb = xr[4 + g];
     }
+    const uint32_t drow = (a.drop_pos && a.keep16 < 65536u && live) ? a.drop_pos[row] : (uint32_t)row;
+    float w1v[2][2];  // layer-0 weights of units 32 w + 2 j + ub, inputs g and 4 + g
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub) {
+        const float* wr = a.params + (32 * w + 2 * j + ub) * 8 + g;
+        w1v[ub][0] = wr[0];
+        w1v[ub][1] = wr[4];
+    }
+    float4 bias[L > 1 ? L - 1 : 1][2];  // biases of the lane's eight units 32 w + 8 g .. + 7
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        const float* bj = a.params + H * 8 + (size_t)(l - 1) * CONN + H * H + 32 * w + 8 * g;
+        bias[l - 1][0] = *reinterpret_cast<const float4*>(bj);
+        bias[l - 1][1] = *reinterpret_cast<const float4*>(bj + 4);
+    }
+    const float4 wo0 = *reinterpret_cast<const float4*>(Wo + 32 * w + 8 * g),
+                 wo1 = *reinterpret_cast<const float4*>(Wo + 32 * w + 8 * g + 4);
+    const float bo = Wo[H];
+
+    float2 wbuf[L - 1][KS];  // connection c: first its transposed copy (forward), then the canonical matrix (dH)
+#pragma unroll
+    for (int c = 0; c < L - 1; ++c) fetch_w(a.wt + (size_t)c * H * H, wbuf[c]);
+
     const float y = __shfl(xb, 48 + j, 64);  // column 7 is the target ...
     if (g == 3) xb = 1.0f;                   // ... and its slot carries the bias input
     if (w == 0) {
@@ -1470,9 +1536,8 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
 #pragma unroll
         for (int ub = 0; ub < 2; ++ub) {
             acc[ub] = v4f16{0.0f, 0.0f, 0.0f, 0.0f};
-            const float* wr = a.params + (32 * w + 2 * j + ub) * 8 + g;
-            acc[ub] = mfma16(wr[0], xa, acc[ub]);
-            acc[ub] = mfma16(wr[4], xb, acc[ub]);
+            acc[ub] = mfma16(w1v[ub][0], xa, acc[ub]);
+            acc[ub] = mfma16(w1v[ub][1], xb, acc[ub]);
         }
         relu_dropout_q16(acc, drow, a.step, 0x100u + (uint32_t)(4 * w + g), a.keep16, a.inv_keep, a.k0, a.k1);
         hreg[0][0] = acc[0];
@@ -1480,12 +1545,12 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
         put(sAct[0], acc);
     }
     __syncthreads();
+    Q16_STAMP(1);
 
     // ---- layers 1 .. L-1
 #pragma unroll
     for (int l = 1; l < L; ++l) {
-        const float* bj = a.params + H * 8 + (size_t)(l - 1) * CONN + H * H + 32 * w + 8 * g;
-        const float4 b0 = *reinterpret_cast<const float4*>(bj), b1 = *reinterpret_cast<const float4*>(bj + 4);
+        const float4 b0 = bias[l - 1][0], b1 = bias[l - 1][1];
         v4f16 acc[2] = {v4f16{b0.x, b0.z, b1.x, b1.z}, v4f16{b0.y, b0.w, b1.y, b1.w}};  // unit offset e = 2 r + ub
         product(wbuf[l - 1], sAct[l - 1], acc);
         fetch_w(a.params + H * 8 + (size_t)(l - 1) * CONN, wbuf[l - 1]);  // the same connection, canonical: for dH
@@ -1495,15 +1560,12 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
         hreg[l][1] = acc[1];
         put(sAct[l], acc);
         __syncthreads();
+        Q16_STAMP(1 + l);
     }
 
     // ---- output, loss, d(loss)/d(out): every wave ends with the same numbers
-    float wo[2][4];
+    const float wo[2][4] = {{wo0.x, wo0.z, wo1.x, wo1.z}, {wo0.y, wo0.w, wo1.y, wo1.w}};  // wo[ub][r] <-> unit offset 2 r + ub
     {
-        const float4 w0 = *reinterpret_cast<const float4*>(Wo + 32 * w + 8 * g),
-                     w1 = *reinterpret_cast<const float4*>(Wo + 32 * w + 8 * g + 4);
-        wo[0][0] = w0.x; wo[1][0] = w0.y; wo[0][1] = w0.z; wo[1][1] = w0.w;
-        wo[0][2] = w1.x; wo[1][2] = w1.y; wo[0][3] = w1.z; wo[1][3] = w1.w;
         float o = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1515,7 +1577,7 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
         if (g == 0) sO[w * 16 + j] = o;
     }
     __syncthreads();
-    float o = Wo[H];
+    float o = bo;
 #pragma unroll
     for (int ww = 0; ww < W; ++ww) o += sO[ww * 16 + j];
     const float diff = live ? o - y : 0.0f;
@@ -1525,66 +1587,67 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
     for (int ub = 0; ub < 2; ++ub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dz[ub][r] = hreg[L - 1][ub][r] > 0.0f ? wo[ub][r] * dout * a.inv_keep : 0.0f;
-    // output-weight gradient of the lane group's eight units: sum over rows of dout * H_{L-1}
+    // output-weight gradient of the own units: sum over rows of dout * H_{L-1} as one more contraction over the rows
+    // (A = dout of row 4 s + g for every output row, B = H_{L-1} of unit 32 w + 2 n + ub): every output row holds the sum
     {
-        float gw[8];
+        v4f16 acc[2] = {v4f16{0.0f, 0.0f, 0.0f, 0.0f}, v4f16{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            gw[2 * r] = rowsum(hreg[L - 1][0][r] * dout);
-            gw[2 * r + 1] = rowsum(hreg[L - 1][1][r] * dout);
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const float dv = __shfl(dout, 4 * s2 + g, 64);  // lanes 0 .. 15 hold the rows' values
+            const float2 hv = own_pair(sAct[L - 1], s2);
+            acc[0] = mfma16(dv, hv.x, acc[0]);
+            acc[1] = mfma16(dv, hv.y, acc[1]);
         }
-        if (j == 0) {
-            float4* po = reinterpret_cast<float4*>(out + H * 8 + (L - 1) * CONN + 32 * w + 8 * g);
-            po[0] = make_float4(gw[0], gw[1], gw[2], gw[3]);
-            po[1] = make_float4(gw[4], gw[5], gw[6], gw[7]);
-        }
+        if (g == 0) *reinterpret_cast<float2*>(out + H * 8 + (L - 1) * CONN + 32 * w + 2 * j) = make_float2(acc[0][0], acc[1][0]);
     }
 
+    Q16_STAMP(5);
 #pragma unroll
     for (int l = L - 1; l >= 1; --l) {
         float* gWl = out + H * 8 + (size_t)(l - 1) * CONN;
         put(sDz, dz);
-        {   // bias gradient: row sums of dZ_l
-            float gb[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                gb[2 * r] = rowsum(dz[0][r]);
-                gb[2 * r + 1] = rowsum(dz[1][r]);
-            }
-            if (j == 0) {
-                float4* po = reinterpret_cast<float4*>(gWl + H * H + 32 * w + 8 * g);
-                po[0] = make_float4(gb[0], gb[1], gb[2], gb[3]);
-                po[1] = make_float4(gb[4], gb[5], gb[6], gb[7]);
-            }
-        }
         __syncthreads();
-        // ---- gW_l rows = own units, all H columns: contraction over the 16 rows, k-step s <-> rows 4 s + g
+        // ---- gW_l, transposed product: rows of the MFMA <-> columns k of gW_l (A = H_{l-1} of unit 16 kb + j), columns
+        // <-> own units i = 32 w + 2 n + ub (B = dZ_l); contraction over the 16 rows, k-step s <-> rows 4 s + g.  A lane's
+        // four registers are gW_l[i][16 kb + 4 g .. + 3]: one 16-byte store.  Block NQ has A = 1: the bias gradient.
         {
-            v4f16 acc[2][NQ];
+            v4f16 acc[2][NQ + 1];
 #pragma unroll
             for (int ub = 0; ub < 2; ++ub)
 #pragma unroll
-                for (int kb = 0; kb < NQ; ++kb) acc[ub][kb] = v4f16{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int kb = 0; kb <= NQ; ++kb) acc[ub][kb] = v4f16{0.0f, 0.0f, 0.0f, 0.0f};
+            // every LDS operand of the product is requested before the first MFMA (left to itself hipcc puts each
+            // ds_read directly in front of the pair of MFMAs that uses it: 32 exposed LDS latencies, 2.7 us per layer)
+            float2 dv[4];
+            float hv[4][NQ];
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                // A: dZ_l of units 32 w + 2 j, + 1 at row 4 s + g (here j is the MFMA's output-row index)
-                const float2 av = *reinterpret_cast<const float2*>(sDz + (8 * w + (j >> 1)) * 64 + (4 * s2 + g) * 4 + 2 * (j & 1));
+                dv[s2] = own_pair(sDz, s2);
+#pragma unroll
+                for (int kb = 0; kb < NQ; ++kb) hv[s2][kb] = sAct[l - 1][(4 * kb + (j >> 2)) * 64 + (4 * s2 + g) * 4 + (j & 3)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
 #pragma unroll
                 for (int kb = 0; kb < NQ; ++kb) {
-                    // B: H_{l-1} of unit 16 kb + j at row 4 s + g (here j is the output-column index)
-                    const float bv = sAct[l - 1][(4 * kb + (j >> 2)) * 64 + (4 * s2 + g) * 4 + (j & 3)];
-                    acc[0][kb] = mfma16(av.x, bv, acc[0][kb]);
-                    acc[1][kb] = mfma16(av.y, bv, acc[1][kb]);
+                    acc[0][kb] = mfma16(hv[s2][kb], dv[s2].x, acc[0][kb]);
+                    acc[1][kb] = mfma16(hv[s2][kb], dv[s2].y, acc[1][kb]);
                 }
+                acc[0][NQ] = mfma16(1.0f, dv[s2].x, acc[0][NQ]);
+                acc[1][NQ] = mfma16(1.0f, dv[s2].y, acc[1][NQ]);
             }
+            if ((OMC_Q16_EXP & 1) == 0 || a.two_over_b == 123.0f) {
 #pragma unroll
-            for (int ub = 0; ub < 2; ++ub)
+                for (int ub = 0; ub < 2; ++ub)
 #pragma unroll
-                for (int kb = 0; kb < NQ; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        gWl[(size_t)(32 * w + 2 * (4 * g + r) + ub) * H + 16 * kb + j] = acc[ub][kb][r];
+                    for (int kb = 0; kb < NQ; ++kb)
+                        *reinterpret_cast<float4*>(gWl + (size_t)(32 * w + 2 * j + ub) * H + 16 * kb + 4 * g) =
+                            make_float4(acc[ub][kb][0], acc[ub][kb][1], acc[ub][kb][2], acc[ub][kb][3]);
+            }
+            if (g == 0) *reinterpret_cast<float2*>(gWl + H * H + 32 * w + 2 * j) = make_float2(acc[0][NQ][0], acc[1][NQ][0]);
         }
+        Q16_STAMP(6 + 2 * (L - 1 - l));
         // ---- dH_{l-1} of the own units = W_l^T dZ_l, then through the ReLU / dropout mask of H_{l-1}
         {
             v4f16 d[2] = {v4f16{0.0f, 0.0f, 0.0f, 0.0f}, v4f16{0.0f, 0.0f, 0.0f, 0.0f}};
@@ -1595,36 +1658,47 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
                 for (int r = 0; r < 4; ++r) dz[ub][r] = hreg[l - 1][ub][r] > 0.0f ? d[ub][r] * a.inv_keep : 0.0f;
         }
         __syncthreads();  // every wave is done with sDz
+        Q16_STAMP(7 + 2 * (L - 1 - l));
     }
 
-    // ---- gW1 (own units x 8 inputs, bias in column 7): one more contraction over the rows, columns = inputs
+    // ---- gW1 (own units x 8 inputs, bias in column 7): the same transposed contraction, MFMA rows = inputs
     put(sDz, dz);
     __syncthreads();
     {
         v4f16 acc[2] = {v4f16{0.0f, 0.0f, 0.0f, 0.0f}, v4f16{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
-            const float2 av = *reinterpret_cast<const float2*>(sDz + (8 * w + (j >> 1)) * 64 + (4 * s2 + g) * 4 + 2 * (j & 1));
-            const float bv = j < 8 ? sX[j * 16 + 4 * s2 + g] : 0.0f;
-            acc[0] = mfma16(av.x, bv, acc[0]);
-            acc[1] = mfma16(av.y, bv, acc[1]);
+            const float2 dv = own_pair(sDz, s2);
+            const float xv = j < 8 ? sX[j * 16 + 4 * s2 + g] : 0.0f;
+            acc[0] = mfma16(xv, dv.x, acc[0]);
+            acc[1] = mfma16(xv, dv.y, acc[1]);
         }
-        if (j < 8) {
+        if (g < 2) {  // registers = inputs 4 g .. 4 g + 3 of unit 32 w + 2 j + ub
 #pragma unroll
             for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) out[(32 * w + 2 * (4 * g + r) + ub) * 8 + j] = acc[ub][r];
+                *reinterpret_cast<float4*>(out + (32 * w + 2 * j + ub) * 8 + 4 * g) =
+                    make_float4(acc[ub][0], acc[ub][1], acc[ub][2], acc[ub][3]);
         }
     }
     if (w == 0) {
         float gbo = g == 0 ? dout : 0.0f, loss = g == 0 ? diff * diff : 0.0f;
-        gbo = rowsum(gbo);
-        loss = rowsum(loss);
+#pragma unroll
+        for (int mk = 1; mk < 16; mk <<= 1) {
+            gbo += __shfl_xor(gbo, mk, 64);
+            loss += __shfl_xor(loss, mk, 64);
+        }
         if (lane == 0) {
             out[NP - 1] = gbo;
             out[NP] = loss;
         }
     }
+#if (OMC_Q16_EXP & 64)
+    if (stamp) {
+        __builtin_amdgcn_s_waitcnt(0);  // the wave's stores have been acknowledged
+        g_q16_stamps[12] = wall_clock64();
+        g_q16_flag = 1;
+    }
+#endif
 }
 
 // ---- many small networks trained side by side (the curve entry points: one net per curve point) ----------------
@@ -2376,6 +2450,16 @@ hipError_t mlp_dropout_masks(hipStream_t st, int variant, int hidden, int layers
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+
+#if (OMC_Q16_EXP & 64)
+}  // namespace omc
+extern "C" int omc_debug_q16_stamps(unsigned long long* out32)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(omc::g_q16_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 2;
+}
+namespace omc {
+#endif
 
 hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out)
 {
