@@ -46,6 +46,7 @@ CONFIGS = {  # BASELINE.json configs[1..3]
     "c3x1": dict(model="gbm", paths_per_gpu=64_000_000),  # ALL of configs[2] on one GPU (65 GB of paths)
     "c4": dict(model="heston", paths_per_gpu=4_000_000),
     "c5": dict(model="gbm", paths_per_gpu=1_000_000),  # configs[4]: the NN regressor (2 x 64): its own flow, bench_c5()
+    "c1nn": dict(model="gbm", paths_per_gpu=10_000),   # configs[0] as the reference itself runs it: its default call, bench_c1nn()
 }
 MARKET = dict(S0=100.0, K=100.0, r=0.05, sigma=0.2, T=1.0)
 HESTON = dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7)
@@ -178,6 +179,68 @@ def bench_c5(a) -> int:
     return 0
 
 
+def bench_c1nn(a) -> int:
+    """BASELINE configs[0] the way the reference runs it -- its DEFAULT call: AdvancedOptionPricer(K, r, sigma, 'put')
+    .price_american_enhanced_lsm(100, 1, 10000, 50) with reference arguments (options_model_3.py:340-358, 565-613:
+    SingleLSMNet 3 x 128, minibatch min(256, R), <= 25 epochs, Adam, dropout 0.1 in training AND in pass 2), through the
+    drop-in class.  A step is one whole pricing (paths, rows, ~22,000 optimizer steps, pass 2).  Dominant kernel: the
+    16-row-tile trainer; its roofline is the float32 matrix-core peak, and the fraction is tiny BY CONSTRUCTION -- a
+    256-row minibatch is 16 tiles on a 256-CU chip and every step waits for two kernel boundaries and one round of
+    parameter fetches (profiles/r05_default_call_timeline.txt holds the measured timeline of a step)."""
+    import torch
+    from options_model_amd import AdvancedOptionPricer, RNGManager
+    M, N = a.paths_per_gpu or CONFIGS["c1nn"]["paths_per_gpu"], (50 if a.n_steps == 252 else a.n_steps)
+    steps, warm = max(1, min(a.steps, 10)), max(1, min(a.warmup, 3))
+
+    def one(seed):
+        q = AdvancedOptionPricer(MARKET["K"], MARKET["r"], MARKET["sigma"], "put", RNGManager(seed))
+        price = q.price_american_enhanced_lsm(MARKET["S0"], MARKET["T"], M, N)
+        return price, q.last_result
+
+    for i in range(warm):
+        one(7 + i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [one(42 + i) for i in range(steps)]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    price, o = outs[0]
+    H = 128
+    flop = 2 * (8 * H + 2 * H * H + H) + 2 * 2 * H * H + 2 * 2 * H * H + 2 * 8 * H  # per row: forward, dH x 2, gW x 2, gW1
+    tk = sum(x.get("seconds_train_kernels", 0.0) for _, x in outs)
+    rows = sum(x.get("R", 0) * x.get("epochs_run", 0) for _, x in outs)
+    nsteps = sum(x.get("optimizer_steps", 0) for _, x in outs)
+    tf = rows * flop / tk / 1e12 if tk > 0 else None
+    prices = [p_ for p_, _ in outs]
+    line = {
+        "metric": "paths x steps / sec (whole American pricing: path-gen + LSM + mean)", "value": M * N / dt,
+        "unit": "path-steps/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"GBM American put, S0=K=100 r=0.05 sigma=0.2 T=1, {M} paths x {N} steps, the reference's default "
+                               f"call: NN regressor SingleLSMNet(7, 128, 3), minibatch {o.get('batch')}, <= 25 epochs, dropout 0.1 "
+                               f"in training and in pass 2 (AdvancedOptionPricer.price_american_enhanced_lsm)",
+                   "baseline_config": "c1 (configs[0]) with the reference's own regressor", "paths_per_gpu": M, "n_steps": N,
+                   "parallelism": "single GPU"},
+        "roofline": {"kernel": "mlp_train_q16_kernel<128,3>", "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": tf / 157.3 if tf else None, "traffic": None, "flop_per_row": flop, "rows_trained": rows,
+                     "optimizer_steps": nsteps, "kernel_seconds": tk,
+                     "us_per_optimizer_step": 1e6 * tk / nsteps if nsteps else None,
+                     "note": "latency-bound by construction: 16 workgroups per minibatch, two dependent launches per optimizer "
+                             "step; the step's measured timeline is profiles/r05_default_call_timeline.txt"},
+        "cpu_baseline": {"value": M * N / 133.0, "unit": "path-steps/s", "cores": 8, "kind": "reference",
+                         "sample": "BASELINE.md section 2: this very call through the reference itself (imported, torch on 8 "
+                                   "threads): 133-147 s per pricing, measured in the build container; quoted, not re-run "
+                                   "(the reference does not travel to the GPU box)"},
+        "price": price, "prices": prices, "stderr": o.get("stderr"), "rows": o.get("R"),
+        "info": {k: o.get(k) for k in ("trainer", "pass2", "rows", "batch", "epochs_run", "optimizer_steps", "best_loss")},
+        "timings_ms": {k[len("seconds_"):]: round(1e3 * v, 3) for k, v in o.items() if k.startswith("seconds_")},
+        "price_check": "tests/test_gpu_nn.py::test_config1_nn_end_to_end_band (the reference's own seed band: 6.81 - 7.29), "
+                       "tests/test_gpu_dropout.py (trainer and pass 2 under the oracle's masks)",
+    }
+    print(json.dumps(line))
+    return 0
+
+
 # ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -229,6 +292,10 @@ def main():
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
+    if a.config == "c1nn":
+        if a.gpus != 1:
+            raise SystemExit("bench.py --config c1nn is a single-GPU line")
+        sys.exit(bench_c1nn(a))
     if a.config == "c5":
         if a.gpus != 1:
             raise SystemExit("bench.py --config c5 is a single-GPU line (the sharded NN flow: tools/time_nn_sharded.py)")
@@ -434,7 +501,18 @@ def main():
     barrier()
     ctx.sync()
     elapsed = time.perf_counter() - t0
+    ranks_table = None
     if dist_mode:
+        # who ran where: every rank's card (HIP ordinal, PCI bus id) and its OWN time per step, through the transport the
+        # pricing used.  Two ranks on one card, or a communicator that does not connect `world` distinct ranks, end the
+        # job on every rank (all hold the same table) -- unless this is the one-GPU rehearsal (--single-device).
+        info = ctx.device_info()
+        rows = omc_dist.gather_rank_table(pricer.allreduce_sum, rank, world, info["device"], info["pci_bus_id"],
+                                          1e3 * elapsed / a.steps)
+        try:
+            ranks_table = omc_dist.check_rank_table(rows, world, allow_shared_device=a.single_device)
+        except ValueError as e:
+            raise SystemExit(f"bench.py rank {rank}: {e}")
         elapsed = pricer.allreduce_max(elapsed)
     ctx.set_option("seq_event_stride", 0)
 
@@ -459,6 +537,9 @@ def main():
         "price": price, "price_stream": last_stream,
         "last_pricing": {k: last_out[k] for k in ("n_paths", "n_exercised", "n_zero", "sum_nitm", "sum", "sumsq")},
         "rccl_ranks": rccl_ranks, "comm": comm, "seq_overlap": seq_overlap,
+        "ranks": ranks_table,
+        "slowest_rank": max(ranks_table, key=lambda t: t["ms_per_step"])["rank"] if ranks_table else None,
+        "distinct_gpus": len({t["pci_bus_id"] for t in ranks_table}) if ranks_table else 1,
         "clock_settled": bool(settled),
         "warmup_by_time": {"seconds": warm_s, "pricings": wgroups * a.group, "rule": "two consecutive groups within 2 %, "
                            f">= {a.min_warmup_seconds} s (cap 5 s), after the --warmup pricings"},

@@ -79,6 +79,10 @@ typedef struct {
 int omc_abi_version(void);
 const char* omc_last_error(void);
 int omc_device_count(int* count);
+/* Which card a context runs on: its HIP ordinal in this process, its PCI bus id ("0000:c1:00.0", at least 13 bytes + NUL)
+ * and its name.  A multi-rank job gathers these to prove that N ranks sit on N DISTINCT cards (bench.py --gpus N fails
+ * loudly otherwise).  Any of the output pointers may be NULL. */
+int omc_ctx_device_info(omc_ctx* ctx, int* device, char* pci_bus_id, int pci_len, char* name, int name_len);
 /* hip_stream == NULL: the context creates its own stream; else it borrows the caller's
  * (e.g. torch.cuda.current_stream().cuda_stream) and never destroys it.
  *

@@ -109,6 +109,7 @@ SIGNATURES = {
     "omc_mlp_train_epoch_batch": (C.c_int, [_P, C.POINTER(MlpJob), _I, _I, _I] + [_D] * 5),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
     "omc_mlp_train_variant": (C.c_int, [C.c_int, C.c_int, _I64]),
+    "omc_ctx_device_info": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int]),
     "omc_mlp_dropout_masks": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _I64, _P, C.c_uint32, _U64, C.c_double, _P]),
     "omc_nn_half_counts": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _I, _P]),
     "omc_mlp_shard_epoch": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _P, _P, _I, _I, _P, _P, _P]),
@@ -458,6 +459,13 @@ class Context:
         r, w = C.c_int(0), C.c_int(0)
         _check(self.lib, self.lib.omc_comm_info(self.handle, C.byref(r), C.byref(w)))
         return r.value, w.value
+
+    def device_info(self) -> dict:
+        """-> dict(device=HIP ordinal, pci_bus_id="0000:c1:00.0", name=...) of the card this context runs on."""
+        dev = C.c_int(-1)
+        pci, name = C.create_string_buffer(64), C.create_string_buffer(256)
+        _check(self.lib, self.lib.omc_ctx_device_info(self.handle, C.byref(dev), pci, 64, name, 256))
+        return dict(device=dev.value, pci_bus_id=pci.value.decode(), name=name.value.decode())
 
     def comm_allreduce(self, values, op="sum"):
         a = np.ascontiguousarray(values, np.float64).copy()

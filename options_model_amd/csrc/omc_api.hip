@@ -574,6 +574,23 @@ int omc_ctx_destroy(omc_ctx* c)
     return 0;
 }
 
+int omc_ctx_device_info(omc_ctx* c, int* device, char* pci_bus_id, int pci_len, char* name, int name_len)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (device) *device = c->device;
+    if (pci_bus_id && pci_len > 0) {
+        pci_bus_id[0] = 0;
+        HIP_TRY(hipDeviceGetPCIBusId(pci_bus_id, pci_len, c->device));
+    }
+    if (name && name_len > 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        snprintf(name, (size_t)name_len, "%s", prop.name);
+    }
+    return 0;
+}
+
 int omc_sync(omc_ctx* c)
 {
     int rc = bind(c);

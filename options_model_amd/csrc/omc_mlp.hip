@@ -27,18 +27,6 @@ namespace omc {
 
 namespace {
 
-#ifndef OMC_Q16_EXP
-#define OMC_Q16_EXP 0  // experiment builds only (tools/gpu_r05.sh q16exp): 1 no gradient stores, 2 no weight fetches, 4 no MFMA, 8 no row sums, 64 time stamps
-#endif
-#if (OMC_Q16_EXP & 64)
-// one optimizer step on the 100 MHz wall clock: phases of tile 0's wave 0, the Adam kernel's first and last workgroup,
-// the next step's entry (read back by omc_debug_q16_stamps; experiment builds only)
-__device__ unsigned long long g_q16_stamps[32];
-__device__ int g_q16_flag = 0;
-#define Q16_STAMP(i) do { if (stamp) g_q16_stamps[i] = wall_clock64(); } while (0)
-#else
-#define Q16_STAMP(i) do { } while (0)
-#endif
 constexpr int kH = 64;                 // hidden width
 constexpr int kLdW1 = 9, kLdW2 = 65;   // LDS leading dimensions (odd: conflict-free column walks)
 // Staging patches are [unit][32 rows] without padding; the row index is XOR-swizzled per unit in
@@ -624,19 +612,7 @@ __device__ __forceinline__ void mlp_adam_body_flat(const MlpAdamArgs& a, const i
 
 __global__ __launch_bounds__(256) void mlp_adam_kernel(MlpAdamArgs a)
 {
-#if (OMC_Q16_EXP & 64)
-    const bool stamp = threadIdx.x == 0 && g_q16_flag == 1 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
-    const int slot = blockIdx.x == 0 ? 16 : 18;
-    Q16_STAMP(slot);
     mlp_adam_body(a);
-    if (stamp) {
-        __builtin_amdgcn_s_waitcnt(0);
-        g_q16_stamps[slot + 1] = wall_clock64();
-        if (blockIdx.x == gridDim.x - 1) g_q16_flag = 2;
-    }
-#else
-    mlp_adam_body(a);
-#endif
 }
 
 // Sharded training.  (1) this rank's gradient sums of the step, partials added in mlp_adam_body's order, as doubles
@@ -1400,10 +1376,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_kernel(MlpQuadArgs a)
 typedef float v4f16 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4f16 mfma16(float a, float b, v4f16 c)
 {
-    if constexpr ((OMC_Q16_EXP & 4) != 0) {
-        c[0] = __builtin_fmaf(a, b, c[0]);
-        return c;
-    }
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
@@ -1442,14 +1414,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
     if (tile >= a.ntiles) return;
     float* out = a.partial + (size_t)tile * a.pstride;
     const float* Wo = a.params + H * 8 + (L - 1) * CONN;
-#if (OMC_Q16_EXP & 64)
-    const bool stamp = tile == 0 && tid == 0 && a.step == 2000u;
-    if (tile == 0 && tid == 0 && g_q16_flag == 2) {
-        g_q16_stamps[24] = wall_clock64();
-        g_q16_flag = 3;
-    }
-    Q16_STAMP(0);
-#endif
 
     // A operands of one H x H product: row k of `src` is the contraction index, this wave's 32 columns 32 w + 2 j, + 1
     auto fetch_w = [&](const float* __restrict__ src, float2 (&dst)[KS]) {
@@ -1457,10 +1421,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if constexpr ((OMC_Q16_EXP & 2) != 0) {
-                    dst[4 * q + t] = make_float2(1e-3f * (float)(q + t + lane), -1e-3f * (float)(q - t));
-                    continue;
-                }
                 dst[4 * q + t] = *reinterpret_cast<const float2*>(src + (size_t)(16 * q + 4 * g + t) * H + 32 * w + 2 * j);
             }
     };
@@ -1545,7 +1505,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
         put(sAct[0], acc);
     }
     __syncthreads();
-    Q16_STAMP(1);
 
     // ---- layers 1 .. L-1
 #pragma unroll
@@ -1560,7 +1519,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
         hreg[l][1] = acc[1];
         put(sAct[l], acc);
         __syncthreads();
-        Q16_STAMP(1 + l);
     }
 
     // ---- output, loss, d(loss)/d(out): every wave ends with the same numbers
@@ -1600,8 +1558,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
         }
         if (g == 0) *reinterpret_cast<float2*>(out + H * 8 + (L - 1) * CONN + 32 * w + 2 * j) = make_float2(acc[0][0], acc[1][0]);
     }
-
-    Q16_STAMP(5);
 #pragma unroll
     for (int l = L - 1; l >= 1; --l) {
         float* gWl = out + H * 8 + (size_t)(l - 1) * CONN;
@@ -1637,17 +1593,14 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
                 acc[0][NQ] = mfma16(1.0f, dv[s2].x, acc[0][NQ]);
                 acc[1][NQ] = mfma16(1.0f, dv[s2].y, acc[1][NQ]);
             }
-            if ((OMC_Q16_EXP & 1) == 0 || a.two_over_b == 123.0f) {
 #pragma unroll
-                for (int ub = 0; ub < 2; ++ub)
+            for (int ub = 0; ub < 2; ++ub)
 #pragma unroll
-                    for (int kb = 0; kb < NQ; ++kb)
-                        *reinterpret_cast<float4*>(gWl + (size_t)(32 * w + 2 * j + ub) * H + 16 * kb + 4 * g) =
-                            make_float4(acc[ub][kb][0], acc[ub][kb][1], acc[ub][kb][2], acc[ub][kb][3]);
-            }
+                for (int kb = 0; kb < NQ; ++kb)
+                    *reinterpret_cast<float4*>(gWl + (size_t)(32 * w + 2 * j + ub) * H + 16 * kb + 4 * g) =
+                        make_float4(acc[ub][kb][0], acc[ub][kb][1], acc[ub][kb][2], acc[ub][kb][3]);
             if (g == 0) *reinterpret_cast<float2*>(gWl + H * H + 32 * w + 2 * j) = make_float2(acc[0][NQ][0], acc[1][NQ][0]);
         }
-        Q16_STAMP(6 + 2 * (L - 1 - l));
         // ---- dH_{l-1} of the own units = W_l^T dZ_l, then through the ReLU / dropout mask of H_{l-1}
         {
             v4f16 d[2] = {v4f16{0.0f, 0.0f, 0.0f, 0.0f}, v4f16{0.0f, 0.0f, 0.0f, 0.0f}};
@@ -1658,7 +1611,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
                 for (int r = 0; r < 4; ++r) dz[ub][r] = hreg[l - 1][ub][r] > 0.0f ? d[ub][r] * a.inv_keep : 0.0f;
         }
         __syncthreads();  // every wave is done with sDz
-        Q16_STAMP(7 + 2 * (L - 1 - l));
     }
 
     // ---- gW1 (own units x 8 inputs, bias in column 7): the same transposed contraction, MFMA rows = inputs
@@ -1692,13 +1644,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
             out[NP] = loss;
         }
     }
-#if (OMC_Q16_EXP & 64)
-    if (stamp) {
-        __builtin_amdgcn_s_waitcnt(0);  // the wave's stores have been acknowledged
-        g_q16_stamps[12] = wall_clock64();
-        g_q16_flag = 1;
-    }
-#endif
 }
 
 // ---- many small networks trained side by side (the curve entry points: one net per curve point) ----------------
@@ -2451,15 +2396,6 @@ hipError_t mlp_dropout_masks(hipStream_t st, int variant, int hidden, int layers
     return hipGetLastError();
 }
 
-#if (OMC_Q16_EXP & 64)
-}  // namespace omc
-extern "C" int omc_debug_q16_stamps(unsigned long long* out32)
-{
-    if (hipDeviceSynchronize() != hipSuccess) return 1;
-    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(omc::g_q16_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 2;
-}
-namespace omc {
-#endif
 
 hipError_t mlp_shuffle_indices(hipStream_t st, int64_t n, uint64_t shuffle_key, int64_t* out)
 {

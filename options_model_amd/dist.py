@@ -98,6 +98,59 @@ class _ShardedBase:
         self.ctx.close()
 
 
+# ---- who ran where: every rank's (device ordinal, PCI bus id, time per step), gathered through a SUM all-reduce ----------
+def pci_to_number(pci_bus_id: str) -> float:
+    """"0000:c1:00.0" -> an integer below 2**40 (exact in a double): domain:bus:device.function."""
+    try:
+        dom, bus, rest = pci_bus_id.strip().split(":")
+        dev, fn = rest.split(".")
+        return float((int(dom, 16) << 24) | (int(bus, 16) << 16) | (int(dev, 16) << 8) | int(fn, 16))
+    except Exception:
+        return -1.0
+
+
+def number_to_pci(x: float) -> str:
+    v = int(x)
+    if v < 0:
+        return "unknown"
+    return f"{v >> 24:04x}:{(v >> 16) & 0xff:02x}:{(v >> 8) & 0xff:02x}.{v & 0xff:x}"
+
+
+RANK_ROW = 5  # doubles per rank: [present, device ordinal, pci number, ms per step, rank]
+
+
+def gather_rank_table(allreduce_sum, rank: int, world: int, device: int, pci_bus_id: str, ms_per_step: float) -> list:
+    """Every rank contributes its row at its own offset of a zero vector; one SUM all-reduce (the transport the pricing
+    itself uses: native communicator, torch.distributed or a test double) hands the whole table to everybody."""
+    vec = [0.0] * (RANK_ROW * world)
+    vec[RANK_ROW * rank:RANK_ROW * (rank + 1)] = [1.0, float(device), pci_to_number(pci_bus_id), float(ms_per_step), float(rank)]
+    out = list(allreduce_sum(vec))
+    return [out[RANK_ROW * r:RANK_ROW * (r + 1)] for r in range(world)]
+
+
+def check_rank_table(rows, world: int, allow_shared_device: bool = False) -> list:
+    """-> [{rank, device, pci_bus_id, ms_per_step}] or ValueError: a rank that contributed no row or twice (the
+    communicator does not have `world` distinct ranks), or two ranks on one card (two processes sharing a GPU would
+    report a 'scaling' number that is really time slicing).  Every rank holds the same table, so every rank raises."""
+    if len(rows) != world:
+        raise ValueError(f"rank table has {len(rows)} rows, expected {world}")
+    table = []
+    for r, (present, device, pci, ms, rk) in enumerate(rows):
+        if present != 1.0 or int(rk) != r:
+            raise ValueError(f"rank {r} contributed {present:g} rows to the rank table (expected exactly 1): the "
+                             f"communicator does not connect {world} distinct ranks")
+        table.append(dict(rank=r, device=int(device), pci_bus_id=number_to_pci(pci), ms_per_step=ms))
+    if not allow_shared_device:
+        seen = {}
+        for t in table:
+            key = t["pci_bus_id"]
+            if key in seen and key != "unknown":
+                raise ValueError(f"ranks {seen[key]} and {t['rank']} both run on the card at PCI {key}: one rank per GPU "
+                                 f"(check LOCAL_RANK / HIP_VISIBLE_DEVICES of the launcher)")
+            seen[key] = t["rank"]
+    return table
+
+
 class RcclUnavailable(RuntimeError):
     """The native communicator cannot be used by this JOB.  Raised on every rank or on none: the ranks vote
     (rendezvous.agree) before and after omc_comm_init, so a caller may fall back to another transport knowing
@@ -203,6 +256,9 @@ class RcclPricer(_ShardedBase):
     def allreduce_max(self, x: float) -> float:
         return float(self.ctx.comm_allreduce([x], "max")[0])
 
+    def allreduce_sum(self, values) -> list:
+        return [float(v) for v in self.ctx.comm_allreduce(list(values), "sum")]
+
     def enable_p2p(self, tag: str | None = None, timeout_s: float = 60.0) -> bool:
         """The per-step flows' moment exchange by direct writes into every peer's mailbox (omc_p2p_*; SURVEY.md
         5.8(b)) instead of an all-reduce per time step.  Collective: every rank exports its mailbox handle, all
@@ -297,3 +353,9 @@ class ShardedPricer(_ShardedBase):
         t = self.torch.tensor([x], dtype=self.torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
+
+    def allreduce_sum(self, values) -> list:
+        dev = self.device if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().tolist()

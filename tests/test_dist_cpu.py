@@ -282,3 +282,78 @@ def test_watchdog_ends_a_stuck_process():
     assert out.returncode == 3 and "test section did not finish within" in out.stderr
     code = code.replace("time.sleep(30)", "w.cancel(); time.sleep(1.0)")
     assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60).returncode == 0
+
+
+# ---- the N > 1 bench line checks itself: N ranks on N distinct cards ---------------------------
+def test_pci_bus_id_round_trip():
+    for s_ in ("0000:c1:00.0", "0002:05:1f.7", "ffff:ff:ff.f"):
+        assert omc_dist.number_to_pci(omc_dist.pci_to_number(s_)) == s_
+    assert omc_dist.pci_to_number("garbage") == -1.0 and omc_dist.number_to_pci(-1.0) == "unknown"
+
+
+def _table(entries, world):
+    """What a SUM all-reduce of the ranks' vectors returns when rank r contributes entries[r] (None = never shows up)."""
+    vec = [0.0] * (omc_dist.RANK_ROW * world)
+    for e in entries:
+        if e is None:
+            continue
+        r, dev, pci, ms = e
+        got = omc_dist.gather_rank_table(lambda v: v, r, world, dev, pci, ms)
+        flat = [x for row in got for x in row]
+        vec = [a + b for a, b in zip(vec, flat)]
+    return [vec[omc_dist.RANK_ROW * r:omc_dist.RANK_ROW * (r + 1)] for r in range(world)]
+
+
+def test_rank_table_accepts_n_ranks_on_n_cards_and_names_the_slowest():
+    rows = _table([(r, r, f"0000:{0x10 + r:02x}:00.0", 4.0 + 0.1 * r) for r in range(8)], 8)
+    t = omc_dist.check_rank_table(rows, 8)
+    assert [x["rank"] for x in t] == list(range(8)) and t[3]["pci_bus_id"] == "0000:13:00.0" and t[3]["device"] == 3
+    assert max(t, key=lambda x: x["ms_per_step"])["rank"] == 7
+    assert len({x["pci_bus_id"] for x in t}) == 8
+
+
+def test_rank_table_rejects_two_ranks_on_one_card():
+    rows = _table([(0, 0, "0000:c1:00.0", 4.0), (1, 0, "0000:c1:00.0", 4.1)], 2)
+    with pytest.raises(ValueError, match="both run on the card at PCI 0000:c1:00.0"):
+        omc_dist.check_rank_table(rows, 2)
+    t = omc_dist.check_rank_table(rows, 2, allow_shared_device=True)  # the one-GPU rehearsal (--single-device)
+    assert [x["pci_bus_id"] for x in t] == ["0000:c1:00.0"] * 2
+
+
+def test_rank_table_rejects_a_communicator_without_n_distinct_ranks():
+    # a rank that never contributed (a communicator of fewer ranks), and one rank number claimed twice
+    with pytest.raises(ValueError, match="rank 1 contributed 0 rows"):
+        omc_dist.check_rank_table(_table([(0, 0, "0000:c1:00.0", 4.0), None], 2), 2)
+    with pytest.raises(ValueError, match="contributed 2 rows"):
+        omc_dist.check_rank_table(_table([(0, 0, "0000:c1:00.0", 4.0), (0, 1, "0000:c2:00.0", 4.0)], 2), 2)
+    with pytest.raises(ValueError, match="expected 4"):
+        omc_dist.check_rank_table(_table([(0, 0, "0000:c1:00.0", 4.0), (1, 1, "0000:c2:00.0", 4.0)], 2), 4)
+
+
+def _table_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def all_reduce_sum(vals):
+            t = torch.tensor(vals, dtype=torch.float64)
+            td.all_reduce(t)
+            return t.tolist()
+
+        rows = omc_dist.gather_rank_table(all_reduce_sum, rank, world, rank, f"0000:{0xc1 + rank:02x}:00.0", 0.5 + rank)
+        t = omc_dist.check_rank_table(rows, world)
+        np.save(os.path.join(out_dir, f"table{rank}.npy"), np.array([[x["rank"], x["device"], x["ms_per_step"]] for x in t]))
+        with open(os.path.join(out_dir, f"pci{rank}.txt"), "w") as f:
+            f.write(",".join(x["pci_bus_id"] for x in t))
+    finally:
+        td.destroy_process_group()
+
+
+def test_rank_table_over_gloo_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_table_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    t0, t1 = np.load(tmp_path / "table0.npy"), np.load(tmp_path / "table1.npy")
+    assert np.array_equal(t0, t1) and np.array_equal(t0, [[0, 0, 0.5], [1, 1, 1.5]])  # every rank holds the whole table
+    assert (tmp_path / "pci0.txt").read_text() == (tmp_path / "pci1.txt").read_text() == "0000:c1:00.0,0000:c2:00.0"

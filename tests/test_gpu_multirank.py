@@ -53,6 +53,11 @@ def test_ranks_sharing_one_gpu_equal_the_unsharded_pricing(ctx, standin, world, 
                      "--min-warmup-seconds", "0.05", "--no-variants", "--no-cpu-baseline", "--no-sustained"], standin)
     d = _line(out)
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["comm"].startswith("rccl-native")
+    # the line says who ran where (gathered through the communicator): `world` distinct ranks, here all on this one card
+    # (--single-device; without that flag two ranks on one PCI id end the job: tests/test_dist_cpu.py)
+    assert [t["rank"] for t in d["ranks"]] == list(range(world)) and d["distinct_gpus"] == 1
+    assert len({t["pci_bus_id"] for t in d["ranks"]}) == 1 and all(t["ms_per_step"] > 0 for t in d["ranks"])
+    assert d["ranks"][d["slowest_rank"]]["ms_per_step"] <= d["ms_per_step"] * 1.0001
     # the sharded job == ONE pricing of world x paths: same Philox pairs (global pair index), sums in another order
     ref = ctx.price_american(_ffi.make_params(semantics=sem, n_paths=world * M_PER_GPU, n_steps=N, seed=42, stream=3))
     assert d["price"] == pytest.approx(ref["price"], rel=1e-12)

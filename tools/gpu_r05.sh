@@ -41,23 +41,6 @@ q16)
   cat gpurun_out/${TAG}_default_pricer.txt; ok $rc || exit 1
   prof default_pricer "$R/tools/prof_default_pricer.py" || exit 1
   ;;
-q16exp)  # where do the 18.6 us of mlp_train_q16_kernel<128,3> go?  experiment builds on the box (hipcc is there)
-  for E in 0 1 2 3 4 8 15; do
-    OMC_HIPCC_FLAGS="-DOMC_Q16_EXP=$E" timeout -k 10 300 python -m options_model_amd._build --force > gpurun_out/${TAG}_build_$E.log 2>&1 || { tail -5 gpurun_out/${TAG}_build_$E.log; exit 1; }
-    echo "EXP=$E" >> gpurun_out/${TAG}_q16exp.txt
-    OMC_HIPCC_FLAGS="-DOMC_Q16_EXP=$E" timeout -k 10 200 python tools/bench_mlp.py 225057 256 4 0.1 3 128 >> gpurun_out/${TAG}_q16exp.txt 2>> gpurun_out/${TAG}_q16exp.err; rc=$?
-    ok $rc || exit 1
-  done
-  cat gpurun_out/${TAG}_q16exp.txt
-  ;;
-stamps)
-  for E in ${EXPS:-64}; do
-    OMC_HIPCC_FLAGS="-DOMC_Q16_EXP=$E" timeout -k 10 300 python -m options_model_amd._build --force > gpurun_out/${TAG}_build_$E.log 2>&1 || { tail -5 gpurun_out/${TAG}_build_$E.log; exit 1; }
-    echo "EXP=$E" >> gpurun_out/${TAG}_stamps.txt
-    for i in 1 2; do OMC_HIPCC_FLAGS="-DOMC_Q16_EXP=$E" timeout -k 10 200 python tools/q16_stamps.py >> gpurun_out/${TAG}_stamps.txt 2>> gpurun_out/${TAG}_stamps.err; done
-  done
-  cat gpurun_out/${TAG}_stamps.txt; tail -3 gpurun_out/${TAG}_stamps.err
-  ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
   tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
