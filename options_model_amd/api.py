@@ -114,7 +114,12 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
             raise ValueError("n_gpus > 1 uses one context per rank process; do not pass ctx.")
         _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
         from . import launcher
+        if isinstance(device, int) and not os.environ.get("OMC_RCCL_LIB"):
+            # (real RCCL refuses two ranks on one card; only the shared-memory stand-in of the tests runs that way)
+            raise ValueError("n_gpus > 1 needs one device per rank: pass device=[d0, d1, ...] or leave it unset.")
         devices = None if device is None else ([int(device)] * n_gpus if isinstance(device, int) else list(device))
+        if devices is not None and len(devices) != n_gpus:
+            raise ValueError(f"device lists {len(devices)} cards for n_gpus={n_gpus}.")
         kw = dict(S0=S0, K=K, r=r, sigma=sigma, T=T, n_paths=int(n_paths), n_steps=int(n_steps), model=model,
                   option_type=option_type, heston_params=heston_params, seed=int(seed), stream=int(stream))
         if regressor == "nn":

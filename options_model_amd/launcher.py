@@ -114,6 +114,9 @@ def launch_ranks(n: int, deadline_s: float, argv, who: str = "options_model_amd.
     return rc
 
 
+VALUE_ERROR_GRACE_S = 5.0  # how long the other ranks may take to raise the same ValueError (see _roundtrip)
+
+
 class RankError(RuntimeError):
     """A rank of the pool died, answered with an error, or did not answer within the deadline.  The pool is closed."""
 
@@ -179,12 +182,21 @@ class RankPool:
         for r, p in enumerate(self.procs):
             sel.register(p.stdout, selectors.EVENT_READ, r)
         deadline = time.monotonic() + timeout_s
+        refused_at = None  # when the first rank answered ValueError
         try:
             while any(a is None for a in answers):
                 left = deadline - time.monotonic()
                 if left <= 0:
                     missing = [r for r, a in enumerate(answers) if a is None]
                     raise RankError(f"rank(s) {missing} did not answer {req['fn']} within {timeout_s:.0f} s")
+                if refused_at is not None and time.monotonic() - refused_at > VALUE_ERROR_GRACE_S:
+                    # An argument error is raised before anything collective -- on EVERY rank, within moments.  A rank
+                    # that has not refused by now took the call: the ValueError was rank-local (a library check that only
+                    # fails for one shard), and that rank's peers sit in a collective it will never enter.
+                    bad = [r for r, a in enumerate(answers) if a is not None and not a.get("ok")]
+                    missing = [r for r, a in enumerate(answers) if a is None]
+                    raise RankError(f"rank(s) {bad} refused {req['fn']} ({answers[bad[0]].get('error')}) while rank(s) "
+                                    f"{missing} went ahead: the ranks are out of step")
                 for key, _ in sel.select(min(left, 0.5)):
                     r = key.data
                     chunk = self.procs[r].stdout.read()
@@ -199,6 +211,8 @@ class RankPool:
                         msg = json.loads(ln)
                         if msg.get("id") == req["id"]:
                             answers[r] = msg
+                            if not msg.get("ok") and msg.get("type") == "ValueError" and refused_at is None:
+                                refused_at = time.monotonic()
                             if not msg.get("ok") and msg.get("type") != "ValueError":
                                 # this rank has left the collective call: its peers may be waiting for it inside a
                                 # collective that has no deadline -- do not wait for their answers

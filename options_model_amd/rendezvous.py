@@ -82,8 +82,19 @@ def default_tag() -> str:
     return tag
 
 
+def _nonce() -> str:
+    nonce = os.environ.get("OMC_RDZV_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID")
+    return "".join(ch for ch in nonce if ch.isalnum())[:32] if nonce and nonce != "none" else ""
+
+
 def _name(tag: str | None = None) -> str:
-    return f"omc_rccl_uid_{default_tag() if tag is None else tag}"
+    """File name of a rendezvous: the default tag carries the launch nonce already; an EXPLICIT tag gets it appended, so
+    that under a nonce no file name can be produced by another launch whatever tag the caller chose -- which is what
+    lets _not_before() skip the staleness test there."""
+    if tag is None:
+        return f"omc_rccl_uid_{default_tag()}"
+    n = _nonce()
+    return f"omc_rccl_uid_{tag}" + (f"_{n}" if n and n not in tag else "")
 
 
 def _tag_hash(tag: str | None) -> bytes:

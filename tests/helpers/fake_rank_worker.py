@@ -22,6 +22,12 @@ for line in sys.stdin:
     elif fn == "bad":
         print(json.dumps(dict(id=rid, ok=False, type="ValueError", error="S0, K, T must be positive.")), flush=True)
         continue
+    elif fn == "bad_on_one":  # a rank-LOCAL ValueError (a library check that fails for one shard only): the peers go ahead
+        if rank == kw.get("rank"):
+            print(json.dumps(dict(id=rid, ok=False, type="ValueError", error="selected another number of rows")), flush=True)
+            continue
+        time.sleep(300)  # ... into a collective the refusing rank never enters
+        continue
     elif fn == "fail_then_hang":
         if rank == kw.get("rank"):
             print(json.dumps(dict(id=rid, ok=False, type="RuntimeError", error="kernel launch failed")), flush=True)

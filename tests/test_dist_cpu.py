@@ -244,6 +244,26 @@ def test_rendezvous_files_are_private_fresh_and_never_followed(tmp_path, monkeyp
     assert rendezvous.fetch(128, tag, timeout_s=1.0) == b"w" * 128
 
 
+def test_an_explicit_tag_carries_the_nonce_too(tmp_path, monkeypatch):
+    """under a nonce the staleness test is skipped -- sound only if the FILE NAME holds the nonce.  Explicit
+    tags (RcclPricer(tag=...), enable_p2p(tag=...)) now get it appended: a leftover frame of an earlier launch under the
+    same explicit tag has another name and is never read."""
+    from options_model_amd import rendezvous as rz
+    monkeypatch.setenv("OMC_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("OMC_RDZV_NONCE", "launchA")
+    rz.publish(b"A" * 16, tag="mytag")
+    assert rz._name("mytag") == "omc_rccl_uid_mytag_launchA"
+    assert rz.fetch(16, tag="mytag", timeout_s=2) == b"A" * 16
+    monkeypatch.setenv("OMC_RDZV_NONCE", "launchB")  # the next launch, same explicit tag: the old frame is invisible
+    assert rz._name("mytag") == "omc_rccl_uid_mytag_launchB"
+    with pytest.raises(TimeoutError):
+        rz.fetch(16, tag="mytag", timeout_s=0.5)
+    assert rz._name(rz.default_tag() + "_p2p0").count("launchB") == 1  # (a tag built from the default is not doubled)
+    monkeypatch.delenv("OMC_RDZV_NONCE")
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    assert rz._name("mytag") == "omc_rccl_uid_mytag"
+
+
 def test_tag_carries_the_launch_nonce(monkeypatch):
     from options_model_amd import rendezvous
     monkeypatch.setenv("MASTER_PORT", "12345")

@@ -57,6 +57,20 @@ def test_an_error_on_one_rank_does_not_wait_for_its_peers():
     assert time.monotonic() - t0 < 30 and all(q.poll() is not None for q in p.procs)
 
 
+def test_a_rank_local_value_error_does_not_leave_the_peers_waiting(monkeypatch):
+    """a ValueError is treated as 'raised on every rank before anything collective'.  When only ONE rank
+    raises it (a library check that fails for its shard), the others have entered the collective and would wait for the
+    600 s / 3600 s deadline.  After a short grace period the call fails, names who refused and who went ahead, and the
+    pool is taken down."""
+    monkeypatch.setattr(launcher, "VALUE_ERROR_GRACE_S", 1.0)
+    p = _pool(3)
+    t0 = time.monotonic()
+    with pytest.raises(launcher.RankError, match=r"rank\(s\) \[1\] refused bad_on_one \(selected another number of rows\) "
+                                                 r"while rank\(s\) \[0, 2\] went ahead"):
+        p.call("bad_on_one", dict(rank=1), timeout_s=600)
+    assert time.monotonic() - t0 < 30 and p._closed and all(q.poll() is not None for q in p.procs)
+
+
 def test_deadline_ends_a_stuck_rank():
     p = _pool(2)
     t0 = time.monotonic()
@@ -131,7 +145,17 @@ def test_facade_from_a_plain_process_goes_through_the_pool(monkeypatch):
         api.price_american_option(-1.0, 100.0, 0.05, 0.2, 1.0, 4000, 20, n_gpus=4)
     with pytest.raises(ValueError, match="do not pass ctx"):
         api.price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 4000, 20, n_gpus=4, ctx=object())
+    # ONE card for several ranks is an argument error (real RCCL refuses it -- it used to surface as "the ranks did not
+    # come up" after the start timeout); only the tests' shared-memory stand-in runs that way
+    monkeypatch.delenv("OMC_RCCL_LIB", raising=False)
+    with pytest.raises(ValueError, match="one device per rank"):
+        api.price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 4000, 20, n_gpus=4, device=0)
+    with pytest.raises(ValueError, match="lists 2 cards for n_gpus=4"):
+        api.price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 4000, 20, n_gpus=4, device=[0, 1])
     assert len(fake.calls) == n
+    monkeypatch.setenv("OMC_RCCL_LIB", "/somewhere/librccl_standin.so")
+    api.price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 4000, 20, n_gpus=2, device=0)
+    assert seen[-1] == (2, [0, 0])
 
 
 def test_advanced_pricer_n_gpus_routes_through_the_facade(monkeypatch):

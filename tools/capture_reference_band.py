@@ -10,7 +10,7 @@ import json, os, sys, time, types
 sys.modules.setdefault("yfinance", types.ModuleType("yfinance"))
 sys.path.insert(0, "/root/reference/options_model_3")
 import torch
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("REF_THREADS", "8")))
 import options_model_3 as om  # noqa: E402
 
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "scalars.json")
