@@ -313,7 +313,14 @@ int omc_lsm_apply_mlp_shard(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_
  * normalised likewise.  *n_rows = number of rows; with data == NULL only the count is made (call
  * once to size the buffer, then again with data and cap_rows >= *n_rows).  stats16 (host) =
  * feat_mean[7], feat_std[7], y_mean, y_std -- on a context with a communicator / hook those of ALL ranks' rows (see the
- * sharded NN regressor below); every rank of the job must then make the call, also one without any row. */
+ * sharded NN regressor below); every rank of the job must then make the call, also one without any row.  There the
+ * call with `data` is COLLECTIVE (two all-reduces of 9 and 8 doubles): a failure only one rank can see (its row buffer
+ * too small, no memory for its scratch) travels as a flag in the first of them and EVERY rank returns an error -- the
+ * rank's own, 3102 on its peers -- instead of leaving them inside a collective; a job without any in-the-money row
+ * returns the default statistics (means 0, stds 1) on every rank.
+ * S is read twice: one sweep counts the rows of every (step, 256-path tile) and forms the statistics -- per-thread sums
+ * around the thread's first row, merged as (n, mean, M2) triples by Chan's formula in a fixed tree: the two-pass values
+ * of :550-563 to ~1e-15, a constant column's variance exactly 0 -- and one sweep writes the rows. */
 int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
                       double r, double T, int is_put, float* data, int64_t cap_rows, int64_t* n_rows,
                       double* stats16);

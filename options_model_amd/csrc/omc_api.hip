@@ -2059,47 +2059,102 @@ int omc_nn_build_rows(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
     if ((rc = check_market(1.0, K, T, r))) return rc;
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
-    if (!n_rows) return fail(-7, "null pointer.");
+    if (!n_rows || (data && !stats16)) return fail(-7, "null pointer.");
+    const bool full = data != nullptr;
+    // On a context with a communicator / hook the full call is COLLECTIVE (two small all-reduces below).  A failure that
+    // only this rank can see -- no memory for its scratch, a row buffer too small for ITS rows, a HIP error -- must not
+    // send it home before the peers have entered them: it is carried as a flag in the first all-reduce instead, and
+    // every rank of the job returns an error together.
+    const bool dist = full && c->distributed();
+    int lerr = 0;
+    std::string ltext;
+    auto local_failure = [&](int code) {
+        lerr = code;
+        ltext = g_err;
+    };
     omc::LsmWorkspace w;
-    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, false, &w))) return rc;
-    if ((rc = c->scratch.ensure(omc::nn_rows_scratch_bytes(n_paths, n_steps)))) return rc;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, false, &w)) ||
+        (rc = c->scratch.ensure(omc::nn_rows_scratch_bytes(n_paths, n_steps)))) {
+        if (!dist) return rc;
+        local_failure(rc);
+    }
     omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
-    const int64_t* total_dev = nullptr;
-    HIP_TRY(omc::nn_rows_count(c->stream, p, w.D, c->scratch.p, &total_dev));
     int64_t R = 0;
-    HIP_TRY(hipMemcpyAsync(&R, total_dev, sizeof R, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    double st[16] = {0.0};  // n, mean[7], M2[7] of [x, x^2, x^3, max(x-1,0), s, x*s, y] over this rank's rows
+    if (!lerr) {
+        // ONE sweep over S: the counts of every (step, tile) and -- when rows are to be written -- the statistics
+        const int64_t* total_dev = nullptr;
+        const double* stats_dev = nullptr;
+        hipError_t e = omc::nn_rows_count(c->stream, p, w.D, c->scratch.p, &total_dev, full, &stats_dev);
+        if (e == hipSuccess) e = hipMemcpyAsync(&R, total_dev, sizeof R, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && full) e = hipMemcpyAsync(st, stats_dev, sizeof st, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            g_err = std::string("pass 1 of the NN flow failed: ") + hipGetErrorString(e);
+            if (!dist) return (int)e;
+            local_failure((int)e);
+            R = 0;
+        }
+    }
     *n_rows = R;
-    if (!data) return 0;  // count only
-    if (!stats16) return fail(-7, "null pointer.");
-    if (cap_rows < R) return fail(-6, "row buffer smaller than the number of in-the-money (step, path) pairs.");
+    if (!full) return 0;  // count only
+    if (!lerr && cap_rows < R) {
+        g_err = "row buffer smaller than the number of in-the-money (step, path) pairs.";
+        if (!dist) return -6;
+        local_failure(-6);
+    }
     for (int i = 0; i < 16; ++i) stats16[i] = i < 7 ? 0.0 : 1.0;
     stats16[0] = 1.0;  // the constant feature: mean 1, std 0 -> 1
     stats16[14] = 0.0;
-    if (R == 0 && !c->distributed()) return 0;  // (a rank without rows still takes part in the job's sums)
-    // On a context with a communicator / hook the statistics are those of ALL ranks' rows: the sums (slot 7 = row
-    // count) and then the squared deviations from the GLOBAL means are added over the ranks -- the two-pass formula
-    // of :550-563 over the union of the shards, in float64 -- and this rank's rows are normalised with them.
-    double sums[8], mean[8], dev[8];
-    HIP_TRY(omc::nn_rows_stats(c->stream, p, w.D, c->scratch.p, 0, nullptr, sums));
-    if (c->distributed() && (rc = allreduce_host(c, w.gmom, sums, 8))) return rc;
-    const double Rg = c->distributed() ? sums[7] : (double)R;  // rows of the job
-    for (int q = 0; q < 8; ++q) mean[q] = sums[q] / Rg;
-    HIP_TRY(omc::nn_rows_stats(c->stream, p, w.D, c->scratch.p, 1, mean, dev));
-    if (c->distributed() && (rc = allreduce_host(c, w.gmom, dev, 8))) return rc;
-    const double R_stat = Rg;
-    // layout: feat_mean[0..6], feat_std[7..13], y_mean [14], y_std [15]; zero std -> 1 (:551-563)
+    double mean[7], m2[7], Rg = (double)R;
+    if (!dist) {
+        if (R == 0) return 0;
+        for (int q = 0; q < 7; ++q) {
+            mean[q] = st[1 + q];
+            m2[q] = st[8 + q];
+        }
+    } else {
+        // The statistics are those of ALL ranks' rows (the reference trains one network on the rows of all paths):
+        // (1) sum over the ranks of n_r mean_r and n_r -> the global means; (2) sum of M2_r + n_r (mean_r - mean)^2 ->
+        // the global sum of squared deviations (Chan's merge, for any number of ranks at once).  A rank without rows
+        // contributes zeros; when NO rank has a row every rank returns the defaults together.
+        if ((rc = c->seq_vote.ensure(sizeof(double) * 16))) return rc;  // (128 bytes: nothing left to do if this fails)
+        const double nr = lerr ? 0.0 : st[0];
+        double v[9];
+        for (int q = 0; q < 7; ++q) v[q] = nr * st[1 + q];
+        v[7] = nr;
+        v[8] = lerr ? 1.0 : 0.0;
+        if ((rc = allreduce_host(c, (double*)c->seq_vote.p, v, 9))) return rc;
+        if (v[8] > 0.0) {
+            if (lerr) return fail(lerr, ltext.c_str());
+            return fail(3102, "another rank of the job could not build its training rows.");
+        }
+        Rg = v[7];
+        if (!(Rg > 0.0)) return 0;
+        double dv[8];
+        for (int q = 0; q < 7; ++q) {
+            mean[q] = v[q] / Rg;
+            const double dm = st[1 + q] - mean[q];
+            dv[q] = nr > 0.0 ? st[8 + q] + nr * dm * dm : 0.0;
+        }
+        dv[7] = 0.0;
+        if ((rc = allreduce_host(c, (double*)c->seq_vote.p, dv, 8))) return rc;
+        for (int q = 0; q < 7; ++q) m2[q] = dv[q];
+    }
+    // layout: feat_mean[0..6], feat_std[7..13], y_mean [14], y_std [15]; population std, zero std -> 1 (:551-563)
     for (int q = 0; q < 6; ++q) {
-        const double sd = std::sqrt(dev[q] / R_stat);
+        const double sd = std::sqrt(m2[q] / Rg);
         stats16[1 + q] = mean[q];
         stats16[8 + q] = sd > 1e-13 * std::fabs(mean[q]) ? sd : 1.0;
     }
-    const double ysd = std::sqrt(dev[6] / R_stat);
+    const double ysd = std::sqrt(m2[6] / Rg);
     stats16[14] = mean[6];
     stats16[15] = ysd > 1e-13 * std::fabs(mean[6]) ? ysd : 1.0;
-    HIP_TRY(omc::nn_rows_write(c->stream, p, w.D, c->scratch.p, stats16, stats16 + 7, stats16[14], stats16[15], data,
-                               cap_rows));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (R > 0) {
+        HIP_TRY(omc::nn_rows_write(c->stream, p, w.D, c->scratch.p, stats16, stats16 + 7, stats16[14], stats16[15], data,
+                                   cap_rows));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 
@@ -2180,6 +2235,7 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
     t.wt = (float*)c->mlp_wt.p;
     t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.weight_decay = weight_decay;
     t.dropout = dropout; t.seed = seed; t.shuffle_key = shuffle_key;
+    t.allow_q16 = true;
     HIP_TRY(omc::mlp_train_steps(c->stream, t));
     double acc = 0.0;
     HIP_TRY(hipMemcpyAsync(&acc, c->mlp_loss.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2287,6 +2343,7 @@ int omc_mlp_train_epoch_sharded(omc_ctx* c, const float* data_epoch, int64_t n_r
     t.nrows = n_rows_local; t.batch = batch; t.first_step = *step; t.hidden = hidden; t.layers = layers;
     t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.weight_decay = weight_decay;
     t.dropout = dropout; t.seed = seed; t.shuffle_key = 0;
+    t.allow_q16 = true;
     t.step_off = step_off; t.rows_global = rows_global; t.drop_pos = drop_pos;
     t.allreduce = allreduce_cb; t.allreduce_user = c;  // no communicator / hook: the sum of one rank
     const int64_t kb = omc::mlp_plan_kernel_batch(t);
@@ -2322,7 +2379,9 @@ int omc_mlp_train_epoch_batch(omc_ctx* c, omc_mlp_job* jobs, int n, int hidden, 
     if (!jobs || n <= 0) return fail(-7, "empty batch.");
     if (n > 65535) return fail(-3, "batch too large (max 65535 networks per call).");
     if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
-    int64_t max_steps = 0, max_batch = 0, last_step = 0;
+    int64_t max_steps = 0, max_batch32 = 0, max_batch16 = 0, last_step = 0;
+    size_t part_bytes = 0;
+    const int64_t q16_rows = omc::mlp_q16_rows(hidden);
     for (int i = 0; i < n; ++i) {
         const omc_mlp_job& j = jobs[i];
         if (!j.data || !j.params || !j.adam_m || !j.adam_v) return fail(-7, "null pointer.");
@@ -2333,12 +2392,15 @@ int omc_mlp_train_epoch_batch(omc_ctx* c, omc_mlp_job* jobs, int n, int hidden, 
                             "minibatches of at most 8192 rows, 32 x 2).");
         const int64_t nb = (j.n_rows + j.batch - 1) / j.batch;
         if (nb > max_steps) max_steps = nb;
-        if (j.batch > max_batch) max_batch = j.batch;
+        // every network runs the kernel its own omc_mlp_train_epoch call runs (16-row tiles up to q16_rows rows)
+        if (j.batch <= q16_rows) max_batch16 = std::max<int64_t>(max_batch16, j.batch);
+        else max_batch32 = std::max<int64_t>(max_batch32, j.batch);
+        part_bytes = std::max(part_bytes, omc::mlp_partial_bytes(hidden, layers, j.batch));
         if (j.step + nb > last_step) last_step = j.step + nb;
     }
     if (max_steps > 0x7fffffff) return fail(-3, "too many steps per epoch.");
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t pb = up(omc::mlp_partial_bytes(hidden, layers, max_batch)), wb = up(omc::mlp_wt_bytes(hidden, layers) + 16);
+    const size_t pb = up(part_bytes), wb = up(omc::mlp_wt_bytes(hidden, layers) + 16);
     const size_t lb = up(sizeof(double) * (size_t)n);
     if ((rc = c->mb_slab.ensure(lb + (pb + wb) * (size_t)n))) return rc;
     if ((rc = c->mb_table.ensure(omc::mlp_batch_table_bytes(n)))) return rc;
@@ -2366,13 +2428,14 @@ int omc_mlp_train_epoch_batch(omc_ctx* c, omc_mlp_job* jobs, int n, int hidden, 
         b.wt = (float*)(slab + lb + (pb + wb) * (size_t)i + pb);
         b.loss_acc = loss + i;
         b.lr = jobs[i].lr; b.seed = jobs[i].seed; b.shuffle_key = jobs[i].shuffle_key;
+        b.allow_q16 = true;
     }
     c->h_table.resize(omc::mlp_batch_table_bytes(n));
     omc::mlp_batch_table_image(hj.data(), n, hidden, layers, beta1, beta2, eps, weight_decay, dropout, c->h_table.data());
     HIP_TRY(hipMemcpyAsync(c->mb_table.p, c->h_table.data(), c->h_table.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(loss, 0, sizeof(double) * (size_t)n, c->stream));
-    const int max_tiles = (int)((max_batch + 31) / 32);
-    HIP_TRY(omc::mlp_train_epoch_batch(c->stream, c->mb_table.p, n, hidden, layers, max_steps, max_tiles,
+    HIP_TRY(omc::mlp_train_epoch_batch(c->stream, c->mb_table.p, n, hidden, layers, max_steps, (int)((max_batch32 + 31) / 32),
+                                       (int)((max_batch16 + 15) / 16),
                                        (const double*)c->mb_bc.p, (const double*)c->mb_bc.p + c->mb_bc_cap));
     c->h_bres.resize((size_t)n);
     HIP_TRY(hipMemcpyAsync(c->h_bres.data(), loss, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));

@@ -151,6 +151,9 @@ struct MlpTrainPlan {
     uint64_t seed;         // dropout bits
     uint64_t shuffle_key;  // 0: rows in storage order; else a keyed pseudo-random permutation
     bool wt_current = false;  // `wt` already mirrors `params` (the Adam kernel of an earlier call kept it so)
+    // minibatches of up to kMlpQ16MaxRows rows may run in 16-row tiles (mlp_train_q16_kernel).  The NN regressor's entry
+    // points say yes; the per-step ContNet flow (single and batched, which must agree bit for bit) keeps the 32-row kernel
+    bool allow_q16 = false;
     // Sharded training (one rank of a job, omc_mlp_train_epoch_sharded): `data` holds THIS rank's rows of the epoch,
     // already in epoch order; step k trains on rows [step_off[k], step_off[k + 1]) of it -- this rank's part of the
     // global minibatch k, which has min(batch, rows_global - k * batch) rows over all ranks -- scales by the GLOBAL
@@ -174,13 +177,17 @@ struct MlpBatchJob {
     double lr;
     uint64_t seed, shuffle_key;
     const double* nrows_dev = nullptr;  // non-null: nrows = batch = the double stored there (set size counted on the device)
+    bool allow_q16 = false;             // as MlpTrainPlan::allow_q16: the kernel a single omc_mlp_train_epoch call would run
 };
 size_t mlp_batch_table_bytes(int n);
 bool mlp_batch_supported(int hidden, int layers, int64_t batch);
 void mlp_batch_table_image(const MlpBatchJob* jobs, int n, int hidden, int layers, double beta1, double beta2, double eps,
                            double weight_decay, double dropout, void* out);
+// max_tiles32 / max_tiles16: the largest minibatch among the problems that run in 32-row / in 16-row tiles (0: none)
 hipError_t mlp_train_epoch_batch(hipStream_t st, const void* table_dev, int n, int hidden, int layers, int64_t max_steps,
-                                 int max_tiles, const double* bc1_dev, const double* bc2_dev);
+                                 int max_tiles32, int max_tiles16, const double* bc1_dev, const double* bc2_dev);
+// rows up to which a minibatch of this width runs in 16-row tiles (0: never; OMC_MLP_Q16 moves it)
+int64_t mlp_q16_rows(int hidden);
 // one full-batch step for every problem of the table (two hidden layers; the per-step ContNet flow), grid_tiles
 // workgroups per problem walking its tiles
 // tile_prefix_dev != null: work-list launch -- grid_tiles workgroups IN TOTAL share all problems' tiles evenly
@@ -209,9 +216,8 @@ hipError_t localvol_paths(hipStream_t st, float* S, int64_t ld, int64_t M, int N
                           double tau_scale, double eps_out);
 // pass 1 of the NN flow straight from the path matrix (omc_rows.hip): count -> scan -> statistics -> rows
 size_t nn_rows_scratch_bytes(int64_t M, int N);
-hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const int64_t** total_dev);
-hipError_t nn_rows_stats(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, int pass,
-                         const double* mean_host, double* sums_host);
+hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const int64_t** total_dev,
+                         bool with_stats = false, const double** stats_dev = nullptr);
 hipError_t nn_rows_write(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const double* feat_mean,
                          const double* feat_std, double y_mean, double y_std, float* data, int64_t cap);
 // float64 means / population variances of the regression features and the target over n rows

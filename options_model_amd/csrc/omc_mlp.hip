@@ -1402,7 +1402,7 @@ __device__ __forceinline__ void relu_dropout_q16(v4f16 (&z)[2], uint32_t row, ui
 }
 
 template <int H, int L>
-__global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
+__device__ __forceinline__ void mlp_train_q16_body(const MlpQuadArgs& a, const int tile)
 {
     constexpr int W = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H, NQ = H / 16, KS = H / 4;
     __shared__ __attribute__((aligned(16))) float sAct[L][H * 16];  // H_j, [k / 4][16 rows][k % 4]
@@ -1410,7 +1410,6 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
     __shared__ float sX[8 * 16];                                    // inputs [in][row] (row 7 = the bias column of ones)
     __shared__ float sO[W * 16];                                    // per-wave partial outputs
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x;
     if (tile >= a.ntiles) return;
     float* out = a.partial + (size_t)tile * a.pstride;
     const float* Wo = a.params + H * 8 + (L - 1) * CONN;
@@ -1646,6 +1645,12 @@ __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
     }
 }
 
+template <int H, int L>
+__global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
+{
+    mlp_train_q16_body<H, L>(a, blockIdx.x);
+}
+
 // ---- many small networks trained side by side (the curve entry points: one net per curve point) ----------------
 // One table row per problem; blockIdx.y = problem, the step index within the epoch is a kernel argument.  A
 // workgroup builds its problem's argument block exactly as quad_steps() does on the host (same float conversions:
@@ -1665,7 +1670,7 @@ struct MlpBatchProb {
     Shuffle shuf;
     uint32_t keep16, k0, k1;
     float inv_keep;
-    int pstride, pad;
+    int pstride, q16_rows;  // q16_rows: minibatches of up to so many rows run in 16-row tiles (0: never)
     // non-null: the set size lives in device memory (the per-step ContNet flow: the regression set of the step,
     // counted by the kernels right before): nrows = batch = (int64_t)*nrows_dev, read when the kernel runs
     const double* nrows_dev;
@@ -1681,16 +1686,20 @@ __device__ __forceinline__ void batch_rows(const MlpBatchProb& p, int64_t* nrows
     }
 }
 
-template <int H, int L>
+// Q16: this launch serves the problems whose minibatch runs in 16-row tiles (the kernel their single call runs,
+// mlp_train_kernel_choice); the others leave at once -- and the other way round in the 32-row launch.
+template <int H, int L, bool Q16 = false>
 __global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBatchProb* __restrict__ tab, int s,
                                                                      int step_base)
 {
     const MlpBatchProb& p = tab[blockIdx.y];
     int64_t nrows, batch;
     batch_rows(p, &nrows, &batch);
+    if ((batch <= (int64_t)p.q16_rows) != Q16) return;
     const int64_t o = (int64_t)s * batch;
     if (o >= nrows) return;
     const int64_t nb = (nrows - o < batch) ? nrows - o : batch;
+    constexpr int kRows = Q16 ? 16 : 32;
     MlpQuadArgs a;
     a.data = p.data;
     a.params = p.params;
@@ -1699,7 +1708,7 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBa
     a.row0 = o;
     a.nrows = nb;
     a.shuf = p.shuf;
-    a.ntiles = (int)((nb + 31) / 32);
+    a.ntiles = (int)((nb + kRows - 1) / kRows);
     a.pstride = p.pstride;
     a.two_over_b = (float)(2.0 / (double)nb);
     a.keep16 = p.keep16;
@@ -1707,7 +1716,8 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBa
     a.step = (uint32_t)(p.first_step + step_base + s + 1);
     a.k0 = p.k0;
     a.k1 = p.k1;
-    mlp_train_quad_body<H, L>(a, blockIdx.x);  // (the grid covers the largest problem's tiles)
+    if constexpr (Q16) mlp_train_q16_body<H, L>(a, blockIdx.x);  // (the grid covers the largest problem's tiles)
+    else mlp_train_quad_body<H, L>(a, blockIdx.x);
 }
 
 // Work-list form of the same launch for batches whose problems differ wildly in size (the per-step ContNet flow of
@@ -1812,7 +1822,7 @@ __global__ __launch_bounds__(256) void mlp_adam_batch_kernel(const MlpBatchProb*
     b.v = p.v;
     b.partial = p.partial;
     b.loss_acc = p.loss_acc;
-    b.nparts = (int)((nb + 31) / 32);
+    b.nparts = batch <= (int64_t)p.q16_rows ? (int)((nb + 15) / 16) : (int)((nb + 31) / 32);  // one partial per tile
     b.nparams = mlp_params_of(H, L);
     b.stride = p.pstride;
     b.wt = p.wt; b.H = H; b.L = L;
@@ -2272,14 +2282,19 @@ static int mlp_train_kernel_choice32(int hidden, int layers, int64_t batch)
     return 0;
 }
 
+// 16-row tiles while a minibatch leaves most of the chip idle (kMlpQ16MaxRows rows = 64 workgroups): the reference's
+// own min(256, R).  OMC_MLP_Q16=0 switches them off, =N moves the limit to N rows (A/B measurements).
+int64_t mlp_q16_rows(int hidden)
+{
+    static const int q16 = getenv("OMC_MLP_Q16") ? atoi(getenv("OMC_MLP_Q16")) : -1;
+    if (hidden != 64 && hidden != 128) return 0;
+    return q16 < 0 ? kMlpQ16MaxRows : q16;
+}
+
 int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
 {
     const int c = mlp_train_kernel_choice32(hidden, layers, batch);
-    // 16-row tiles while a minibatch leaves most of the chip idle (kMlpQ16MaxRows rows = 64 workgroups): the reference's
-    // own min(256, R).  OMC_MLP_Q16=0 switches them off, =N moves the limit to N rows (A/B measurements).
-    static const int q16 = getenv("OMC_MLP_Q16") ? atoi(getenv("OMC_MLP_Q16")) : -1;
-    const int64_t lim = q16 < 0 ? kMlpQ16MaxRows : q16;
-    if (c == 3 && (hidden == 64 || hidden == 128) && batch <= lim) return 4;
+    if (c == 3 && batch <= mlp_q16_rows(hidden)) return 4;
     return c;
 }
 
@@ -2680,7 +2695,8 @@ int64_t mlp_plan_kernel_batch(const MlpTrainPlan& t)
 
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
 {
-    const int choice = mlp_train_kernel_choice(t.hidden, t.layers, mlp_plan_kernel_batch(t));
+    int choice = mlp_train_kernel_choice(t.hidden, t.layers, mlp_plan_kernel_batch(t));
+    if (choice == 4 && !t.allow_q16) choice = 3;  // (4 is only ever returned where 3 applies)
     if (choice == 1) return t.layers == 2 ? train_steps<2>(st, t) : train_steps<3>(st, t);
     if (choice == 2) {
         if (t.hidden == 64) return t.layers == 2 ? tile_steps<64, 2>(st, t) : tile_steps<64, 3>(st, t);
@@ -2724,20 +2740,29 @@ void mlp_batch_table_image(const MlpBatchJob* jobs, int n, int hidden, int layer
         p.k0 = (uint32_t)j.seed;
         p.k1 = (uint32_t)(j.seed >> 32);
         p.pstride = hidden == 32 ? tile_pstride(32, 2) : (hidden == 64 ? tile_pstride(64, layers) : tile_pstride(128, layers));
+        p.q16_rows = j.allow_q16 ? (int)mlp_q16_rows(hidden) : 0;
         p.nrows_dev = j.nrows_dev;
     }
 }
 
 template <int H, int L>
-static hipError_t batch_epoch(hipStream_t st, const MlpBatchProb* tab, int n, int64_t max_steps, int max_tiles,
-                              const double* bc1, const double* bc2)
+static hipError_t batch_epoch(hipStream_t st, const MlpBatchProb* tab, int n, int64_t max_steps, int max_tiles32,
+                              int max_tiles16, const double* bc1, const double* bc2)
 {
     hipLaunchKernelGGL(mlp_transpose_batch_kernel, dim3(16, n), dim3(256), 0, st, tab, H, L);
     const bool flat = n >= 8;
-    const dim3 gq((unsigned)max_tiles, (unsigned)n),
-        ga((unsigned)(flat ? (mlp_params_of(H, L) + 256) / 256 : (mlp_params_of(H, L) + 16) / 16), (unsigned)n);
+    const dim3 ga((unsigned)(flat ? (mlp_params_of(H, L) + 256) / 256 : (mlp_params_of(H, L) + 16) / 16), (unsigned)n);
     for (int64_t s = 0; s < max_steps; ++s) {
-        hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L>), gq, dim3(H * 2), 0, st, tab, (int)s, 0);
+        // every problem runs the kernel its own omc_mlp_train_epoch call runs: one launch for the problems in 32-row
+        // tiles, one for those in 16-row tiles (a curve's points normally all share the reference's minibatch of 256)
+        if (max_tiles32 > 0)
+            hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L, false>), dim3((unsigned)max_tiles32, (unsigned)n), dim3(H * 2), 0,
+                               st, tab, (int)s, 0);
+        if constexpr (H >= 64) {
+            if (max_tiles16 > 0)
+                hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L, true>), dim3((unsigned)max_tiles16, (unsigned)n), dim3(H * 2),
+                                   0, st, tab, (int)s, 0);
+        }
         if (flat) hipLaunchKernelGGL(mlp_adam_batch_kernel<true>, ga, dim3(256), 0, st, tab, (int)s, 0, H, L, bc1, bc2);
         else hipLaunchKernelGGL(mlp_adam_batch_kernel<false>, ga, dim3(256), 0, st, tab, (int)s, 0, H, L, bc1, bc2);
     }
@@ -2755,7 +2780,7 @@ static hipError_t batch_one_step(hipStream_t st, const MlpBatchProb* tab, int n,
     const dim3 gq((unsigned)grid_tiles, (unsigned)n),
         ga((unsigned)(flat ? (mlp_params_of(H, L) + 256) / 256 : (mlp_params_of(H, L) + 16) / 16), (unsigned)n);
     if (prefix) hipLaunchKernelGGL((mlp_train_quad_list_kernel<H, L>), dim3((unsigned)grid_tiles), dim3(H * 2), 0, st, tab, prefix, n, step_base);
-    else hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L>), gq, dim3(H * 2), 0, st, tab, 0, step_base);
+    else hipLaunchKernelGGL((mlp_train_quad_batch_kernel<H, L, false>), gq, dim3(H * 2), 0, st, tab, 0, step_base);
     if (flat) hipLaunchKernelGGL(mlp_adam_batch_kernel<true>, ga, dim3(256), 0, st, tab, 0, step_base, H, L, bc1, bc2);
     else hipLaunchKernelGGL(mlp_adam_batch_kernel<false>, ga, dim3(256), 0, st, tab, 0, step_base, H, L, bc1, bc2);
     return hipGetLastError();
@@ -2778,14 +2803,15 @@ hipError_t mlp_tile_prefix(hipStream_t st, const void* table_dev, int n, int* pr
 }
 
 hipError_t mlp_train_epoch_batch(hipStream_t st, const void* table_dev, int n, int hidden, int layers, int64_t max_steps,
-                                 int max_tiles, const double* bc1_dev, const double* bc2_dev)
+                                 int max_tiles32, int max_tiles16, const double* bc1_dev, const double* bc2_dev)
 {
     const MlpBatchProb* tab = (const MlpBatchProb*)table_dev;
-    if (hidden == 32 && layers == 2) return batch_epoch<32, 2>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev);
-    if (hidden == 64) return layers == 2 ? batch_epoch<64, 2>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev)
-                                         : batch_epoch<64, 3>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev);
-    if (hidden == 128) return layers == 2 ? batch_epoch<128, 2>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev)
-                                          : batch_epoch<128, 3>(st, tab, n, max_steps, max_tiles, bc1_dev, bc2_dev);
+    const int t32 = max_tiles32, t16 = max_tiles16;
+    if (hidden == 32 && layers == 2) return batch_epoch<32, 2>(st, tab, n, max_steps, t32, 0, bc1_dev, bc2_dev);
+    if (hidden == 64) return layers == 2 ? batch_epoch<64, 2>(st, tab, n, max_steps, t32, t16, bc1_dev, bc2_dev)
+                                         : batch_epoch<64, 3>(st, tab, n, max_steps, t32, t16, bc1_dev, bc2_dev);
+    if (hidden == 128) return layers == 2 ? batch_epoch<128, 2>(st, tab, n, max_steps, t32, t16, bc1_dev, bc2_dev)
+                                          : batch_epoch<128, 3>(st, tab, n, max_steps, t32, t16, bc1_dev, bc2_dev);
     return hipErrorInvalidValue;
 }
 

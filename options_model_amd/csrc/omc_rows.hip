@@ -2,8 +2,15 @@
 // (step, path) of a device path matrix becomes one training row [7 normalised features, normalised
 // target], in the reference's order (steps N-1 down to 1, paths ascending within a step), with the
 // normalisers (feature means / population stds, target mean / std; zero std -> 1) computed on the
-// way.  Nothing but the row matrix itself is materialised: counts -> scan -> two statistics passes
-// over S -> one write pass, each a streaming read of S.
+// way.  Nothing but the row matrix itself is materialised: ONE sweep over S counts the rows of every (step, tile) and
+// forms the statistics (round 5; until then: count, sums, squared deviations = three sweeps), a scan turns the counts
+// into row offsets, one more sweep writes the rows.
+// The statistics are the reference's two-pass mean / population variance (:550-563) computed in one pass without its
+// cancellation problem: a thread accumulates sums of d = f - c and d^2 around ITS OWN first row's values c (so a
+// constant column has d = 0 exactly: variance exactly 0, and the std-0 -> 1 rule of :562 sees a true zero), turns them
+// into (n, mean, M2 = sum (f - mean)^2), and the triples are merged pairwise by Chan's formula -- the one the reference
+// itself uses for its streaming European pricer (:33-49) -- in a fixed tree order: bitwise reproducible, float64
+// throughout, agreeing with the two-pass values to ~1e-15 relative.
 #include "omc_device.h"
 #include "omc_kernels.h"
 
@@ -129,56 +136,155 @@ __device__ __forceinline__ void row_values(double sd, double payN, double K, dou
     f[7] = 1.0;
 }
 
-// PASS 0: sums of the 7 quantities (+ count in slot 7); PASS 1: squared deviations from `mean`
-template <int PASS>
-__global__ __launch_bounds__(kBlock) void rows_stats_kernel(RowsArgs a, const double* __restrict__ mean,
-                                                            double* __restrict__ part, int pstride)
+// ---- (n, mean[7], M2[7]) triples and their merge
+constexpr int kTrip = 16;  // doubles per stored triple: n, mean[7], M2[7], pad
+struct Trip {
+    double n, mean[7], m2[7];
+};
+
+// Chan / Golub / LeVeque: b merged into a.  A side without rows leaves the other untouched.
+__device__ __forceinline__ void trip_merge(Trip& a, const Trip& b)
 {
-    __shared__ double red[kNQ * kRedStride];
-    extern __shared__ double sst[];  // s_t = sqrt(max(T - t dt, 1e-6)), t = 0 .. N
-    for (int t = threadIdx.x; t <= a.N; t += kBlock) sst[t] = sqrt(fmax(a.T - (double)t * a.dt, 1e-6));
-    __syncthreads();
-    double acc[8], mu[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        acc[q] = 0.0;
-        mu[q] = PASS ? mean[q] : 0.0;
+    if (b.n == 0.0) return;
+    if (a.n == 0.0) {
+        a = b;
+        return;
     }
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < a.M; p += stride) {
-        const float* col = a.S + p;
-        const double pn = payoff_d(col[(int64_t)a.N * a.ld], a.K, a.is_put);
-        const double payN = pn > 0.0 ? pn : 0.0;
-        for (int t = a.N - 1; t >= 1; --t) {
-            const float s = col[(int64_t)t * a.ld];
-            if (!itm(s, a.K, a.is_put)) continue;
-            double f[8];
-            row_values((double)s, payN, a.K, sst[t], a.D[a.N - t], f);
+    const double n = a.n + b.n, wb = b.n / n, wab = a.n * wb;
 #pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                const double d = f[q] - mu[q];
-                acc[q] += PASS ? d * d : d;
-            }
-            acc[7] += 1.0;
-        }
+    for (int q = 0; q < 7; ++q) {
+        const double delta = b.mean[q] - a.mean[q];
+        a.mean[q] += delta * wb;
+        a.m2[q] += b.m2[q] + delta * delta * wab;
     }
-    const double r = block_reduce8(acc, red);
-    if (threadIdx.x < 64 && (threadIdx.x & 7) == 0) part[(size_t)(threadIdx.x >> 3) * pstride + blockIdx.x] = r;
+    a.n = n;
 }
 
-// part[q][0..nblk) summed in index order -> out[q]
-__global__ __launch_bounds__(kBlock) void rows_finish_kernel(const double* part, int nblk, int pstride, double* out)
+// the workgroup's 256 triples -> thread 0's, by a fixed binary tree through LDS (lds: kBlock x kTrip doubles)
+__device__ __forceinline__ void trip_block_merge(Trip& t, double* lds)
 {
-    __shared__ double red[kNQ * kRedStride];
-    double acc[8];
+    const int tid = threadIdx.x;
+    double* mine = lds + (size_t)tid * kTrip;
+    mine[0] = t.n;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += kBlock) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += part[(size_t)q * pstride + i];
+    for (int q = 0; q < 7; ++q) {
+        mine[1 + q] = t.mean[q];
+        mine[8 + q] = t.m2[q];
     }
-    const double r = block_reduce8(acc, red);
-    if (threadIdx.x < 64 && (threadIdx.x & 7) == 0) out[threadIdx.x >> 3] = r;
+    __syncthreads();
+    for (int stride = kBlock / 2; stride >= 1; stride >>= 1) {
+        if (tid < stride) {
+            const double* o = lds + (size_t)(tid + stride) * kTrip;
+            Trip b;
+            b.n = o[0];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                b.mean[q] = o[1 + q];
+                b.m2[q] = o[8 + q];
+            }
+            trip_merge(t, b);
+            mine[0] = t.n;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                mine[1 + q] = t.mean[q];
+                mine[8 + q] = t.m2[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ONE sweep: cnt[(N-1-t) * ntiles + tile] as rows_count_kernel, and the workgroup's (n, mean, M2) triple of the seven
+// quantities [x, x^2, x^3, max(x-1,0), s, x*s, y] over its in-the-money (step, path) pairs -> part[wg][kTrip]
+__global__ __launch_bounds__(kBlock) void rows_count_stats_kernel(RowsArgs a, int32_t* __restrict__ cnt, double* __restrict__ part)
+{
+    __shared__ int wsum[kBlock / 64];
+    __shared__ double lds[kBlock * kTrip];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int64_t p = (int64_t)tile * kBlock + tid;
+    const bool live = p < a.M;
+    const float* col = a.S + (live ? p : 0);
+    const double pn = payoff_d(col[(int64_t)a.N * a.ld], a.K, a.is_put);
+    const double payN = pn > 0.0 ? pn : 0.0;
+    const int t0 = 1 + blockIdx.y * a.tchunk, t1 = min(t0 + a.tchunk, a.N);
+    double c[7], sd[7], sq[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) c[q] = sd[q] = sq[q] = 0.0;
+    double n = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const float s = col[(int64_t)t * a.ld];
+        const bool f = live && itm(s, a.K, a.is_put);
+        const int wc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
+        if (lane == 0) wsum[wave] = wc;
+        __syncthreads();
+        if (tid == 0) cnt[(size_t)(a.N - 1 - t) * a.ntiles + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        if (!f) continue;
+        double v[8];
+        row_values((double)s, payN, a.K, sqrt(fmax(a.T - (double)t * a.dt, 1e-6)), a.D[a.N - t], v);
+        if (n == 0.0) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) c[q] = v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const double d = v[q] - c[q];
+            sd[q] += d;
+            sq[q] = __builtin_fma(d, d, sq[q]);
+        }
+        n += 1.0;
+    }
+    Trip tr;
+    tr.n = n;
+    const double inv = n > 0.0 ? 1.0 / n : 0.0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        tr.mean[q] = c[q] + sd[q] * inv;
+        const double m2 = sq[q] - sd[q] * sd[q] * inv;
+        tr.m2[q] = m2 > 0.0 ? m2 : 0.0;
+    }
+    trip_block_merge(tr, lds);
+    if (tid == 0) {
+        double* o = part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kTrip;
+        o[0] = tr.n;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            o[1 + q] = tr.mean[q];
+            o[8 + q] = tr.m2[q];
+        }
+    }
+}
+
+// part[0 .. nwg) -> out[kTrip]: thread i folds partials i, i + 256, ... in index order, then the same tree
+__global__ __launch_bounds__(kBlock) void rows_merge_kernel(const double* __restrict__ part, int nwg, double* __restrict__ out)
+{
+    __shared__ double lds[kBlock * kTrip];
+    Trip t;
+    t.n = 0.0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) t.mean[q] = t.m2[q] = 0.0;
+    for (int i = threadIdx.x; i < nwg; i += kBlock) {
+        const double* o = part + (size_t)i * kTrip;
+        Trip b;
+        b.n = o[0];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            b.mean[q] = o[1 + q];
+            b.m2[q] = o[8 + q];
+        }
+        trip_merge(t, b);
+    }
+    trip_block_merge(t, lds);
+    if (threadIdx.x == 0) {
+        out[0] = t.n;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            out[1 + q] = t.mean[q];
+            out[8 + q] = t.m2[q];
+        }
+        out[15] = 0.0;
+    }
 }
 
 struct RowsNorm {
@@ -232,14 +338,19 @@ __global__ __launch_bounds__(kBlock) void rows_write_kernel(RowsArgs a, RowsNorm
 
 }  // namespace
 
+static size_t rows_nwg(int64_t M, int N, int tchunk)
+{
+    return (size_t)((M + kBlock - 1) / kBlock) * (size_t)((N - 1 + tchunk - 1) / tchunk > 0 ? (N - 1 + tchunk - 1) / tchunk : 1);
+}
+
 size_t nn_rows_scratch_bytes(int64_t M, int N)
 {
     const size_t n = (size_t)(N - 1 > 0 ? N - 1 : 0) * (size_t)((M + kBlock - 1) / kBlock);
-    return sizeof(int64_t) * (n + 2) + sizeof(int32_t) * (n + 2) + sizeof(double) * (8 * 1024 + 32);
+    return sizeof(int64_t) * (n + 2) + sizeof(int32_t) * (n + 2) + sizeof(double) * (kTrip * (rows_nwg(M, N, 32) + 2) + 32);
 }
 
-// scratch layout: offs int64[n+1] | cnt int32[n] | part double[8][1024] | out double[16]
-static void carve(void* scratch, size_t n, int64_t** offs, int32_t** cnt, double** part, double** out)
+// scratch layout: offs int64[n+1] | cnt int32[n] | part double[nwg][kTrip] | out double[kTrip]
+static void carve(void* scratch, size_t n, size_t nwg, int64_t** offs, int32_t** cnt, double** part, double** out)
 {
     char* b = (char*)scratch;
     *offs = (int64_t*)b;
@@ -247,7 +358,7 @@ static void carve(void* scratch, size_t n, int64_t** offs, int32_t** cnt, double
     *cnt = (int32_t*)b;
     b += (sizeof(int32_t) * (n + 2) + 7) / 8 * 8;
     *part = (double*)b;
-    *out = *part + 8 * 1024;
+    *out = *part + kTrip * (nwg + 1);
 }
 
 static RowsArgs make_args(const LsmProblem& p, const double* D)
@@ -260,17 +371,26 @@ static RowsArgs make_args(const LsmProblem& p, const double* D)
     return a;
 }
 
-// counts + scan; *total_dev points at the device int64 holding R afterwards
-hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const int64_t** total_dev)
+// counts + scan; *total_dev points at the device int64 holding R afterwards.  with_stats: the same sweep also forms the
+// statistics, *stats_dev then points at 16 device doubles: n, mean[7], M2[7] (sum of squared deviations) of
+// [x, x^2, x^3, max(x-1,0), s, x*s, y].
+hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const int64_t** total_dev,
+                         bool with_stats, const double** stats_dev)
 {
     const RowsArgs a = make_args(p, D);
-    const size_t n = (size_t)(p.N - 1) * a.ntiles;
+    const size_t n = (size_t)(p.N - 1) * a.ntiles, nwg = rows_nwg(p.M, p.N, a.tchunk);
     int64_t* offs; int32_t* cnt; double *part, *out;
-    carve(scratch, n, &offs, &cnt, &part, &out);
-    if (n > 0)
-        hipLaunchKernelGGL(rows_count_kernel, dim3(a.ntiles, (p.N - 1 + a.tchunk - 1) / a.tchunk), dim3(kBlock), 0, st,
-                           a, cnt);
+    carve(scratch, n, nwg, &offs, &cnt, &part, &out);
+    const dim3 grid(a.ntiles, (p.N - 1 + a.tchunk - 1) / a.tchunk);
+    if (n > 0) {
+        if (with_stats) hipLaunchKernelGGL(rows_count_stats_kernel, grid, dim3(kBlock), 0, st, a, cnt, part);
+        else hipLaunchKernelGGL(rows_count_kernel, grid, dim3(kBlock), 0, st, a, cnt);
+    }
     hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int64_t)n, offs);
+    if (with_stats) {
+        hipLaunchKernelGGL(rows_merge_kernel, dim3(1), dim3(kBlock), 0, st, part, n > 0 ? (int)(grid.x * grid.y) : 0, out);
+        *stats_dev = out;
+    }
     *total_dev = offs + n;
     return hipGetLastError();
 }
@@ -289,31 +409,6 @@ hipError_t nn_rows_half_counts(hipStream_t st, const LsmProblem& p, int64_t half
     return hipGetLastError();
 }
 
-// PASS 0 -> sums_host[0..7] (slot 7 = row count); PASS 1 (mean_host[0..7]) -> squared deviations.
-// Synchronises the stream (the 8 results go back to the host).
-hipError_t nn_rows_stats(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, int pass,
-                         const double* mean_host, double* sums_host)
-{
-    const RowsArgs a = make_args(p, D);
-    const size_t n = (size_t)(p.N - 1) * a.ntiles;
-    int64_t* offs; int32_t* cnt; double *part, *out;
-    carve(scratch, n, &offs, &cnt, &part, &out);
-    int nblk = (int)((p.M + kBlock - 1) / kBlock);
-    nblk = nblk > 1024 ? 1024 : nblk;
-    const size_t dyn = sizeof(double) * (size_t)(p.N + 1);
-    hipError_t e;
-    if (pass == 0) {
-        hipLaunchKernelGGL(rows_stats_kernel<0>, dim3(nblk), dim3(kBlock), dyn, st, a, (const double*)nullptr, part, 1024);
-    } else {
-        if ((e = hipMemcpyAsync(out + 16, mean_host, sizeof(double) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-        hipLaunchKernelGGL(rows_stats_kernel<1>, dim3(nblk), dim3(kBlock), dyn, st, a, (const double*)(out + 16), part, 1024);
-    }
-    hipLaunchKernelGGL(rows_finish_kernel, dim3(1), dim3(kBlock), 0, st, part, nblk, 1024, out);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(sums_host, out, sizeof(double) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    return hipStreamSynchronize(st);
-}
-
 hipError_t nn_rows_write(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const double* feat_mean,
                          const double* feat_std, double y_mean, double y_std, float* data, int64_t cap)
 {
@@ -321,7 +416,7 @@ hipError_t nn_rows_write(hipStream_t st, const LsmProblem& p, const double* D, v
     const size_t n = (size_t)(p.N - 1) * a.ntiles;
     if (n == 0) return hipSuccess;
     int64_t* offs; int32_t* cnt; double *part, *out;
-    carve(scratch, n, &offs, &cnt, &part, &out);
+    carve(scratch, n, rows_nwg(p.M, p.N, a.tchunk), &offs, &cnt, &part, &out);
     RowsNorm nm;
     for (int i = 0; i < 7; ++i) {
         nm.fm[i] = feat_mean[i];

@@ -85,6 +85,11 @@ bench)  # the driver's command, then every config's line, then rocprofv3 kernel 
   prof c5 "$R/bench.py" --config c5 --steps 2 --warmup 1 || exit 1
   prof c1nn "$R/bench.py" --config c1nn --steps 5 --warmup 2 || exit 1
   ;;
+nn)  # the NN flow's tests + the multi-rank files (rows sweep, dropout oracle, K vote)
+  timeout -k 10 1100 python -m pytest tests/test_gpu_nn.py tests/test_gpu_nn_full.py tests/test_gpu_dropout.py tests/test_gpu_nn_curve.py tests/test_gpu_nn_dist.py tests/test_gpu_multirank.py tests/test_gpu_facade_ranks.py tests/test_gpu_dist.py -q --durations=12 -s > gpurun_out/${TAG}_nn_tests.log 2>&1; rc=$?
+  grep -v "^\.*$" gpurun_out/${TAG}_nn_tests.log | tail -60; echo "pytest exit=$rc"; ok $rc || exit 1
+  timeout -k 10 300 python tools/time_c5.py > gpurun_out/${TAG}_c5.json 2> gpurun_out/${TAG}_c5.err; cat gpurun_out/${TAG}_c5.json | cut -c1-700
+  ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
   tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
