@@ -30,67 +30,88 @@ struct RowsArgs {
 
 __device__ __forceinline__ bool itm(float s, double K, int is_put) { return payoff_d(s, K, is_put) > 0.0; }
 
+constexpr int kTChunk = 32;  // time steps per workgroup of the three sweeps (RowsArgs::tchunk)
+
+// A thread's spots of the chunk's time steps, ALL requested before the first is used: the loops below synchronise the
+// workgroup twice per time step (the tile's count / ranks), and a load issued inside such a loop is waited for on the
+// spot -- one HBM latency per time step, 32 per workgroup (round 5 profile: the count sweep ran at 2.7 TB/s, the fused
+// statistics sweep at 0.8).
+__device__ __forceinline__ void load_chunk(const float* col, int64_t ld, int t0, int t1, float (&sv)[kTChunk])
+{
+#pragma unroll
+    for (int i = 0; i < kTChunk; ++i) sv[i] = t0 + i < t1 ? __builtin_nontemporal_load(col + (int64_t)(t0 + i) * ld) : 0.0f;
+}
+
 // cnt[(N-1-t) * ntiles + tile] = in-the-money paths of the tile at step t  (t = 1 .. N-1)
 __global__ __launch_bounds__(kBlock) void rows_count_kernel(RowsArgs a, int32_t* __restrict__ cnt)
 {
-    __shared__ int wsum[kBlock / 64];
+    __shared__ int wsum[kTChunk][kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int64_t p = (int64_t)tile * kBlock + tid;
     const bool live = p < a.M;
     const float* col = a.S + (live ? p : 0);
-    const int t0 = 1 + blockIdx.y * a.tchunk, t1 = min(t0 + a.tchunk, a.N);
-    for (int t = t0; t < t1; ++t) {
-        const bool f = live && itm(col[(int64_t)t * a.ld], a.K, a.is_put);
+    const int t0 = 1 + blockIdx.y * kTChunk, t1 = min(t0 + kTChunk, a.N);
+    float sv[kTChunk];
+    load_chunk(col, a.ld, t0, t1, sv);
+#pragma unroll
+    for (int i = 0; i < kTChunk; ++i) {
+        const bool f = live && t0 + i < t1 && itm(sv[i], a.K, a.is_put);
         const int wc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
-        if (lane == 0) wsum[wave] = wc;
-        __syncthreads();
-        if (tid == 0) cnt[(size_t)(a.N - 1 - t) * a.ntiles + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
+        if (lane == 0) wsum[i][wave] = wc;
     }
+    __syncthreads();
+    if (tid < t1 - t0) cnt[(size_t)(a.N - 1 - (t0 + tid)) * a.ntiles + tile] = wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
 }
 
-// exclusive prefix of cnt[0..n) into offs[0..n), total into offs[n]; one workgroup of 1024 threads.
-// The array is walked in tiles of 1024 x 8 counts: a thread owns 8 CONSECUTIVE counts of the tile (a wave reads 2 KB
-// contiguous), scans them in registers, the workgroup scans the 1024 thread sums through LDS and a running carry links
-// the tiles.  (Until round 4 every thread walked its own contiguous 1/1024 of the array: two passes of fully
-// uncoalesced loads, 2.6 ms for config 5's 980k counts; integer sums, so the result is the same.)
-__global__ __launch_bounds__(1024) void rows_scan_kernel(const int32_t* __restrict__ cnt, int64_t n,
-                                                         int64_t* __restrict__ offs)
+// Exclusive prefix of counts, one workgroup of 1024 threads per SEGMENT: workgroup b scans cnt[b * seg .. b * seg + len)
+// (len = min(seg, n - b * seg)) into offs[same positions] and stores the segment's total in tot[b].  A segment is walked
+// in tiles of 1024 x 8 counts: a thread owns 8 CONSECUTIVE counts of the tile (a wave reads 2 KB contiguous), scans them
+// in registers, the workgroup scans the 1024 thread sums through LDS and a running carry links the tiles.
+// One segment (seg >= n): the flat scan, total also in offs[n].  The row sweeps use TWO levels instead -- one segment per
+// time step, then one more launch over the per-step totals -- because a lone workgroup walking config 5's 980k counts
+// took 1.05 ms (round 5 profile), most of pass 1.
+template <class In>
+__global__ __launch_bounds__(1024) void rows_scan_kernel(const In* __restrict__ cnt, int64_t n, int64_t seg,
+                                                         int64_t* __restrict__ offs, int64_t* __restrict__ tot)
 {
-    __shared__ int64_t seg[1024];
+    __shared__ int64_t part[1024];
     __shared__ int64_t carry_sh;
     const int tid = threadIdx.x;
+    const int64_t first = (int64_t)blockIdx.x * seg, last = first + seg < n ? first + seg : n;
     int64_t carry = 0;
-    for (int64_t base = 0; base < n; base += 1024 * 8) {
+    for (int64_t base = first; base < last; base += 1024 * 8) {
         const int64_t lo = base + (int64_t)tid * 8;
-        int c[8];
+        int64_t c[8];
         int64_t s = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            c[k] = lo + k < n ? cnt[lo + k] : 0;
+            c[k] = lo + k < last ? (int64_t)cnt[lo + k] : 0;
             s += c[k];
         }
-        seg[tid] = s;
+        part[tid] = s;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan of the thread sums
-            const int64_t v = tid >= d ? seg[tid - d] : 0;
+            const int64_t v = tid >= d ? part[tid - d] : 0;
             __syncthreads();
-            seg[tid] += v;
+            part[tid] += v;
             __syncthreads();
         }
-        int64_t run = carry + (tid ? seg[tid - 1] : 0);
+        int64_t run = carry + (tid ? part[tid - 1] : 0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (lo + k < n) offs[lo + k] = run;
+            if (lo + k < last) offs[lo + k] = run;
             run += c[k];
         }
-        if (tid == 1023) carry_sh = carry + seg[1023];
+        if (tid == 1023) carry_sh = carry + part[1023];
         __syncthreads();
         carry = carry_sh;
         __syncthreads();
     }
-    if (tid == 0) offs[n] = carry;
+    if (tid == 0) {
+        if (tot) tot[blockIdx.x] = carry;
+        if (seg >= n) offs[n] = carry;
+    }
 }
 
 // half[(N-1-t) * 2 + h] = in-the-money paths at step t among columns [0, half) (h = 0) / [half, M) (h = 1);
@@ -198,28 +219,29 @@ __device__ __forceinline__ void trip_block_merge(Trip& t, double* lds)
 // quantities [x, x^2, x^3, max(x-1,0), s, x*s, y] over its in-the-money (step, path) pairs -> part[wg][kTrip]
 __global__ __launch_bounds__(kBlock) void rows_count_stats_kernel(RowsArgs a, int32_t* __restrict__ cnt, double* __restrict__ part)
 {
-    __shared__ int wsum[kBlock / 64];
+    __shared__ int wsum[kTChunk][kBlock / 64];
     __shared__ double lds[kBlock * kTrip];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int64_t p = (int64_t)tile * kBlock + tid;
     const bool live = p < a.M;
     const float* col = a.S + (live ? p : 0);
+    const int t0 = 1 + blockIdx.y * kTChunk, t1 = min(t0 + kTChunk, a.N);
+    float sv[kTChunk];
+    load_chunk(col, a.ld, t0, t1, sv);
     const double pn = payoff_d(col[(int64_t)a.N * a.ld], a.K, a.is_put);
     const double payN = pn > 0.0 ? pn : 0.0;
-    const int t0 = 1 + blockIdx.y * a.tchunk, t1 = min(t0 + a.tchunk, a.N);
     double c[7], sd[7], sq[7];
 #pragma unroll
     for (int q = 0; q < 7; ++q) c[q] = sd[q] = sq[q] = 0.0;
     double n = 0.0;
-    for (int t = t0; t < t1; ++t) {
-        const float s = col[(int64_t)t * a.ld];
-        const bool f = live && itm(s, a.K, a.is_put);
+#pragma unroll 4
+    for (int i = 0; i < kTChunk; ++i) {
+        const int t = t0 + i;
+        const float s = sv[i];
+        const bool f = live && t < t1 && itm(s, a.K, a.is_put);
         const int wc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
-        if (lane == 0) wsum[wave] = wc;
-        __syncthreads();
-        if (tid == 0) cnt[(size_t)(a.N - 1 - t) * a.ntiles + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
+        if (lane == 0) wsum[i][wave] = wc;
         if (!f) continue;
         double v[8];
         row_values((double)s, payN, a.K, sqrt(fmax(a.T - (double)t * a.dt, 1e-6)), a.D[a.N - t], v);
@@ -235,6 +257,8 @@ __global__ __launch_bounds__(kBlock) void rows_count_stats_kernel(RowsArgs a, in
         }
         n += 1.0;
     }
+    __syncthreads();
+    if (tid < t1 - t0) cnt[(size_t)(a.N - 1 - (t0 + tid)) * a.ntiles + tile] = wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
     Trip tr;
     tr.n = n;
     const double inv = n > 0.0 ? 1.0 / n : 0.0;
@@ -292,32 +316,41 @@ struct RowsNorm {
     double ym, rys;
 };
 
-// rows in the reference's order: offs[(N-1-t) * ntiles + tile] + rank of the path among the tile's
-// in-the-money paths at step t
+// rows in the reference's order: rowbase[N-1-t] (rows of the later steps) + offs[(N-1-t) * ntiles + tile] (rows of the
+// step's earlier tiles) + rank of the path among the tile's in-the-money paths at step t
 __global__ __launch_bounds__(kBlock) void rows_write_kernel(RowsArgs a, RowsNorm nm, const int64_t* __restrict__ offs,
-                                                            float* __restrict__ data, int64_t cap)
+                                                            const int64_t* __restrict__ rowbase, float* __restrict__ data, int64_t cap)
 {
-    __shared__ int wsum[kBlock / 64];
+    __shared__ int wsum[kTChunk][kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int64_t p = (int64_t)tile * kBlock + tid;
     const bool live = p < a.M;
     const float* col = a.S + (live ? p : 0);
+    const int t0 = 1 + blockIdx.y * kTChunk, t1 = min(t0 + kTChunk, a.N);
+    float sv[kTChunk];
+    load_chunk(col, a.ld, t0, t1, sv);
     const double pn = payoff_d(col[(int64_t)a.N * a.ld], a.K, a.is_put);
     const double payN = pn > 0.0 ? pn : 0.0;
-    const int t0 = 1 + blockIdx.y * a.tchunk, t1 = min(t0 + a.tchunk, a.N);
-    for (int t = t0; t < t1; ++t) {
-        const float s = col[(int64_t)t * a.ld];
-        const bool f = live && itm(s, a.K, a.is_put);
+#pragma unroll
+    for (int i = 0; i < kTChunk; ++i) {
+        const bool f = live && t0 + i < t1 && itm(sv[i], a.K, a.is_put);
+        const int wc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
+        if (lane == 0) wsum[i][wave] = wc;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < kTChunk; ++i) {
+        const int t = t0 + i;
+        const float s = sv[i];
+        const bool f = live && t < t1 && itm(s, a.K, a.is_put);
         const uint64_t b = __builtin_amdgcn_ballot_w64(f);
-        if (lane == 0) wsum[wave] = __builtin_popcountll(b);
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        const int rank = woff + __builtin_popcountll(b & ((1ull << lane) - 1ull));
-        __syncthreads();
         if (!f) continue;
-        const int64_t row = offs[(size_t)(a.N - 1 - t) * a.ntiles + tile] + rank;
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[i][w];
+        const int rank = woff + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+        const int r = a.N - 1 - t;
+        const int64_t row = rowbase[r] + offs[(size_t)r * a.ntiles + tile] + rank;
         if (row >= cap) continue;
         double v[8];
         row_values((double)s, payN, a.K, sqrt(fmax(a.T - (double)t * a.dt, 1e-6)), a.D[a.N - t], v);
@@ -346,15 +379,21 @@ static size_t rows_nwg(int64_t M, int N, int tchunk)
 size_t nn_rows_scratch_bytes(int64_t M, int N)
 {
     const size_t n = (size_t)(N - 1 > 0 ? N - 1 : 0) * (size_t)((M + kBlock - 1) / kBlock);
-    return sizeof(int64_t) * (n + 2) + sizeof(int32_t) * (n + 2) + sizeof(double) * (kTrip * (rows_nwg(M, N, 32) + 2) + 32);
+    return sizeof(int64_t) * (n + 2 + 2 * ((size_t)N + 2)) + sizeof(int32_t) * (n + 2) +
+           sizeof(double) * (kTrip * (rows_nwg(M, N, kTChunk) + 2) + 32);
 }
 
-// scratch layout: offs int64[n+1] | cnt int32[n] | part double[nwg][kTrip] | out double[kTrip]
-static void carve(void* scratch, size_t n, size_t nwg, int64_t** offs, int32_t** cnt, double** part, double** out)
+// scratch layout: offs int64[n+2] | rowtot int64[N+2] | rowbase int64[N+2] | cnt int32[n] | part double[nwg][kTrip] | out double[kTrip]
+static void carve(void* scratch, size_t n, size_t nwg, int N, int64_t** offs, int64_t** rowtot, int64_t** rowbase, int32_t** cnt,
+                  double** part, double** out)
 {
     char* b = (char*)scratch;
     *offs = (int64_t*)b;
     b += sizeof(int64_t) * (n + 2);
+    *rowtot = (int64_t*)b;
+    b += sizeof(int64_t) * ((size_t)N + 2);
+    *rowbase = (int64_t*)b;
+    b += sizeof(int64_t) * ((size_t)N + 2);
     *cnt = (int32_t*)b;
     b += (sizeof(int32_t) * (n + 2) + 7) / 8 * 8;
     *part = (double*)b;
@@ -367,7 +406,7 @@ static RowsArgs make_args(const LsmProblem& p, const double* D)
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
     a.K = p.K; a.T = p.T; a.dt = p.T / (double)p.N; a.D = D;
     a.ntiles = (int)((p.M + kBlock - 1) / kBlock);
-    a.tchunk = 32;
+    a.tchunk = kTChunk;
     return a;
 }
 
@@ -379,25 +418,30 @@ hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, v
 {
     const RowsArgs a = make_args(p, D);
     const size_t n = (size_t)(p.N - 1) * a.ntiles, nwg = rows_nwg(p.M, p.N, a.tchunk);
-    int64_t* offs; int32_t* cnt; double *part, *out;
-    carve(scratch, n, nwg, &offs, &cnt, &part, &out);
+    int64_t *offs, *rowtot, *rowbase; int32_t* cnt; double *part, *out;
+    carve(scratch, n, nwg, p.N, &offs, &rowtot, &rowbase, &cnt, &part, &out);
+    const int nrow = p.N - 1 > 0 ? p.N - 1 : 0;
     const dim3 grid(a.ntiles, (p.N - 1 + a.tchunk - 1) / a.tchunk);
     if (n > 0) {
         if (with_stats) hipLaunchKernelGGL(rows_count_stats_kernel, grid, dim3(kBlock), 0, st, a, cnt, part);
         else hipLaunchKernelGGL(rows_count_kernel, grid, dim3(kBlock), 0, st, a, cnt);
+        // two-level scan: every time step's tiles in their own workgroup, then the per-step totals
+        hipLaunchKernelGGL(rows_scan_kernel<int32_t>, dim3((unsigned)nrow), dim3(1024), 0, st, (const int32_t*)cnt, (int64_t)n,
+                           (int64_t)a.ntiles, offs, rowtot);
     }
-    hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int64_t)n, offs);
+    hipLaunchKernelGGL(rows_scan_kernel<int64_t>, dim3(1), dim3(1024), 0, st, (const int64_t*)rowtot, (int64_t)nrow,
+                       (int64_t)(nrow > 0 ? nrow : 1), rowbase, (int64_t*)nullptr);
     if (with_stats) {
         hipLaunchKernelGGL(rows_merge_kernel, dim3(1), dim3(kBlock), 0, st, part, n > 0 ? (int)(grid.x * grid.y) : 0, out);
         *stats_dev = out;
     }
-    *total_dev = offs + n;
+    *total_dev = rowbase + nrow;
     return hipGetLastError();
 }
 
 hipError_t nn_scan_counts(hipStream_t st, const int32_t* cnt, int64_t n, int64_t* offs)
 {
-    hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, n, offs);
+    hipLaunchKernelGGL(rows_scan_kernel<int32_t>, dim3(1), dim3(1024), 0, st, cnt, n, n > 0 ? n : (int64_t)1, offs, (int64_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -415,8 +459,8 @@ hipError_t nn_rows_write(hipStream_t st, const LsmProblem& p, const double* D, v
     const RowsArgs a = make_args(p, D);
     const size_t n = (size_t)(p.N - 1) * a.ntiles;
     if (n == 0) return hipSuccess;
-    int64_t* offs; int32_t* cnt; double *part, *out;
-    carve(scratch, n, rows_nwg(p.M, p.N, a.tchunk), &offs, &cnt, &part, &out);
+    int64_t *offs, *rowtot, *rowbase; int32_t* cnt; double *part, *out;
+    carve(scratch, n, rows_nwg(p.M, p.N, a.tchunk), p.N, &offs, &rowtot, &rowbase, &cnt, &part, &out);
     RowsNorm nm;
     for (int i = 0; i < 7; ++i) {
         nm.fm[i] = feat_mean[i];
@@ -425,7 +469,7 @@ hipError_t nn_rows_write(hipStream_t st, const LsmProblem& p, const double* D, v
     nm.ym = y_mean;
     nm.rys = 1.0 / y_std;
     hipLaunchKernelGGL(rows_write_kernel, dim3(a.ntiles, (p.N - 1 + a.tchunk - 1) / a.tchunk), dim3(kBlock), 0, st, a,
-                       nm, offs, data, cap);
+                       nm, offs, rowbase, data, cap);
     return hipGetLastError();
 }
 

@@ -182,25 +182,45 @@ def test_config1_nn_end_to_end_band(torch_cuda, golden):
     assert p.rng_manager.get_child_seed() == golden["scalars"]["rng_manager_42_child_seeds"][2]
 
 
-def test_config1_nn_mean_over_eight_seeds_is_inside_the_reference_range(torch_cuda, golden):
-    """Round 3: the reference's own prices for config 1 (five seeds, default 3 x 128 net) span [6.81, 7.29].  The mean
-    of OUR pricer over eight seeds must lie inside that range (no widening), and every single price within the range
-    widened by the reference's own standard deviation -- the band a sixth reference seed would be held to."""
+def test_config1_nn_prices_follow_the_references_distribution(torch_cuda, golden):
+    """The price of ONE seed is a chaotic function of the training noise: on the same paths, rows and initial weights
+    PyTorch autograd, the 32-row and the 16-row trainer kernels end at the same loss (to 1e-3) and at prices 7.02 / 7.14 /
+    6.87 for seed 42, 6.96 / 6.69 / 6.45 for seed 5, 6.61 / 6.96 / 6.98 for seed 6 (profiles/r05_nn_seed_study.jsonl) --
+    two equally good fits place the exercise boundary differently.  So prices cannot be compared seed by seed, and a band
+    drawn from five reference runs (rounds 3-4) says little about a sixth.  Round 5: the reference itself was run for
+    master seeds 42 and 1 .. 20 (tools/capture_reference_band.py, ~150 s of CPU each; tests/golden/scalars.json), and
+    OUR pricer is run for the same 21 seeds.  The two SAMPLES must agree:
+      * means: Welch's t below 3.5;
+      * distributions: two-sample Kolmogorov-Smirnov statistic below its 0.1 % critical value 1.95 sqrt((n + m) / (n m));
+      * spread: standard deviations within a factor 2 of each other;
+      * every single price inside the reference's own range widened by its standard deviation -- the band a further
+        reference seed would be held to."""
     import numpy as np
+    from scipy import stats
 
     from options_model_amd import AdvancedOptionPricer, RNGManager
     sc = golden["scalars"]
-    refs = np.array([sc["end_to_end_10k_x_50_seed42"]["gbm_put_cv_off"]] + list(sc["reference_nn_seed_band"].values()))
-    lo, hi, sd = refs.min(), refs.max(), refs.std(ddof=1)
+    ref = {42: sc["end_to_end_10k_x_50_seed42"]["gbm_put_cv_off"]}
+    ref.update({int(k): v for k, v in sc["reference_nn_seed_band"].items()})
+    assert len(ref) >= 15, "run tools/capture_reference_band.py for more seeds"
+    seeds = sorted(ref)
+    refs = np.array([ref[k] for k in seeds])
     prices = []
-    for seed in (42, 1, 2, 3, 4, 5, 6, 7):
+    for seed in seeds:
         p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(seed),
                                  use_control_variate=False)
         prices.append(p.price_american_option(100.0, 1.0, 10000, 50))
     prices = np.array(prices)
-    print("config-1 NN prices over 8 seeds:", np.round(prices, 4), "mean", prices.mean(), "reference", np.round(refs, 4))
-    assert lo <= prices.mean() <= hi, (prices, refs)
-    assert np.all((prices > lo - sd) & (prices < hi + sd)), (prices, refs)
+    n, m = len(prices), len(refs)
+    t = (prices.mean() - refs.mean()) / np.sqrt(prices.var(ddof=1) / n + refs.var(ddof=1) / m)
+    ks = stats.ks_2samp(prices, refs).statistic
+    print(f"config-1 NN, {n} seeds: ours mean {prices.mean():.4f} sd {prices.std(ddof=1):.4f} [{prices.min():.3f}, {prices.max():.3f}]; "
+          f"reference mean {refs.mean():.4f} sd {refs.std(ddof=1):.4f} [{refs.min():.3f}, {refs.max():.3f}]; Welch t {t:.2f}, KS {ks:.3f}")
+    assert abs(t) < 3.5, (t, prices, refs)
+    assert ks < 1.95 * np.sqrt((n + m) / (n * m)), (ks, prices, refs)
+    assert 0.5 < prices.std(ddof=1) / refs.std(ddof=1) < 2.0
+    sd = refs.std(ddof=1)
+    assert np.all((prices > refs.min() - sd) & (prices < refs.max() + sd)), (prices, refs)
 
 
 def test_config1_nn_hidden64_all_hip_lands_in_the_reference_band(torch_cuda, golden):
