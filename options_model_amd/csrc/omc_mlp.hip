@@ -1566,39 +1566,50 @@ __device__ __forceinline__ void mlp_train_q16_body(const MlpQuadArgs& a, const i
         // <-> own units i = 32 w + 2 n + ub (B = dZ_l); contraction over the 16 rows, k-step s <-> rows 4 s + g.  A lane's
         // four registers are gW_l[i][16 kb + 4 g .. + 3]: one 16-byte store.  Block NQ has A = 1: the bias gradient.
         {
-            v4f16 acc[2][NQ + 1];
-#pragma unroll
-            for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-                for (int kb = 0; kb <= NQ; ++kb) acc[ub][kb] = v4f16{0.0f, 0.0f, 0.0f, 0.0f};
-            // every LDS operand of the product is requested before the first MFMA (left to itself hipcc puts each
-            // ds_read directly in front of the pair of MFMAs that uses it: 32 exposed LDS latencies, 2.7 us per layer)
+            // The column blocks in two halves: half as many accumulators live at a time (with the weights of two
+            // connections in flight the kernel sits at the 256 registers that still let two workgroups share a CU --
+            // what the side-by-side trainer of a curve's networks needs; every output element sums its four k-steps in
+            // the same order either way).  Every LDS operand of a half is requested before its first MFMA (left to
+            // itself hipcc puts each ds_read directly in front of the pair of MFMAs that uses it).
             float2 dv[4];
-            float hv[4][NQ];
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                dv[s2] = own_pair(sDz, s2);
+            for (int s2 = 0; s2 < 4; ++s2) dv[s2] = own_pair(sDz, s2);
 #pragma unroll
-                for (int kb = 0; kb < NQ; ++kb) hv[s2][kb] = sAct[l - 1][(4 * kb + (j >> 2)) * 64 + (4 * s2 + g) * 4 + (j & 3)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int half = 0; half < 2; ++half) {
+                constexpr int NH = NQ / 2;
+                v4f16 acc[2][NH + 1];
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
+                for (int ub = 0; ub < 2; ++ub)
 #pragma unroll
-                for (int kb = 0; kb < NQ; ++kb) {
-                    acc[0][kb] = mfma16(hv[s2][kb], dv[s2].x, acc[0][kb]);
-                    acc[1][kb] = mfma16(hv[s2][kb], dv[s2].y, acc[1][kb]);
+                    for (int kb = 0; kb <= NH; ++kb) acc[ub][kb] = v4f16{0.0f, 0.0f, 0.0f, 0.0f};
+                float hv[4][NH];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int kb = 0; kb < NH; ++kb)
+                        hv[s2][kb] = sAct[l - 1][(4 * (NH * half + kb) + (j >> 2)) * 64 + (4 * s2 + g) * 4 + (j & 3)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                    for (int kb = 0; kb < NH; ++kb) {
+                        acc[0][kb] = mfma16(hv[s2][kb], dv[s2].x, acc[0][kb]);
+                        acc[1][kb] = mfma16(hv[s2][kb], dv[s2].y, acc[1][kb]);
+                    }
+                    if (half == 1) {  // block NQ has A = 1: the bias gradient
+                        acc[0][NH] = mfma16(1.0f, dv[s2].x, acc[0][NH]);
+                        acc[1][NH] = mfma16(1.0f, dv[s2].y, acc[1][NH]);
+                    }
                 }
-                acc[0][NQ] = mfma16(1.0f, dv[s2].x, acc[0][NQ]);
-                acc[1][NQ] = mfma16(1.0f, dv[s2].y, acc[1][NQ]);
+#pragma unroll
+                for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                    for (int kb = 0; kb < NH; ++kb)
+                        *reinterpret_cast<float4*>(gWl + (size_t)(32 * w + 2 * j + ub) * H + 16 * (NH * half + kb) + 4 * g) =
+                            make_float4(acc[ub][kb][0], acc[ub][kb][1], acc[ub][kb][2], acc[ub][kb][3]);
+                if (half == 1 && g == 0)
+                    *reinterpret_cast<float2*>(gWl + H * H + 32 * w + 2 * j) = make_float2(acc[0][NH][0], acc[1][NH][0]);
             }
-#pragma unroll
-            for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-                for (int kb = 0; kb < NQ; ++kb)
-                    *reinterpret_cast<float4*>(gWl + (size_t)(32 * w + 2 * j + ub) * H + 16 * kb + 4 * g) =
-                        make_float4(acc[ub][kb][0], acc[ub][kb][1], acc[ub][kb][2], acc[ub][kb][3]);
-            if (g == 0) *reinterpret_cast<float2*>(gWl + H * H + 32 * w + 2 * j) = make_float2(acc[0][NQ][0], acc[1][NQ][0]);
         }
         // ---- dH_{l-1} of the own units = W_l^T dZ_l, then through the ReLU / dropout mask of H_{l-1}
         {
@@ -1693,6 +1704,7 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBa
                                                                      int step_base)
 {
     const MlpBatchProb& p = tab[blockIdx.y];
+    const int tile = blockIdx.x;
     int64_t nrows, batch;
     batch_rows(p, &nrows, &batch);
     if ((batch <= (int64_t)p.q16_rows) != Q16) return;
@@ -1716,8 +1728,8 @@ __global__ __launch_bounds__(H * 2) void mlp_train_quad_batch_kernel(const MlpBa
     a.step = (uint32_t)(p.first_step + step_base + s + 1);
     a.k0 = p.k0;
     a.k1 = p.k1;
-    if constexpr (Q16) mlp_train_q16_body<H, L>(a, blockIdx.x);  // (the grid covers the largest problem's tiles)
-    else mlp_train_quad_body<H, L>(a, blockIdx.x);
+    if constexpr (Q16) mlp_train_q16_body<H, L>(a, tile);  // (T covers the largest problem's tiles)
+    else mlp_train_quad_body<H, L>(a, tile);
 }
 
 // Work-list form of the same launch for batches whose problems differ wildly in size (the per-step ContNet flow of

@@ -85,8 +85,9 @@ def test_k_pricings_with_external_moments(ctx):
         c.set_allreduce_hook(ident)
         with torch.cuda.stream(stream):
             out = c.price_american_seq(ps)
-        # N - 1 collectives of 8K doubles (K = 5) + one of 8n result sums -- not n (N - 1) of 8
-        assert calls.count(8 * n) == (N - 1) + 1 and len(calls) == N
+        # first the vote on K (34 doubles: every rank of a job takes part, whatever its own K -- ADVICE r4), then N - 1
+        # collectives of 8K doubles (K = 5) + one of 8n result sums -- not n (N - 1) of 8
+        assert calls[0] == 34 and calls.count(8 * n) == (N - 1) + 1 and len(calls) == N + 1
         for a, b in zip(out, base):
             _same(a, b)
 

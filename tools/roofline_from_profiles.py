@@ -66,6 +66,8 @@ for name, (M, N) in SIZES.items():
         b, why = algo(kname, M, N)
         if b is None:
             continue
+        if "lsm_step_multi_kernel" in kname and name != "reference":
+            continue  # (launched there by bench.py's per-step extra at other pricings-per-launch: see the `reference` rows)
         gbs = b / avg_ns  # bytes per ns = GB/s
         short = kname.split("(")[0].replace("void ", "").replace("omc::", "").replace("(anonymous namespace)::", "")
         bf = ""
