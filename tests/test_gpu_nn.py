@@ -195,9 +195,6 @@ def test_config1_nn_prices_follow_the_references_distribution(torch_cuda, golden
       * spread: standard deviations within a factor 2 of each other;
       * every single price inside the reference's own range widened by its standard deviation -- the band a further
         reference seed would be held to."""
-    import numpy as np
-    from scipy import stats
-
     from options_model_amd import AdvancedOptionPricer, RNGManager
     sc = golden["scalars"]
     ref = {42: sc["end_to_end_10k_x_50_seed42"]["gbm_put_cv_off"]}
@@ -210,11 +207,18 @@ def test_config1_nn_prices_follow_the_references_distribution(torch_cuda, golden
         p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(seed),
                                  use_control_variate=False)
         prices.append(p.price_american_option(100.0, 1.0, 10000, 50))
-    prices = np.array(prices)
+    _same_distribution(np.array(prices), refs, "config-1 NN 3 x 128")
+
+
+def _same_distribution(prices, refs, what):
+    """Two samples of prices over the same master seeds (ours / the reference's own runs): Welch's t below 3.5, the
+    two-sample Kolmogorov-Smirnov statistic below its 0.1 % critical value, standard deviations within a factor 2, and
+    every single price of ours inside the reference's range widened by its own standard deviation."""
+    from scipy import stats
     n, m = len(prices), len(refs)
     t = (prices.mean() - refs.mean()) / np.sqrt(prices.var(ddof=1) / n + refs.var(ddof=1) / m)
     ks = stats.ks_2samp(prices, refs).statistic
-    print(f"config-1 NN, {n} seeds: ours mean {prices.mean():.4f} sd {prices.std(ddof=1):.4f} [{prices.min():.3f}, {prices.max():.3f}]; "
+    print(f"{what}, {n} seeds: ours mean {prices.mean():.4f} sd {prices.std(ddof=1):.4f} [{prices.min():.3f}, {prices.max():.3f}]; "
           f"reference mean {refs.mean():.4f} sd {refs.std(ddof=1):.4f} [{refs.min():.3f}, {refs.max():.3f}]; Welch t {t:.2f}, KS {ks:.3f}")
     assert abs(t) < 3.5, (t, prices, refs)
     assert ks < 1.95 * np.sqrt((n + m) / (n * m)), (ks, prices, refs)
@@ -223,25 +227,25 @@ def test_config1_nn_prices_follow_the_references_distribution(torch_cuda, golden
     assert np.all((prices > refs.min() - sd) & (prices < refs.max() + sd)), (prices, refs)
 
 
-def test_config1_nn_hidden64_all_hip_lands_in_the_reference_band(torch_cuda, golden):
-    """Same flow with nn_hidden=64: SingleLSMNet(7, 64, 3) -- here the network is trained by the
-    library's fused MFMA trainer and applied by its pass-2 kernel (no PyTorch autograd, no PyTorch
-    forward).  The reference's own prices for this setting over four seeds are in
-    scalars.json["reference_nn_seed_band_h64"] (tools/capture_reference_band.py --hidden 64, ~75 s of
-    CPU each); ours must land in that band, and their mean inside its range."""
+def test_config1_nn_hidden64_all_hip_follows_the_references_distribution(torch_cuda, golden):
+    """Same flow with nn_hidden=64: SingleLSMNet(7, 64, 3) -- trained by the library's 16-row-tile MFMA trainer and
+    applied by its pass-2 kernel (no PyTorch autograd, no PyTorch forward).  The reference's own prices for this setting
+    (tools/capture_reference_band.py --hidden 64, ~75 s of CPU each; master seeds 1 .. 20 in
+    scalars.json["reference_nn_seed_band_h64"]) against ours for the same master seeds, as two samples -- see
+    test_config1_nn_prices_follow_the_references_distribution for why not seed by seed."""
     from options_model_amd import AdvancedOptionPricer, RNGManager
-    refs = list(golden["scalars"]["reference_nn_seed_band_h64"].values())
-    assert len(refs) >= 4
-    lo, hi, sd = min(refs), max(refs), float(np.std(refs, ddof=1))
+    band = golden["scalars"]["reference_nn_seed_band_h64"]
+    seeds = sorted(int(k) for k in band)
+    assert len(seeds) >= 4
+    refs = np.array([band[str(k)] for k in seeds])
     prices = []
-    for seed in (42, 1, 2, 3):
+    for seed in seeds:
         p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(seed),
                                  use_control_variate=False, regressor="nn", nn_hidden=64)
         prices.append(p.price_american_option(100.0, 1.0, 10000, 50))
         info = p.last_result
         assert info["trainer"] == "hip" and info["pass2"] == "hip" and info["batch"] == 256
-        assert lo - sd < prices[-1] < hi + sd, (prices, refs)  # one reference sd either side of its own range
-    assert lo < sum(prices) / len(prices) < hi, (prices, refs)  # the mean: inside the reference's range itself
+    _same_distribution(np.array(prices), refs, "config-1 NN 3 x 64")
 
 
 def test_facade_nn_regressor_2x64(torch_cuda):

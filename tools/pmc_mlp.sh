@@ -1,13 +1,15 @@
 #!/bin/bash
 # SQ / GRBM counters of the fused trainer (2 x 64, batch 2^17): which clock does the chip hold, how busy is the MFMA pipe.
-# usage: pmc_mlp.sh TAG
+# usage: pmc_mlp.sh TAG [bench_mlp.py arguments; default: 8388608 131072 1 0.1 = config 5's trainer.
+#        The reference's default call: 225057 256 2 0.1 3 128]
 set -u
 R="$GRAFT_REPO_ROOT"; cd /tmp && export TMPDIR=/tmp
+TAGX=$1; shift; ARGS="${*:-8388608 131072 1 0.1}"; set -- "$TAGX"
 for PASS in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA"; do
   N=$(echo $PASS | cut -d' ' -f1)
   OUT="$R/gpurun_out/pmc_mlp_$1_$N"
   timeout -k 10 300 rocprofv3 --pmc $PASS --kernel-trace --output-format csv -d "$OUT" -- \
-    python3 "$R/tools/bench_mlp.py" 8388608 131072 1 0.1 > /dev/null 2> "$OUT.err" || { echo "pass $N failed"; tail -3 "$OUT.err"; }
+    python3 "$R/tools/bench_mlp.py" $ARGS > /dev/null 2> "$OUT.err" || { echo "pass $N failed"; tail -3 "$OUT.err"; }
 done
 python3 - "$R/gpurun_out" "$1" <<'PY' | tee "$R/gpurun_out/pmc_mlp_summary_$1.txt"
 import csv, glob, sys, collections, re, os
