@@ -341,7 +341,7 @@ int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t
 int omc_mlp_shuffle_indices(omc_ctx* ctx, int64_t n_rows, uint64_t shuffle_key, int64_t* out_device);
 /* Which of the four trainer kernels omc_mlp_train_epoch runs for this shape at this minibatch size: 1 = one
  * workgroup per 128 rows with the weights in LDS (64 units, more than 32 tiles of 32 rows), 2 = one 32-row tile per
- * wave, 3 = one 32-row tile per workgroup, 4 = one 16-row tile per workgroup (minibatches of up to 1,024 rows: the
+ * wave, 3 = one 32-row tile per workgroup, 4 = one 16-row tile per workgroup (minibatches of up to 4,096 rows: the
  * reference's own min(256, R)), 0 = not covered.  The kernels hold the hidden units in different register orders, so
  * WHICH units dropout drops for a given (seed, step, row) depends on it. */
 int omc_mlp_train_variant(int hidden, int layers, int64_t batch);

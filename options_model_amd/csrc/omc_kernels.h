@@ -136,7 +136,7 @@ hipError_t lsm_final_reduce(hipStream_t st, const LsmProblem& p, const LsmWorksp
 constexpr int kMlpPartialStride2 = 4800;                   // gradient partial per workgroup, 2 / 3 hidden layers
 constexpr int kMlpPartialStride3 = 8960;                   // (>= parameters + 1 loss slot, multiple of 64)
 constexpr int kMlpMaxGroups = 256;                         // one workgroup per CU
-constexpr int kMlpQ16MaxRows = 1024;                       // minibatches up to here run in 16-row tiles (mlp_train_q16_kernel)
+constexpr int kMlpQ16MaxRows = 4096;                       // minibatches up to here run in 16-row tiles (mlp_train_q16_kernel): one tile per CU
 struct MlpTrainPlan {
     const float* data;  // [nrows][8] float32: 7 inputs + target
     float* params;      // [mlp_train_param_count(64, layers)], updated in place
