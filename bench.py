@@ -232,7 +232,7 @@ def bench_c1nn(a) -> int:
                                    "threads): 133-147 s per pricing, measured in the build container; quoted, not re-run "
                                    "(the reference does not travel to the GPU box)"},
         "price": price, "prices": prices, "stderr": o.get("stderr"), "rows": o.get("R"),
-        "info": {k: o.get(k) for k in ("trainer", "pass2", "rows", "batch", "epochs_run", "optimizer_steps", "best_loss")},
+        "info": {k: o.get(k) for k in ("trainer", "trainer_kernel", "pass2", "rows", "batch", "epochs_run", "optimizer_steps", "best_loss")},
         "timings_ms": {k[len("seconds_"):]: round(1e3 * v, 3) for k, v in o.items() if k.startswith("seconds_")},
         "price_check": "tests/test_gpu_nn.py::test_config1_nn_end_to_end_band (the reference's own seed band: 6.81 - 7.29), "
                        "tests/test_gpu_dropout.py (trainer and pass 2 under the oracle's masks)",

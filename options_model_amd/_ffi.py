@@ -623,7 +623,7 @@ class Context:
 
     def mlp_dropout_masks(self, variant, hidden, layers, n_rows, step, seed, dropout, keys=None):
         """keep (True) / drop of every hidden activation as kernel `variant` draws it -> bool [layers, n_rows, hidden]
-        (variant 0: pass 2, keys = path columns, step = time step; 1 / 2 / 3: omc_mlp_train_variant)."""
+        (variant 0: pass 2, keys = path columns, step = time step; 1 .. 4: omc_mlp_train_variant)."""
         out = np.zeros((int(layers), int(n_rows), int(hidden)), np.uint8)
         k = None if keys is None else np.ascontiguousarray(keys, np.uint32)
         assert k is None or k.size == n_rows

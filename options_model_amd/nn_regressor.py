@@ -361,8 +361,11 @@ def _train_fused(net, data, epochs, lr, bs, verbose):
                 print(f"Early stopping at epoch {epoch + 1}, restoring best weights")
             break
     unflatten_params(net, best_params if best_params is not None else params)
+    H_, L_ = _linear_shape(net)
+    kernel = {1: "mlp_train_kernel", 2: "mlp_train_tile_kernel", 3: "mlp_train_quad_kernel", 4: "mlp_train_q16_kernel"}.get(
+        int(ctx.lib.omc_mlp_train_variant(int(H_), int(L_), int(bs))), "?")
     return dict(batch=bs, optimizer_steps=step, epochs_run=epoch + 1, best_loss=ctl.best_loss, best_epoch=ctl.best_epoch,
-                final_lr=ctl.lr, graphed=False, trainer="hip", seconds_train_kernels=t_kernels)
+                final_lr=ctl.lr, graphed=False, trainer="hip", trainer_kernel=kernel, seconds_train_kernels=t_kernels)
 
 
 def build_rows_fused(S, K, r, T, is_put):
@@ -691,5 +694,5 @@ def price_american_option_nn(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", 
                        n_exercised=out.get("n_exercised", 0), sum_nitm=out.get("R", 0), model=model_l,
                        semantics="two_pass", option_type=option_type,
                        timings_ms={k[len("seconds_"):]: 1e3 * v for k, v in out.items() if k.startswith("seconds_")},
-                       info={k: out[k] for k in ("trainer", "pass2", "rows", "batch", "epochs_run", "optimizer_steps",
+                       info={k: out[k] for k in ("trainer", "trainer_kernel", "pass2", "rows", "batch", "epochs_run", "optimizer_steps",
                                                  "best_loss", "graphed") if k in out})

@@ -178,6 +178,7 @@ def test_config1_nn_end_to_end_band(torch_cuda, golden):
     price = p.price_american_option(100.0, 1.0, 10000, 50)
     info = p.last_result
     assert info["R"] > 200_000 and info["batch"] == 256 and info["n_paths"] == 10000
+    assert info["trainer"] == "hip" and info["trainer_kernel"] == "mlp_train_q16_kernel" and info["pass2"] == "hip"
     assert lo < price < hi, (price, refs)
     assert p.rng_manager.get_child_seed() == golden["scalars"]["rng_manager_42_child_seeds"][2]
 
