@@ -12,7 +12,7 @@ p.price_american_enhanced_lsm(100.0, 1.0, 10000, 50)  # warm (library load, torc
 for seed in (1, 2, 3):
     q = AdvancedOptionPricer(100.0, 0.05, 0.2, "put", RNGManager(seed))
     t0 = time.perf_counter(); price = q.price_american_enhanced_lsm(100.0, 1.0, 10000, 50); dt = time.perf_counter() - t0
-    info = q.last_result.get("info", {})
+    info = q.last_result
     print(f"v3 default: {dt:.3f} s  price {price:.4f}  epochs {info.get('epochs_run')} steps {info.get('optimizer_steps')} trainer {info.get('trainer')}", flush=True)
 v1(100.0, 100.0, 1.0, 0.05, 0.2, 10000, 50, "put")
 t0 = time.perf_counter(); m = v1(100.0, 100.0, 1.0, 0.05, 0.2, 10000, 50, "put"); dt = time.perf_counter() - t0
