@@ -253,3 +253,28 @@ def test_facade_nn_regressor_2x64(torch_cuda):
     from options_model_amd import price_american_option
     res = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 40_000, 25, regressor="nn", seed=3)
     assert 5.6 < res.price < 8.0 and res.n_paths == 40_000 and res.sum_nitm > 0
+
+
+def test_bench_c1nn_line_is_the_references_default_call(torch_cuda):
+    """`python bench.py --config c1nn`: ONE JSON line for the reference's default call (3 x 128, minibatch 256, dropout on)
+    with the contract's fields, the trainer's MFMA roofline and the reference's own time as the quoted CPU baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c1nn", "--steps", "1", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["unit"] == "path-steps/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["value"] == pytest.approx(10000 * 50 / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    assert d["info"]["trainer"] == "hip" and d["info"]["trainer_kernel"] == "mlp_train_q16_kernel" and d["info"]["batch"] == 256
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0 < r["frac"] < 0.1 and 20_000 < r["optimizer_steps"] <= 22_100
+    assert 10 < r["us_per_optimizer_step"] < 60
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["value"] == pytest.approx(10000 * 50 / 133.0) and c["cores"] == 8
+    assert 6.0 < d["price"] < 8.0 and d["ms_per_step"] < 2000
