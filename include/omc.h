@@ -324,6 +324,18 @@ int omc_lsm_apply_mlp_shard(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_
 int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
                       double r, double T, int is_put, float* data, int64_t cap_rows, int64_t* n_rows,
                       double* stats16);
+/* Regressor "ols7": the v3 two-pass flow (options_model_3.py:482-516 pass 1, :542-563 normalisation, :615-651 pass 2,
+ * :651 mean at t = dt) with ONE global least-squares fit on the reference's seven features [1, x, x^2, x^3, max(x-1,0),
+ * s, x*s] (create_regression_features, :105-121) in place of the network -- the reference validates `lsm_poly_degree`
+ * and never uses it; this is the linear regressor its own features define, between the per-step 3-term
+ * polynomial (omc_lsm_poly) and the network.  Pass 1 is one sweep over S (co-moments of the 6 non-constant features and
+ * the target, float64, merged by Chan's formula in a fixed order); the fit is lstsq on the normalised design matrix
+ * (zero-variance columns get weight 0, as numpy's minimum-norm solution gives them); pass 2 applies it, strict >, sticky.
+ * res->sum_nitm = rows of the regression; weights7 (host, may be NULL) = the fit, column 0 the constant; stats16 (host,
+ * may be NULL) = feat_mean[7], feat_std[7], y_mean, y_std as omc_nn_build_rows returns them.  One GPU (-8 on a
+ * distributed context). */
+int omc_lsm_ols7(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r, double T,
+                 int is_put, omc_result* res, double* weights7, double* stats16, float* sx_out, int32_t* tex_out);
 /* Normalisers of the training rows (options_model_3.py:550-563) in float64: for rows i < n_rows
  * with x[i] = S/K, step index t[i] and target y[i] (device arrays), out16[0..6] = means of
  * [x, x^2, x^3, max(x-1,0), s, x*s, y] with s = sqrt(max(T - t*dt, 1e-6)), out16[8..14] =

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomc.so")
-SOURCES = ["omc_paths.hip", "omc_lsm.hip", "omc_batch.hip", "omc_mlp.hip", "omc_contnet.hip", "omc_rows.hip", "omc_comm.hip", "omc_p2p.hip",
+SOURCES = ["omc_paths.hip", "omc_lsm.hip", "omc_batch.hip", "omc_mlp.hip", "omc_contnet.hip", "omc_rows.hip", "omc_ols7.hip", "omc_comm.hip", "omc_p2p.hip",
            "omc_api.hip"]
 HEADERS = ["omc_device.h", "omc_kernels.h", "omc_lsm_dev.h", "omc_paths_dev.h", "omc_contnet_dev.h", "omc_batch.h", "omc_comm.h", "omc_p2p.h",
            os.path.join("..", "..", "include", "omc.h")]

@@ -109,6 +109,7 @@ SIGNATURES = {
     "omc_mlp_train_epoch_batch": (C.c_int, [_P, C.POINTER(MlpJob), _I, _I, _I] + [_D] * 5),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
     "omc_mlp_train_variant": (C.c_int, [C.c_int, C.c_int, _I64]),
+    "omc_lsm_ols7": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, C.POINTER(Result), _P, _P, _P, _P]),
     "omc_ctx_device_info": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int]),
     "omc_mlp_dropout_masks": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _I64, _P, C.c_uint32, _U64, C.c_double, _P]),
     "omc_nn_half_counts": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _I, _P]),
@@ -378,6 +379,26 @@ class Context:
                                                 tex.ctypes.data if want_state else None))
         d = res.as_dict()
         d.update(betas=betas[:, :3], nitm=betas[:, 3].astype(np.int64), sx=sx, tex=tex)
+        return d
+
+    def lsm_ols7(self, S, K, r, T, is_put, want_state=False, n_paths=None):
+        """Two-pass flow with the global least-squares fit on the reference's 7 features (omc_lsm_ols7) on a device path
+        matrix -> result dict + weights [7], feat_mean / feat_std [7], y_mean, y_std (+ sx, tex if want_state)."""
+        N = S.shape[0] - 1
+        ld = S.shape[1]
+        M = ld if n_paths is None else n_paths
+        res = Result()
+        w = np.zeros(7)
+        st = np.zeros(16)
+        sx = np.zeros(M, np.float32) if want_state else None
+        tex = np.zeros(M, np.int32) if want_state else None
+        ptr = S.ptr if isinstance(S, DeviceArray) else int(S.data_ptr())
+        _check(self.lib, self.lib.omc_lsm_ols7(self.handle, ptr, ld, M, N, K, r, T, int(is_put), C.byref(res), w.ctypes.data,
+                                                st.ctypes.data, sx.ctypes.data if want_state else None,
+                                                tex.ctypes.data if want_state else None))
+        d = res.as_dict()
+        d.update(weights=w, feat_mean=st[:7].copy(), feat_std=st[7:14].copy(), y_mean=float(st[14]), y_std=float(st[15]),
+                 sx=sx, tex=tex)
         return d
 
     def lsm_apply_frozen(self, S, K, r, T, is_put, betas4, want_state=True):

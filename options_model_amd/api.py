@@ -94,7 +94,9 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
                           regressor="poly", semantics="two_pass", heston_params=None,
                           heston_scheme="reference", antithetic=True, seed=42, stream=0,
                           device=None, ctx=None, n_gpus=1, nn_options=None) -> PriceResult:
-    """nn_options (regressor="nn" only): dict with any of nn_hidden, nn_layers, nn_dropout, nn_epochs, nn_lr, nn_batch,
+    """regressor: "poly" (OLS on [1, u, u^2] per time step: the flows of `semantics`), "nn" (the reference's network, two-pass
+    flow), "ols7" (one least-squares fit on the reference's 7 features, two-pass flow).
+    nn_options (regressor="nn" only): dict with any of nn_hidden, nn_layers, nn_dropout, nn_epochs, nn_lr, nn_batch,
     inference_dropout, torch_seed -- the network named by BASELINE config 5 (2 x 64) by default."""
     model_l = str(model).lower()
     n_gpus = int(n_gpus)
@@ -106,8 +108,35 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
         raise ValueError("model must be 'GBM' or 'Heston'.")
     if semantics not in _SEM:
         raise ValueError(f"semantics must be one of {sorted(set(_SEM))}.")
-    if regressor not in ("poly", "nn"):
-        raise ValueError("regressor must be 'poly' or 'nn'.")
+    if regressor not in ("poly", "nn", "ols7"):
+        raise ValueError("regressor must be 'poly', 'nn' or 'ols7'.")
+    if regressor == "ols7":
+        # ONE global least-squares fit on the reference's seven features (options_model_3.py:105-121) in its two-pass flow
+        # (omc_lsm_ols7): the linear regressor between the per-step polynomial and the network.  One GPU.
+        if n_gpus > 1:
+            raise ValueError("regressor='ols7' runs on one GPU (n_gpus must be 1).")
+        _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
+        M = int(n_paths) // 2 * 2 if antithetic else int(n_paths)
+        if M <= 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        c = ctx or _ffi.default_context(_ffi.resolve_device(None) if device is None else device)
+        if model_l == "heston":
+            hp = heston_defaults(sigma, heston_params)
+            sch = _ffi.HESTON_SCHEMES[heston_scheme] if isinstance(heston_scheme, str) else int(heston_scheme)
+            S = c.heston_paths(M, int(n_steps), S0, r, T, hp["v0"], hp["kappa"], hp["theta"], hp["xi"], hp["rho"], seed, stream,
+                               scheme=sch)
+        else:
+            S = c.gbm_paths(M, int(n_steps), S0, r, sigma, T, seed, stream, antithetic=antithetic)
+        try:
+            out = c.lsm_ols7(S, K, r, T, option_type == "put")
+        finally:
+            S.free()
+        var = max(out["sumsq"] / M - out["price"] ** 2, 0.0)
+        return PriceResult(price=out["price"], stderr=math.sqrt(var / M), std=out["std"], zero_prob=out["zero_prob"], n_paths=M,
+                           n_exercised=out["n_exercised"], sum_nitm=out["sum_nitm"], model=model_l, semantics="two_pass",
+                           option_type=option_type,
+                           info=dict(regressor="ols7", weights=[float(v) for v in out["weights"]], y_mean=out["y_mean"],
+                                     y_std=out["y_std"]))
     if n_gpus > 1 and not _in_job(n_gpus):
         # a plain process: validate here (the reference's messages), then let the rank pool do the collective call
         if ctx is not None:

@@ -2158,6 +2158,98 @@ int omc_nn_build_rows(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
     return 0;
 }
 
+// Solve the normal equations of the live (non-constant) standardised columns: A w = b with A = the correlation matrix of
+// the columns, b = their correlations with the target; symmetric Gauss elimination with diagonal pivoting, a column
+// whose pivot has vanished (exactly collinear with those before it) gets weight 0 -- any solution of a consistent
+// singular system predicts the same values, and that is all pass 2 uses.
+static void ols7_solve(const double* st, double n, const double* sd, const bool* live, double* w7)
+{
+    auto C = [&](int i, int j) { return i <= j ? st[8 + i * 7 - i * (i - 1) / 2 + (j - i)] : st[8 + j * 7 - j * (j - 1) / 2 + (i - j)]; };
+    int idx[6], m = 0;
+    for (int q = 0; q < 6; ++q)
+        if (live[q]) idx[m++] = q;
+    double A[6][7];
+    for (int i = 0; i < m; ++i) {
+        for (int j = 0; j < m; ++j) A[i][j] = C(idx[i], idx[j]) / (n * sd[idx[i]] * sd[idx[j]]);
+        A[i][m] = C(idx[i], 6) / (n * sd[idx[i]] * sd[6]);
+    }
+    bool used[6] = {false, false, false, false, false, false};
+    int order[6], rank = 0;
+    for (int k = 0; k < m; ++k) {
+        int pv = -1;
+        double best = 1e-13;  // (unit diagonal: a pivot below this is rounding noise of an exactly dependent column)
+        for (int i = 0; i < m; ++i)
+            if (!used[i] && A[i][i] > best) { best = A[i][i]; pv = i; }
+        if (pv < 0) break;
+        used[pv] = true;
+        order[rank++] = pv;
+        for (int i = 0; i < m; ++i) {
+            if (i == pv) continue;
+            const double f = A[i][pv] / A[pv][pv];
+            if (f == 0.0) continue;
+            for (int j = 0; j <= m; ++j) A[i][j] -= f * A[pv][j];
+        }
+    }
+    for (int q = 0; q < 7; ++q) w7[q] = 0.0;  // column 0 is the constant: normalised to zero, minimum-norm weight 0
+    for (int k = 0; k < rank; ++k) w7[1 + idx[order[k]]] = A[order[k]][m] / A[order[k]][order[k]];
+}
+
+int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r, double T,
+                 int is_put, omc_result* res, double* weights7, double* stats16, float* sx_out, int32_t* tex_out)
+{
+    int rc;
+    if ((rc = bind_in(c))) return rc;
+    if ((rc = check_market(1.0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    if (c->distributed()) return fail(-8, "regressor 'ols7' runs on one GPU (its co-moments are not exchanged between ranks).");
+    omc::LsmWorkspace w;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w))) return rc;
+    if ((rc = c->scratch.ensure(omc::ols7_scratch_bytes(n_paths, n_steps)))) return rc;
+    omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
+    // pass 1 (:482-516): one sweep -> (n, mean, co-moments) of the 6 non-constant features and the target
+    const double* stats_dev = nullptr;
+    double st[omc::kOls7Stats];
+    HIP_TRY(omc::ols7_comoments(c->stream, p, w.D, c->scratch.p, &stats_dev));
+    HIP_TRY(hipMemcpyAsync(st, stats_dev, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double n = st[0];
+    // normalisation (:550-563): population std, zero std -> 1 (the column is then all zero)
+    double s16[16], sd[7], w7[7];
+    bool live[7];
+    for (int i = 0; i < 16; ++i) s16[i] = i < 7 ? 0.0 : 1.0;
+    s16[0] = 1.0;
+    s16[14] = 0.0;
+    for (int q = 0; q < 7; ++q) w7[q] = 0.0;
+    if (n > 0.0) {
+        for (int q = 0; q < 7; ++q) {
+            const double mean = st[1 + q], v = std::sqrt(st[8 + q * 7 - q * (q - 1) / 2] / n);
+            live[q] = v > 1e-13 * std::fabs(mean);
+            sd[q] = live[q] ? v : 1.0;
+        }
+        for (int q = 0; q < 6; ++q) {
+            s16[1 + q] = st[1 + q];
+            s16[8 + q] = sd[q];
+        }
+        s16[14] = st[7];
+        s16[15] = sd[6];
+        if (live[6]) ols7_solve(st, n, sd, live, w7);  // (a constant target: every weight 0, continuation = its mean)
+    }
+    // pass 2 (:615-651) with the fit, then the mean of the cash-flows valued at t = dt (:651)
+    HIP_TRY(omc::ols7_pass2(c->stream, p, s16, s16 + 7, w7, s16[14], s16[15], w.sx, w.tex));
+    HIP_TRY(omc::lsm_final_reduce(c->stream, p, w, 1));
+    HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(res, 0, sizeof *res);
+    fill_result(res, c->hres, n_paths);
+    res->sum_nitm = (int64_t)llround(n);
+    if (weights7) memcpy(weights7, w7, sizeof w7);
+    if (stats16) memcpy(stats16, s16, sizeof s16);
+    return 0;
+}
+
 int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const double* y, int64_t n_rows,
                          double T, double dt, double* out16)
 {

@@ -214,6 +214,12 @@ int localvol_param_count(int hidden, int layers);
 hipError_t localvol_paths(hipStream_t st, float* S, int64_t ld, int64_t M, int N, int layers, const float* params,
                           const float* Z, double S0, double r, double T, double K, double m_scale,
                           double tau_scale, double eps_out);
+// regressor "ols7" (omc_ols7.hip): ONE least-squares fit on the reference's seven features in the two-pass flow
+constexpr int kOls7Stats = 36;  // n, mean[7], C[28] (upper triangle, row-major) of [x, x^2, x^3, max(x-1,0), s, x*s, y]
+size_t ols7_scratch_bytes(int64_t M, int N);
+hipError_t ols7_comoments(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const double** stats_dev);
+hipError_t ols7_pass2(hipStream_t st, const LsmProblem& p, const double* feat_mean, const double* feat_std,
+                      const double* w7, double y_mean, double y_std, float* sx, int32_t* tex);
 // pass 1 of the NN flow straight from the path matrix (omc_rows.hip): count -> scan -> statistics -> rows
 size_t nn_rows_scratch_bytes(int64_t M, int N);
 hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const int64_t** total_dev,

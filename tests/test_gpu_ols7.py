@@ -1,0 +1,139 @@
+"""Regressor "ols7": the v3 two-pass flow (options_model_3.py:482-516, 542-563, 615-651) with ONE least-squares fit on the
+reference's seven features (:105-121) -- omc_lsm_ols7 (csrc/omc_ols7.hip: one co-moment sweep, a 6 x 6 solve on the host,
+the sticky pass 2) against the oracle (oracle.reference_flow.two_pass_ols7_regressor: numpy lstsq on the materialised
+design matrix) on the same float32 paths, against the fixture built with the reference's own feature function
+(tests/golden/poly_flows.npz ols7_mid_put_*) and against SURVEY's anchor 6.986699434012439 on the reference's seed-42
+paths."""
+import numpy as np
+import pytest
+
+from oracle import cpu as orc
+from oracle import reference_flow as rf
+
+pytestmark = pytest.mark.gpu
+
+K, R, SIG, T = 100.0, 0.05, 0.2, 1.0
+
+
+def _oracle(S32, K_, r, T_, is_put):
+    N = S32.shape[0] - 1
+    reg, pred = rf.two_pass_ols7_regressor(K_, T_, N)
+    return rf.lsm_two_pass(S32.astype(np.float64), K_, r, T_, is_put, reg, pred)
+
+
+def _cashflows(out, K_, r, T_, N, is_put):
+    sx = out["sx"].astype(np.float64)
+    pay = np.maximum((K_ - sx) if is_put else (sx - K_), 0)
+    return pay * np.exp(-r * (T_ / N) * (out["tex"].astype(np.float64) - 1))
+
+
+def _compare(ctx, S_dev, S32, K_, r, T_, is_put, max_flips=2):
+    N, M = S32.shape[0] - 1, S32.shape[1]
+    out = ctx.lsm_ols7(S_dev, K_, r, T_, is_put, want_state=True)
+    cf, ex, m = _oracle(S32, K_, r, T_, is_put)
+    if m is None:  # never in the money: no regression, nobody exercises (:518-519)
+        assert out["sum_nitm"] == 0 and np.all(out["weights"] == 0) and np.all(out["tex"] == N)
+        assert out["price"] == pytest.approx(float(cf.mean()), rel=1e-12, abs=1e-300)
+        return out, None
+    assert out["sum_nitm"] == m["R"]
+    # normalisers: float64 on both sides, merged triples vs numpy's pairwise sums
+    assert np.allclose(out["feat_mean"], m["fm"], rtol=1e-11, atol=0)
+    assert np.allclose(out["feat_std"], m["fs"], rtol=1e-9, atol=0)
+    assert out["y_mean"] == pytest.approx(float(m["Y_mean"]), rel=1e-11) and out["y_std"] == pytest.approx(float(m["Y_std"]), rel=1e-9)
+    # the FIT is compared through what pass 2 uses, its predictions on the regression rows' range (the weights of the
+    # nearly collinear x, x^2, x^3 columns move by 1e-7 between the normal equations and lstsq's SVD; predictions by 1e-10)
+    # (an underdetermined fit -- a handful of rows -- has many exact solutions that differ AWAY from the rows: there only the
+    # decisions, taken at the rows themselves, are compared)
+    xs = np.linspace(S32[1:N].min(), S32[1:N].max(), 64) if m["R"] >= 100 else np.zeros(0)
+    for t in (1, max(1, N // 2), max(1, N - 1)):
+        f = rf.regression_features(xs, K_, T_, t * T_ / N)
+        zn = (f - m["fm"]) / m["fs"]
+        ref = zn @ m["w"] * m["Y_std"] + m["Y_mean"]
+        got = ((f - out["feat_mean"]) / out["feat_std"]) @ out["weights"] * out["y_std"] + out["y_mean"]
+        assert np.allclose(got, ref, rtol=1e-7, atol=1e-7 * float(m["Y_std"]))
+    ex_h = out["tex"] < N
+    flips = int((ex_h != ex).sum())
+    moved = int((np.abs(_cashflows(out, K_, r, T_, N, is_put) - cf) > 2e-5).sum())
+    assert flips <= max_flips and moved <= 2 * max_flips + 1, (flips, moved, M)
+    assert out["price"] == pytest.approx(float(cf.mean()), rel=2e-5 if (flips or moved) else 1e-9)
+    return out, m
+
+
+def test_fixture_built_with_the_references_feature_function(ctx, golden):
+    """The reference's own paths (float64, rounded to the kernels' float32): R exact, the fit's predictions, the decisions and
+    the price of the fixture."""
+    g, pf = golden["paths"], golden["poly"]
+    S64 = g["gbm_mid_S"]
+    S32 = S64.astype(np.float32)
+    S = ctx.to_device(S32, np.float32)
+    out = ctx.lsm_ols7(S, K, R, T, True, want_state=True)
+    S.free()
+    N = S32.shape[0] - 1
+    assert abs(out["sum_nitm"] - int(pf["ols7_mid_put_R"])) <= 2  # float32 rounding of a spot sitting on the strike
+    assert np.allclose(out["feat_mean"], pf["ols7_mid_put_feat_mean"], rtol=2e-6, atol=1e-9)
+    assert np.allclose(out["feat_std"], pf["ols7_mid_put_feat_std"], rtol=2e-5, atol=1e-9)
+    flips = int(((out["tex"] < N) != pf["ols7_mid_put_ex"]).sum())
+    assert flips <= 2, flips
+    assert out["price"] == pytest.approx(float(pf["ols7_mid_put_cf"].mean()), rel=2e-3 if flips else 2e-5)
+
+
+def test_anchor_on_the_references_seed42_paths(ctx, golden):
+    """6.986699434012439 on the 10k x 50 paths the reference builds for RNGManager(42) (float64 there)."""
+    z_half = rf.RNGManager(42).get_child_rng().standard_normal((50, 5000))
+    S64 = rf.gbm_paths_from_normals(z_half, 100.0, R, SIG, T)
+    S32 = S64.astype(np.float32)
+    S = ctx.to_device(S32, np.float32)
+    out, m = _compare(ctx, S, S32, K, R, T, True)
+    S.free()
+    assert out["price"] == pytest.approx(6.986699434012439, rel=2e-4)  # float32 paths against the float64 anchor
+    assert abs(out["sum_nitm"] - 225_057) <= 2  # R of the float64 paths; float32 rounding of a spot sitting on the strike
+
+
+@pytest.mark.parametrize("M,N,is_put,S0,sigma", [
+    (20_000, 50, True, 100.0, 0.2), (20_000, 50, False, 100.0, 0.2), (4_098, 7, True, 100.0, 0.3), (130, 3, True, 100.0, 0.4),
+    (2, 2, True, 100.0, 0.5), (100_000, 25, True, 90.0, 0.2), (50_000, 60, False, 110.0, 0.25), (10_000, 130, True, 100.0, 0.2),
+])
+def test_gbm_matches_the_oracle_on_the_same_paths(ctx, M, N, is_put, S0, sigma):
+    S = ctx.gbm_paths(M, N, S0, R, sigma, T, 7, 3)
+    _compare(ctx, S, S.to_host(), K, R, T, is_put)
+    S.free()
+
+
+def test_heston_matches_the_oracle_on_the_same_paths(ctx):
+    S = ctx.heston_paths(40_000, 40, 100.0, R, T, 0.04, 2.0, 0.04, 0.3, -0.7, 11, 0, scheme=1)
+    for is_put in (True, False):
+        _compare(ctx, S, S.to_host(), K, R, T, is_put)
+    S.free()
+
+
+def test_never_in_the_money_and_constant_columns(ctx):
+    # a put that is never in the money: no rows, no exercise, the discounted terminal payoff (0)
+    S = ctx.gbm_paths(2_000, 10, 400.0, R, 0.1, T, 3, 0)
+    out, m = _compare(ctx, S, S.to_host(), K, R, T, True)
+    S.free()
+    assert m is None and out["price"] == 0.0
+    # N = 2: one decision date, the s column is constant (std 0 -> 1, weight 0) and x*s is collinear with x
+    S = ctx.gbm_paths(5_000, 2, 100.0, R, 0.3, T, 5, 0)
+    out, m = _compare(ctx, S, S.to_host(), K, R, T, True)
+    S.free()
+    assert out["feat_std"][5] == 1.0 and out["weights"][5] == 0.0 and out["weights"][0] == 0.0
+    assert out["feat_std"][4] == 1.0 and out["weights"][4] == 0.0  # max(x - 1, 0) is identically 0 for a put
+
+
+def test_facade_regressor_ols7(ctx):
+    from options_model_amd import price_american_option
+    r1 = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 200_000, 50, regressor="ols7", seed=42, ctx=ctx)
+    S = ctx.gbm_paths(200_000, 50, 100.0, 0.05, 0.2, 1.0, 42, 0)
+    direct = ctx.lsm_ols7(S, 100.0, 0.05, 1.0, True)
+    S.free()
+    assert r1.price == direct["price"] and r1.info["regressor"] == "ols7" and len(r1.info["weights"]) == 7
+    assert r1.semantics == "two_pass" and r1.sum_nitm == direct["sum_nitm"] and 0 < r1.stderr < 0.05
+    poly = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 200_000, 50, regressor="poly", seed=42, ctx=ctx)
+    assert abs(r1.price - poly.price) < 0.25  # another regressor in the same flow on the same paths: same ballpark
+    h = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 50_000, 40, model="Heston", option_type="call", regressor="ols7",
+                              heston_scheme="full_truncation", seed=5, ctx=ctx)
+    assert 8.0 < h.price < 13.0
+    with pytest.raises(ValueError, match="one GPU"):
+        price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 1000, 10, regressor="ols7", n_gpus=2)
+    with pytest.raises(ValueError, match="'poly', 'nn' or 'ols7'"):
+        price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 1000, 10, regressor="spline")

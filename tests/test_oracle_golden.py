@@ -105,6 +105,23 @@ def test_numpy_flows_reproduce_golden_exactly(golden, name):
     assert np.allclose(cf, pf[f"poly_mid_put_{name}_cf"], rtol=1e-12, atol=0)
 
 
+def test_ols7_flow_reproduces_the_fixture_built_with_the_references_features(golden):
+    """`ols7_mid_put_*` (tools/capture_golden.py flow_two_pass_ols7): the v3 control flow with ONE least-squares fit on the
+    design matrix the REFERENCE's create_regression_features builds (options_model_3.py:105-121), normalised as
+    :550-563.  The oracle's two_pass_ols7_regressor must give its weights, normalisers, decisions and cash-flows."""
+    g, pf = golden["paths"], golden["poly"]
+    S = g["gbm_mid_S"]
+    reg, pred = rf.two_pass_ols7_regressor(K, T, S.shape[0] - 1)
+    cf, ex, m = rf.lsm_two_pass(S, K, R, T, True, reg, pred)
+    assert m["R"] == int(pf["ols7_mid_put_R"])
+    assert np.allclose(m["fm"], pf["ols7_mid_put_feat_mean"], rtol=1e-13, atol=0)
+    assert np.allclose(m["fs"], pf["ols7_mid_put_feat_std"], rtol=1e-12, atol=0)
+    assert float(m["Y_mean"]) == pytest.approx(float(pf["ols7_mid_put_Y_mean"]), rel=1e-13)
+    assert float(m["Y_std"]) == pytest.approx(float(pf["ols7_mid_put_Y_std"]), rel=1e-13)
+    assert np.allclose(m["w"], pf["ols7_mid_put_w"], rtol=1e-7, atol=1e-9)  # x, x^2, x^3 are nearly collinear: cond ~ 1e6
+    assert np.array_equal(ex, pf["ols7_mid_put_ex"]) and np.allclose(cf, pf["ols7_mid_put_cf"], rtol=1e-12, atol=0)
+
+
 def _c1_paths(golden):
     c1 = golden["scalars"]["c1_seed42_gbm_put"]
     z_half = rf.RNGManager(42).get_child_rng().standard_normal((50, 5000))
