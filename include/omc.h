@@ -336,6 +336,8 @@ int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
  * distributed context). */
 int omc_lsm_ols7(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r, double T,
                  int is_put, omc_result* res, double* weights7, double* stats16, float* sx_out, int32_t* tex_out);
+/* the same as one fused call (paths into the context's own matrix, then omc_lsm_ols7): the facade's regressor="ols7" */
+int omc_price_american_ols7(omc_ctx* ctx, const omc_params* p, omc_result* res, double* weights7, double* stats16);
 /* Normalisers of the training rows (options_model_3.py:550-563) in float64: for rows i < n_rows
  * with x[i] = S/K, step index t[i] and target y[i] (device arrays), out16[0..6] = means of
  * [x, x^2, x^3, max(x-1,0), s, x*s, y] with s = sqrt(max(T - t*dt, 1e-6)), out16[8..14] =

@@ -109,6 +109,7 @@ SIGNATURES = {
     "omc_mlp_train_epoch_batch": (C.c_int, [_P, C.POINTER(MlpJob), _I, _I, _I] + [_D] * 5),
     "omc_mlp_shuffle_indices": (C.c_int, [_P, _I64, _U64, _P]),
     "omc_mlp_train_variant": (C.c_int, [C.c_int, C.c_int, _I64]),
+    "omc_price_american_ols7": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result), _P, _P]),
     "omc_lsm_ols7": (C.c_int, [_P, _P, _I64, _I64, _I, _D, _D, _D, _I, C.POINTER(Result), _P, _P, _P, _P]),
     "omc_ctx_device_info": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int]),
     "omc_mlp_dropout_masks": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _I64, _P, C.c_uint32, _U64, C.c_double, _P]),
@@ -519,6 +520,16 @@ class Context:
             self.handle, C.byref(params), C.byref(res), keep_paths.ptr if keep_paths else None,
             keep_paths.shape[1] if keep_paths else 0))
         return res.as_dict()
+
+    def price_american_ols7(self, params: Params):
+        """Fused pricing with regressor "ols7" (paths + omc_lsm_ols7 in the context's own matrix) -> result dict + fit."""
+        res = Result()
+        w, st = np.zeros(7), np.zeros(16)
+        _check(self.lib, self.lib.omc_price_american_ols7(self.handle, C.byref(params), C.byref(res), w.ctypes.data,
+                                                           st.ctypes.data))
+        d = res.as_dict()
+        d.update(weights=w, feat_mean=st[:7].copy(), feat_std=st[7:14].copy(), y_mean=float(st[14]), y_std=float(st[15]))
+        return d
 
     def price_european(self, params: Params):
         res = Result()

@@ -120,17 +120,10 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
         if M <= 0:
             raise ValueError("num_simulations and num_time_steps must be positive integers.")
         c = ctx or _ffi.default_context(_ffi.resolve_device(None) if device is None else device)
-        if model_l == "heston":
-            hp = heston_defaults(sigma, heston_params)
-            sch = _ffi.HESTON_SCHEMES[heston_scheme] if isinstance(heston_scheme, str) else int(heston_scheme)
-            S = c.heston_paths(M, int(n_steps), S0, r, T, hp["v0"], hp["kappa"], hp["theta"], hp["xi"], hp["rho"], seed, stream,
-                               scheme=sch)
-        else:
-            S = c.gbm_paths(M, int(n_steps), S0, r, sigma, T, seed, stream, antithetic=antithetic)
-        try:
-            out = c.lsm_ols7(S, K, r, T, option_type == "put")
-        finally:
-            S.free()
+        out = c.price_american_ols7(_ffi.make_params(
+            model=model_l, is_put=(option_type == "put"), semantics="two_pass", antithetic=antithetic,
+            heston_scheme=heston_scheme, n_paths=M, n_steps=int(n_steps), S0=S0, K=K, r=r, sigma=sigma or 0.0, T=T, seed=seed,
+            stream=stream, **heston_defaults(sigma, heston_params)))
         var = max(out["sumsq"] / M - out["price"] ** 2, 0.0)
         return PriceResult(price=out["price"], stderr=math.sqrt(var / M), std=out["std"], zero_prob=out["zero_prob"], n_paths=M,
                            n_exercised=out["n_exercised"], sum_nitm=out["sum_nitm"], model=model_l, semantics="two_pass",

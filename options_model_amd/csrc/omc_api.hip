@@ -2250,6 +2250,19 @@ int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     return 0;
 }
 
+int omc_price_american_ols7(omc_ctx* c, const omc_params* p, omc_result* res, double* weights7, double* stats16)
+{
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if ((rc = check_params(p))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    const int64_t ld = (p->n_paths + 63) / 64 * 64;
+    if ((rc = c->S.ensure(sizeof(float) * (size_t)ld * (size_t)(p->n_steps + 1)))) return rc;  // the context's own path matrix
+    if ((rc = enqueue_paths(c, p, (float*)c->S.p, ld))) return rc;
+    return omc_lsm_ols7(c, (const float*)c->S.p, ld, p->n_paths, p->n_steps, p->K, p->r, p->T, p->is_put ? 1 : 0, res, weights7,
+                        stats16, nullptr, nullptr);
+}
+
 int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const double* y, int64_t n_rows,
                          double T, double dt, double* out16)
 {

@@ -36,15 +36,24 @@ def _compare(ctx, S_dev, S32, K_, r, T_, is_put, max_flips=2):
         assert out["price"] == pytest.approx(float(cf.mean()), rel=1e-12, abs=1e-300)
         return out, None
     assert out["sum_nitm"] == m["R"]
-    # normalisers: float64 on both sides, merged triples vs numpy's pairwise sums
-    assert np.allclose(out["feat_mean"], m["fm"], rtol=1e-11, atol=0)
-    assert np.allclose(out["feat_std"], m["fs"], rtol=1e-9, atol=0)
-    assert out["y_mean"] == pytest.approx(float(m["Y_mean"]), rel=1e-11) and out["y_std"] == pytest.approx(float(m["Y_std"]), rel=1e-9)
+    # normalisers: float64 on both sides; the looser side is numpy's (a column mean over axis 0 of the R x 7 matrix is a
+    # plain running sum: ~R eps), the kernel's merged triples are good to ~1e-15
+    assert np.allclose(out["feat_mean"], m["fm"], rtol=1e-9, atol=0)
+    # a constant column: the kernel's merged triples give variance exactly 0 (-> std 1, :562); numpy's np.std of the same
+    # column may return rounding noise (4e-14 seen for s with one decision date) -- which the reference would divide by
+    const = m["fs"] <= 1e-12 * np.maximum(np.abs(m["fm"]), 1e-300)
+    assert np.all(out["feat_std"][const] == 1.0)
+    assert np.allclose(out["feat_std"][~const], m["fs"][~const], rtol=1e-8, atol=0)
+    assert out["y_mean"] == pytest.approx(float(m["Y_mean"]), rel=1e-9) and out["y_std"] == pytest.approx(float(m["Y_std"]), rel=1e-8)
     # the FIT is compared through what pass 2 uses, its predictions on the regression rows' range (the weights of the
     # nearly collinear x, x^2, x^3 columns move by 1e-7 between the normal equations and lstsq's SVD; predictions by 1e-10)
     # (an underdetermined fit -- a handful of rows -- has many exact solutions that differ AWAY from the rows: there only the
     # decisions, taken at the rows themselves, are compared)
-    xs = np.linspace(S32[1:N].min(), S32[1:N].max(), 64) if m["R"] >= 100 else np.zeros(0)
+    # -- and on IN-THE-MONEY spots, the only ones pass 2 asks about: for a call max(x - 1, 0) = x - 1 on every row, exactly
+    # collinear with x, and the two solutions of that singular system differ out of the money.
+    body = S32[1:N].astype(np.float64)
+    itm_spots = body[rf.payoff(body, K_, is_put) > 0]
+    xs = np.quantile(itm_spots, np.linspace(0.0, 1.0, 64)) if m["R"] >= 100 else np.zeros(0)
     for t in (1, max(1, N // 2), max(1, N - 1)):
         f = rf.regression_features(xs, K_, T_, t * T_ / N)
         zn = (f - m["fm"]) / m["fs"]
@@ -129,7 +138,7 @@ def test_facade_regressor_ols7(ctx):
     assert r1.price == direct["price"] and r1.info["regressor"] == "ols7" and len(r1.info["weights"]) == 7
     assert r1.semantics == "two_pass" and r1.sum_nitm == direct["sum_nitm"] and 0 < r1.stderr < 0.05
     poly = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 200_000, 50, regressor="poly", seed=42, ctx=ctx)
-    assert abs(r1.price - poly.price) < 0.25  # another regressor in the same flow on the same paths: same ballpark
+    assert abs(r1.price - poly.price) < 0.6  # another regressor (one global fit, not one per step) on the same paths: same ballpark
     h = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 50_000, 40, model="Heston", option_type="call", regressor="ols7",
                               heston_scheme="full_truncation", seed=5, ctx=ctx)
     assert 8.0 < h.price < 13.0
