@@ -19,7 +19,9 @@ import sys
 
 def _result_dict(res):
     d = dataclasses.asdict(res)
-    d["info"] = {k: v for k, v in d.get("info", {}).items() if isinstance(v, (int, float, str, bool, type(None)))}
+    plain = (int, float, str, bool, type(None))
+    d["info"] = {k: v for k, v in d.get("info", {}).items()
+                 if isinstance(v, plain) or (isinstance(v, list) and all(isinstance(x, plain) for x in v))}
     return d
 
 

@@ -110,26 +110,6 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
         raise ValueError(f"semantics must be one of {sorted(set(_SEM))}.")
     if regressor not in ("poly", "nn", "ols7"):
         raise ValueError("regressor must be 'poly', 'nn' or 'ols7'.")
-    if regressor == "ols7":
-        # ONE global least-squares fit on the reference's seven features (options_model_3.py:105-121) in its two-pass flow
-        # (omc_lsm_ols7): the linear regressor between the per-step polynomial and the network.  One GPU.
-        if n_gpus > 1:
-            raise ValueError("regressor='ols7' runs on one GPU (n_gpus must be 1).")
-        _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
-        M = int(n_paths) // 2 * 2 if antithetic else int(n_paths)
-        if M <= 0:
-            raise ValueError("num_simulations and num_time_steps must be positive integers.")
-        c = ctx or _ffi.default_context(_ffi.resolve_device(None) if device is None else device)
-        out = c.price_american_ols7(_ffi.make_params(
-            model=model_l, is_put=(option_type == "put"), semantics="two_pass", antithetic=antithetic,
-            heston_scheme=heston_scheme, n_paths=M, n_steps=int(n_steps), S0=S0, K=K, r=r, sigma=sigma or 0.0, T=T, seed=seed,
-            stream=stream, **heston_defaults(sigma, heston_params)))
-        var = max(out["sumsq"] / M - out["price"] ** 2, 0.0)
-        return PriceResult(price=out["price"], stderr=math.sqrt(var / M), std=out["std"], zero_prob=out["zero_prob"], n_paths=M,
-                           n_exercised=out["n_exercised"], sum_nitm=out["sum_nitm"], model=model_l, semantics="two_pass",
-                           option_type=option_type,
-                           info=dict(regressor="ols7", weights=[float(v) for v in out["weights"]], y_mean=out["y_mean"],
-                                     y_std=out["y_std"]))
     if n_gpus > 1 and not _in_job(n_gpus):
         # a plain process: validate here (the reference's messages), then let the rank pool do the collective call
         if ctx is not None:
@@ -148,10 +128,37 @@ def price_american_option(S0, K, r, sigma, T, n_paths, n_steps, model="GBM", opt
             kw.update(nn_options or {})
             d = launcher.pool(n_gpus, devices).call("price_american_option_nn", kw, timeout_s=3600.0)
         else:
-            kw.update(regressor="poly", semantics=semantics, heston_scheme=heston_scheme, antithetic=bool(antithetic))
+            kw.update(regressor=regressor, semantics=semantics, heston_scheme=heston_scheme, antithetic=bool(antithetic))
             d = launcher.pool(n_gpus, devices).call("price_american_option", kw)
         d["info"] = dict(d.get("info", {}), launched_ranks=n_gpus)
         return PriceResult(**d)
+    if regressor == "ols7":
+        # ONE global least-squares fit on the reference's seven features (options_model_3.py:105-121) in its two-pass flow
+        # (omc_price_american_ols7): the linear regressor between the per-step polynomial and the network.  Across GPUs the
+        # paths shard by antithetic pair and the ranks' co-moments are merged by two small all-reduces: the fit is the job's.
+        _validate(S0, K, T, r, sigma, n_paths, n_steps, option_type, need_sigma=(model_l == "gbm"))
+        M = int(n_paths) // 2 * 2 if antithetic else int(n_paths)
+        if M <= 0:
+            raise ValueError("num_simulations and num_time_steps must be positive integers.")
+        kwp = dict(model=model_l, is_put=(option_type == "put"), semantics="two_pass", antithetic=antithetic,
+                   heston_scheme=heston_scheme, n_steps=int(n_steps), S0=S0, K=K, r=r, sigma=sigma or 0.0, T=T, seed=seed,
+                   stream=stream, **heston_defaults(sigma, heston_params))
+        info = dict(regressor="ols7")
+        if n_gpus > 1:
+            if ctx is not None:
+                raise ValueError("n_gpus > 1 uses the job's own per-rank context; do not pass ctx.")
+            sp = _job_pricer(n_gpus, device)
+            out = sp.price_american_ols7(M, **kwp)
+            info.update(n_gpus=n_gpus, rank=sp.rank, transport=sp.transport)
+        else:
+            c = ctx or _ffi.default_context(_ffi.resolve_device(None) if device is None else device)
+            out = c.price_american_ols7(_ffi.make_params(n_paths=M, **kwp))
+        Mg = out["n_paths"]
+        var = max(out["sumsq"] / Mg - out["price"] ** 2, 0.0)
+        info.update(weights=[float(v) for v in out["weights"]], y_mean=out["y_mean"], y_std=out["y_std"])
+        return PriceResult(price=out["price"], stderr=math.sqrt(var / Mg), std=out["std"], zero_prob=out["zero_prob"], n_paths=Mg,
+                           n_exercised=out["n_exercised"], sum_nitm=out["sum_nitm"], model=model_l, semantics="two_pass",
+                           option_type=option_type, info=info)
     if regressor == "nn":
         if n_gpus > 1:
             from . import nn_dist

@@ -2203,7 +2203,6 @@ int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
     if (!res) return fail(-7, "null result pointer.");
-    if (c->distributed()) return fail(-8, "regressor 'ols7' runs on one GPU (its co-moments are not exchanged between ranks).");
     omc::LsmWorkspace w;
     if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w))) return rc;
     if ((rc = c->scratch.ensure(omc::ols7_scratch_bytes(n_paths, n_steps)))) return rc;
@@ -2214,6 +2213,32 @@ int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     HIP_TRY(omc::ols7_comoments(c->stream, p, w.D, c->scratch.p, &stats_dev));
     HIP_TRY(hipMemcpyAsync(st, stats_dev, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->distributed()) {
+        // The fit is over ALL ranks' rows (paths shard by antithetic pair, the regression does not): the ranks' triples
+        // (n_r, mean_r, C_r) are merged by Chan's formula for any number of ranks at once -- (1) sum of n_r mean_r and
+        // n_r -> the global means; (2) sum of C_r + n_r (mean_r - mean)(mean_r - mean)^T -> the global co-moments -- the
+        // "regression moments" all-reduce of north_star, 8 + 28 doubles.  Every rank then solves the same 6 x 6 system.
+        if ((rc = c->seq_vote.ensure(sizeof(double) * 40))) return rc;
+        const double nr = st[0];
+        double v[8], mr[7];
+        for (int q = 0; q < 7; ++q) {
+            mr[q] = st[1 + q];
+            v[q] = nr * mr[q];
+        }
+        v[7] = nr;
+        if ((rc = allreduce_host(c, (double*)c->seq_vote.p, v, 8))) return rc;
+        const double ng = v[7];
+        double cg[28];
+        for (int i = 0, k = 0; i < 7; ++i)
+            for (int j = i; j < 7; ++j, ++k) {
+                const double di = ng > 0.0 ? mr[i] - v[i] / ng : 0.0, dj = ng > 0.0 ? mr[j] - v[j] / ng : 0.0;
+                cg[k] = nr > 0.0 ? st[8 + k] + nr * di * dj : 0.0;
+            }
+        if ((rc = allreduce_host(c, (double*)c->seq_vote.p, cg, 28))) return rc;
+        st[0] = ng;
+        for (int q = 0; q < 7; ++q) st[1 + q] = ng > 0.0 ? v[q] / ng : 0.0;
+        for (int k = 0; k < 28; ++k) st[8 + k] = cg[k];
+    }
     const double n = st[0];
     // normalisation (:550-563): population std, zero std -> 1 (the column is then all zero)
     double s16[16], sd[7], w7[7];
@@ -2239,12 +2264,13 @@ int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     // pass 2 (:615-651) with the fit, then the mean of the cash-flows valued at t = dt (:651)
     HIP_TRY(omc::ols7_pass2(c->stream, p, s16, s16 + 7, w7, s16[14], s16[15], w.sx, w.tex));
     HIP_TRY(omc::lsm_final_reduce(c->stream, p, w, 1));
+    if (c->distributed() && (rc = allreduce(c, w.result, 8))) return rc;  // the discounted-payoff sums of all ranks
     HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
     if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     memset(res, 0, sizeof *res);
-    fill_result(res, c->hres, n_paths);
-    res->sum_nitm = (int64_t)llround(n);
+    fill_result(res, c->hres, c->distributed() ? n_paths * c->world : n_paths, c->distributed() ? c->world : 1);
+    res->sum_nitm = (int64_t)llround(n);  // rows of the regression (of the job)
     if (weights7) memcpy(weights7, w7, sizeof w7);
     if (stats16) memcpy(stats16, s16, sizeof s16);
     return 0;

@@ -79,6 +79,15 @@ class _ShardedBase:
         out["local"] = res
         return out
 
+    def price_american_ols7(self, n_paths_global: int, **kw) -> dict:
+        """Regressor "ols7" sharded: this rank's paths, the job's fit and sums (omc_price_american_ols7 on a distributed
+        context merges the ranks' co-moments and adds their result sums)."""
+        anti = kw.get("antithetic", True)
+        n_local, off = shard(n_paths_global, self.world, self.rank, anti)
+        p = self._ffi.make_params(n_paths=n_local, pair_offset=off, **kw)
+        with self._enter():
+            return self.ctx.price_american_ols7(p)
+
     def price_american_seq(self, n_paths_global: int, streams, **kw) -> list:
         """len(streams) pricings (one Philox stream id each) enqueued back to back, one wait at the end;
         the all-reduces are stream-ordered, so no rank waits on the host in between."""

@@ -51,6 +51,21 @@ def test_facade_starts_its_own_ranks_and_equals_the_unsharded_pricing(ctx, plain
     assert again.n_paths == 200_000 and [p.pid for p in plain_process.pool(world, [0] * world).procs] == pids
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_regressor_ols7_shards_its_fit_over_the_ranks(ctx, plain_process, world):
+    """regressor="ols7" with n_gpus = N from a plain process: every rank sweeps its own paths, the ranks' (n, mean, co-moment)
+    triples are merged by two small all-reduces, every rank solves the same 6 x 6 system -- the fit and the price of the
+    unsharded pricing (same Philox pairs; sums in another order)."""
+    from options_model_amd import price_american_option
+    for kw in (dict(option_type="put"), dict(option_type="call", model="Heston", heston_scheme="full_truncation")):
+        r = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 120_000, 30, regressor="ols7", seed=9, stream=1, n_gpus=world,
+                                  device=0, **kw)
+        one = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 120_000, 30, regressor="ols7", seed=9, stream=1, ctx=ctx, **kw)
+        assert r.info["launched_ranks"] == world and r.n_paths == 120_000 and r.sum_nitm == one.sum_nitm
+        assert r.info["weights"] == pytest.approx(one.info["weights"], rel=1e-6, abs=1e-9)
+        assert r.n_exercised == one.n_exercised and r.price == pytest.approx(one.price, rel=1e-12)
+
+
 def test_advanced_pricer_n_gpus_from_a_plain_process(ctx, plain_process, golden):
     """The v3 class with the reference's own arguments plus n_gpus: same child seeds, same price as one GPU."""
     from options_model_amd import AdvancedOptionPricer, RNGManager

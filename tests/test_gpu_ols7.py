@@ -142,7 +142,5 @@ def test_facade_regressor_ols7(ctx):
     h = price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 50_000, 40, model="Heston", option_type="call", regressor="ols7",
                               heston_scheme="full_truncation", seed=5, ctx=ctx)
     assert 8.0 < h.price < 13.0
-    with pytest.raises(ValueError, match="one GPU"):
-        price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 1000, 10, regressor="ols7", n_gpus=2)
     with pytest.raises(ValueError, match="'poly', 'nn' or 'ols7'"):
         price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 1000, 10, regressor="spline")
