@@ -67,6 +67,15 @@ int main()
     REQUIRE(omc_mlp_param_count(64, 2) > 0 && omc_mlp_param_count(63, 2) < 0);
     REQUIRE(omc_localvol_param_count(64, 4) > 0);
     REQUIRE(omc_mlp_train_supported(128, 3, 256) == 1 && omc_mlp_train_supported(32, 2, 256) == 1 && omc_mlp_train_supported(32, 3, 256) == 0 && omc_mlp_train_supported(48, 2, 256) == 0);
+    // round 5's entry points: which trainer kernel a minibatch runs (host arithmetic), and the failure branches of the rest
+    REQUIRE(omc_mlp_train_variant(128, 3, 256) == 4 && omc_mlp_train_variant(128, 3, 4096) == 4 && omc_mlp_train_variant(128, 3, 4097) == 3);
+    REQUIRE(omc_mlp_train_variant(128, 3, 8193) == 2 && omc_mlp_train_variant(64, 2, 1024) == 4 && omc_mlp_train_variant(64, 2, 1025) == 1);
+    REQUIRE(omc_mlp_train_variant(32, 2, 5000) == 3 && omc_mlp_train_variant(48, 2, 256) == 0 && omc_mlp_train_variant(64, 4, 256) == 0);
+    unsigned char mask[64];
+    REQUIRE(omc_mlp_dropout_masks(nullptr, 4, 64, 1, 1, nullptr, 1, 1, 0.1, mask) != 0);
+    REQUIRE(omc_ctx_device_info(nullptr, nullptr, nullptr, 0, nullptr, 0) != 0);
+    REQUIRE(omc_lsm_ols7(nullptr, nullptr, 0, 1000, 10, 100.0, 0.05, 1.0, 1, &res, nullptr, nullptr, nullptr, nullptr) != 0);
+    REQUIRE(omc_price_american_ols7(nullptr, &p, &res, nullptr, nullptr) != 0);
     if (ctx) omc_ctx_destroy(ctx);
 
     // ---- batched path: slab planning and the per-problem table (host arithmetic only; the "device"
