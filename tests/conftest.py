@@ -19,7 +19,7 @@ def pytest_configure(config):
 # oracle, config 5 against the reference's trained nets, the full-size configs), then the kernels against autograd,
 # then the wider entry points, and the multi-process / timing-sensitive files LAST.  Files not named keep their
 # alphabetical order between the two groups.
-_FIRST = ["test_gpu_parity.py", "test_gpu_fuzz.py", "test_gpu_nn.py", "test_gpu_nn_full.py", "test_gpu_large.py",
+_FIRST = ["test_gpu_parity.py", "test_gpu_quirks.py", "test_gpu_fuzz.py", "test_gpu_nn.py", "test_gpu_nn_full.py", "test_gpu_large.py",
           "test_gpu_api.py", "test_gpu_contnet.py", "test_gpu_calibrator.py", "test_gpu_localvol.py", "test_gpu_mlp.py"]
 _LAST = ["test_gpu_step_multi.py", "test_gpu_dist.py", "test_gpu_multirank.py", "test_gpu_facade_ranks.py",
          "test_gpu_nn_dist.py"]
