@@ -15,7 +15,6 @@ the price -- does not depend on the number of shards.  Only two things cross GPU
 from __future__ import annotations
 
 import math
-import time
 
 
 def shard(n_paths_global: int, world: int, rank: int, antithetic: bool = True):

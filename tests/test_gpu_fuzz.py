@@ -3,12 +3,51 @@ aligned path counts, 1..70 steps), both option types, all three flows, both mode
 and off, shard offsets.  Every case: same Philox stream on both sides -> paths within the
 numerics-contract tolerance, exercise state identical wherever the paths agree to the last bit,
 price within 1e-9 on the device's own paths."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import cpu as orc
+from oracle import reference_flow as rf
 
 pytestmark = pytest.mark.gpu
+
+# soak runs: OMC_FUZZ_SCALE multiplies the number of cases of every sweep, OMC_FUZZ_SEED shifts their seeds
+# (tools/gpu_r05.sh soak; the committed record is profiles/r05_fuzz_soak.txt)
+_SCALE = int(os.environ.get("OMC_FUZZ_SCALE", "1"))
+_SHIFT = int(os.environ.get("OMC_FUZZ_SEED", "0"))
+
+
+def _smallest_margin(S, K, r, T, is_put, sem):
+    """min |immediate - continuation| / K over all decisions of the numpy restatement of the flow on the paths S: a TIE
+    (the strict '>' decided by the last bit) is the one situation in which two correct implementations may count another
+    number of exercised paths -- at the same price, since both branches of a tie are worth the same."""
+    best = [np.inf]
+
+    def note(x, cont):
+        imm = K * (1.0 - x) if is_put else K * (x - 1.0)
+        if cont is not None and cont.size:
+            best[0] = min(best[0], float(np.abs(imm - cont).min()) / K)
+
+    S = S.astype(np.float64)
+    if sem == "two_pass":
+        regress, predict = rf.two_pass_poly_regressor(K)
+
+        def pred(model, t, s):
+            cont = predict(model, t, s)
+            note(s / K, cont)
+            return cont
+
+        rf.lsm_two_pass(S, K, r, T, is_put, regress, pred)
+    else:
+        def fit(x, y):
+            b, cont = rf._fit_poly2(x, y)
+            note(x, cont)
+            return b, cont
+
+        rf.lsm_per_step(S, K, r, T, is_put, textbook=(sem == "textbook"), fit=fit)
+    return best[0]
 
 
 def _cases(n, seed):
@@ -31,7 +70,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(40, 20250101), ids=lambda c: f"{c['model']}-{c['sem']}-{c['M']}x{c['N']}")
+@pytest.mark.parametrize("case", _cases(40 * _SCALE, 20250101 + _SHIFT), ids=lambda c: f"{c['model']}-{c['sem']}-{c['M']}x{c['N']}")
 def test_fused_pricing_matches_oracle(ctx, case):
     from options_model_amd import _ffi
     c = case
@@ -56,9 +95,15 @@ def test_fused_pricing_matches_oracle(ctx, case):
     assert np.abs(Sg / So - 1).max() <= tol
     # backward induction on the DEVICE's paths by the oracle: the fused call must agree to 1e-9
     ref = orc.lsm_poly(Sg, c["K"], c["r"], c["T"], c["is_put"], c["sem"])
-    assert abs(res["price"] - ref["price"]) <= 1e-9 * max(abs(ref["price"]), 1e-12) + 1e-15
-    assert (res["n_exercised"], res["n_zero"], res["sum_nitm"]) == (ref["n_exercised"], ref["n_zero"],
-                                                                    ref["sum_nitm"])
+    same = (abs(res["price"] - ref["price"]) <= 1e-9 * max(abs(ref["price"]), 1e-12) + 1e-15
+            and (res["n_exercised"], res["n_zero"], res["sum_nitm"]) == (ref["n_exercised"], ref["n_zero"], ref["sum_nitm"]))
+    if not same:
+        # Two soak runs (2 x 29,600 cases, profiles/r05_fuzz_soak.txt) found five such cases, all alike: Heston, r = 0, four
+        # or six paths, the variance clamped to 0 -- the spot stands still, the immediate payoff EQUALS the cash-flow the
+        # path gets later, a fit on three rows interpolates it: an exact tie, decided by the last bit of the fitted value
+        # (and, through the sticky mask, moving the path's later decisions).  The device is deterministic there (60
+        # repetitions, fresh contexts: one answer); it and the oracle just round differently.  Anything else is a failure.
+        assert c["M"] <= 64 and _smallest_margin(Sg, c["K"], c["r"], c["T"], c["is_put"], c["sem"]) <= 1e-10, (res, ref)
 
 
 def _seq_cases(n, seed):
@@ -76,7 +121,7 @@ def _seq_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _seq_cases(24, 20261004), ids=lambda c: f"{c['model']}-{c['sem']}-{c['M']}x{c['N']}-n{c['n']}-k{c['k']}")
+@pytest.mark.parametrize("case", _seq_cases(24 * _SCALE, 20261004 + _SHIFT), ids=lambda c: f"{c['model']}-{c['sem']}-{c['M']}x{c['N']}-n{c['n']}-k{c['k']}")
 def test_sequences_sharing_their_launches_match_single_calls(ctx, case):
     """Round 3: K pricings per launch of the per-timestep kernel.  Random geometry, sequence length and batch width:
     every pricing of the sequence returns the bits of its own call (which the test above ties to the oracle)."""
@@ -112,7 +157,7 @@ def _cn_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cn_cases(10, 77), ids=lambda c: f"h{c['hidden']}-e{c['epochs']}-n{len(c['probs'])}")
+@pytest.mark.parametrize("case", _cn_cases(10 * _SCALE, 77 + _SHIFT), ids=lambda c: f"h{c['hidden']}-e{c['epochs']}-n{len(c['probs'])}")
 def test_contnet_batches_match_single_calls(ctx, case):
     """Round 3: the v1 / v2 regressor for many pricings at once; random mixes of sizes (incl. ones without 16-byte
     access), widths and epoch counts (0 epochs: the fresh net decides): batch == single calls, bit for bit."""
