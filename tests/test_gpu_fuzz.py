@@ -170,3 +170,30 @@ def test_contnet_batches_match_single_calls(ctx, case):
         one = ctx.price_american_contnet(p, case["hidden"], case["epochs"], 1e-3, s)
         for k in ("price", "sum", "sumsq", "n_exercised", "n_zero", "sum_nitm", "n_paths"):
             assert b[k] == one[k], (k, b[k], one[k])
+
+
+def _ols7_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append(dict(model="heston" if rng.random() < 0.3 else "gbm",
+                        M=int(rng.choice([200, 254, 1000, 1026, 4096, 10_000, 20_002])), N=int(rng.choice([2, 3, 5, 8, 16, 33, 50])),
+                        is_put=bool(rng.integers(0, 2)), S0=float(rng.choice([85.0, 100.0, 115.0])), K=100.0,
+                        r=float(rng.choice([0.0, 0.03, 0.08])), sigma=float(rng.choice([0.1, 0.2, 0.45])),
+                        T=float(rng.choice([0.1, 1.0, 2.5])), seed=int(rng.integers(1, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("case", _ols7_cases(12 * _SCALE, 4242 + _SHIFT), ids=lambda c: f"{c['model']}-{c['M']}x{c['N']}")
+def test_ols7_flow_matches_the_numpy_restatement(ctx, case):
+    """Round 5: the regressor "ols7" (one co-moment sweep, 6 x 6 normal equations, sticky pass 2) against
+    oracle.reference_flow.two_pass_ols7_regressor (numpy lstsq on the materialised R x 7 matrix) on the device's own
+    paths: row count exact, normalisers, predictions on the in-the-money range, decisions (<= 2 boundary flips), price."""
+    from test_gpu_ols7 import _compare
+    c = case
+    if c["model"] == "gbm":
+        S = ctx.gbm_paths(c["M"], c["N"], c["S0"], c["r"], c["sigma"], c["T"], c["seed"], 0)
+    else:
+        S = ctx.heston_paths(c["M"], c["N"], c["S0"], c["r"], c["T"], 0.04, 2.0, 0.05, 0.4, -0.6, c["seed"], 0, scheme=0)
+    _compare(ctx, S, S.to_host(), c["K"], c["r"], c["T"], c["is_put"])
+    S.free()
