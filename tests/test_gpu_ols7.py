@@ -61,7 +61,7 @@ def _compare(ctx, S_dev, S32, K_, r, T_, is_put, max_flips=2):
     # (a direction that is null BY CONSTRUCTION -- max(x - 1, 0) = x - 1 on every row of a call -- is harmless: both solvers
     # drop it and the predictions on in-the-money spots do not depend on how; relative singular value ~1e-17)
     rel = np.linalg.svd(((X - m["fm"]) / m["fs"])[:, ~const], compute_uv=False)
-    rel = rel / rel[0]
+    rel = rel / rel[0] if rel.size and rel[0] > 0 else np.zeros(1)
     if m["R"] < 100 or ((rel > 1e-13) & (rel < 1e-6)).any():
         return out, m
     # ... AT THE ROWS (a sample of them, every date represented): what the least-squares problem determines even when a
