@@ -197,3 +197,72 @@ def test_ols7_flow_matches_the_numpy_restatement(ctx, case):
         S = ctx.heston_paths(c["M"], c["N"], c["S0"], c["r"], c["T"], 0.04, 2.0, 0.05, 0.4, -0.6, c["seed"], 0, scheme=0)
     _compare(ctx, S, S.to_host(), c["K"], c["r"], c["T"], c["is_put"])
     S.free()
+
+
+def _mask_cases(n, seed):
+    from oracle import dropout as dr
+    rng = np.random.default_rng(seed)
+    shapes = [(dr.GROUP, 64), (dr.TILE, 64), (dr.TILE, 128), (dr.QUAD, 32), (dr.QUAD, 64), (dr.QUAD, 128), (dr.Q16, 64),
+              (dr.Q16, 128), (0, 64), (0, 128)]  # 0: pass 2 (mlp_apply_kernel), keyed by path column and time step
+    out = []
+    for _ in range(n):
+        variant, hidden = shapes[int(rng.integers(0, len(shapes)))]
+        out.append(dict(variant=variant, hidden=hidden, layers=2 if hidden == 32 else int(rng.integers(2, 4)),
+                        rows=int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 255, 257, 1000, 4097])),
+                        step=int(rng.choice([1, 2, 255, 256, 65_535, 65_536, 22_050, 2 ** 31 - 1])),
+                        seed=int(rng.integers(0, 2 ** 63)), p=float(rng.choice([0.0, 0.05, 0.1, 0.25, 0.5, 0.9])),
+                        keyed=bool(rng.integers(0, 2)), kseed=int(rng.integers(0, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("case", _mask_cases(24 * _SCALE, 555 + _SHIFT),
+                         ids=lambda c: f"v{c['variant']}-h{c['hidden']}x{c['layers']}-r{c['rows']}-p{c['p']}")
+def test_dropout_masks_equal_the_oracle(ctx, case):
+    """Round 5: the kernels' dropout masks (omc_mlp_dropout_masks runs their own relu_dropout* functions) against
+    oracle/dropout.py, bit for bit, over random kernels / shapes / row counts / optimizer steps / 63-bit seeds / rates /
+    row keys (the sharded trainer's positions, pass 2's path columns up to 2^32 - 1)."""
+    from oracle import dropout as dr
+    c = case
+    keys = None
+    if c["keyed"] or c["variant"] == 0:
+        keys = np.random.default_rng(c["kseed"]).integers(0, 2 ** 32, c["rows"], dtype=np.uint64).astype(np.uint32)
+    got = ctx.mlp_dropout_masks(c["variant"], c["hidden"], c["layers"], c["rows"], c["step"], c["seed"], c["p"], keys=keys)
+    rows = np.arange(c["rows"]) if keys is None else keys.astype(np.int64)
+    if c["variant"] == 0:
+        want = dr.apply_masks(c["hidden"], c["layers"], rows, c["step"], c["seed"], c["p"])
+    else:
+        want = dr.train_masks(c["variant"], c["hidden"], c["layers"], rows, c["step"], c["seed"], c["p"])
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def _grad_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        rows = int(rng.choice([1, 7, 16, 17, 100, 255, 256, 257, 1000, 2049, 4096, 4097, 9000, 20_000, 40_001]))
+        out.append(dict(hidden=int(rng.choice([64, 128])), layers=int(rng.integers(2, 4)), rows=rows,
+                        p=float(rng.choice([0.05, 0.1, 0.3, 0.5])), step=int(rng.choice([0, 1, 999, 21_999, 10 ** 6])),
+                        seed=int(rng.integers(0, 2 ** 62))))
+    return out
+
+
+@pytest.mark.parametrize("case", _grad_cases(16 * _SCALE, 808 + _SHIFT),
+                         ids=lambda c: f"h{c['hidden']}x{c['layers']}-r{c['rows']}-p{c['p']}-s{c['step']}")
+def test_masked_gradients_match_autograd(ctx, case):
+    """Round 5: loss and gradient of whichever trainer kernel the library picks for the shape (omc_mlp_train_variant)
+    against PyTorch autograd through relu(z) * mask / keep with the oracle's masks of that kernel, at the dropout-free
+    tolerance 2e-5 (tests/test_gpu_dropout.py, here over random shapes / row counts / rates / optimizer steps / seeds)."""
+    import torch
+
+    import test_gpu_dropout as td
+    from options_model_amd import nn_regressor as nnr
+    c = case
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    net = nnr.make_net(7, c["hidden"], c["layers"], c["p"]).to(dev)
+    # (rows with a pre-activation within 1e-5 of its ReLU kink are replaced first: see rows_clear_of_relu_boundaries)
+    data, variant = td.rows_clear_of_relu_boundaries(torch, ctx, net, td._data(torch, dev, c["rows"], 11), c["hidden"],
+                                                     c["layers"], c["p"], c["step"], c["seed"])
+    assert variant in (1, 2, 3, 4) and data.shape[0] == c["rows"]
+    td._check_one_step((torch, nnr, dev), ctx, c["hidden"], c["layers"], data.shape[0], c["p"], variant, first_step=c["step"],
+                       seed=c["seed"], data=data, net=net)
