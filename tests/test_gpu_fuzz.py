@@ -266,3 +266,133 @@ def test_masked_gradients_match_autograd(ctx, case):
     assert variant in (1, 2, 3, 4) and data.shape[0] == c["rows"]
     td._check_one_step((torch, nnr, dev), ctx, c["hidden"], c["layers"], data.shape[0], c["p"], variant, first_step=c["step"],
                        seed=c["seed"], data=data, net=net)
+
+
+def _pass2_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append(dict(hidden=int(rng.choice([64, 128])), layers=int(rng.integers(2, 4)),
+                        M=int(rng.choice([2, 64, 254, 1000, 1026, 3000])), N=int(rng.choice([2, 3, 5, 12, 30])),
+                        is_put=bool(rng.integers(0, 2)), model="heston" if rng.random() < 0.3 else "gbm",
+                        S0=float(rng.choice([90.0, 100.0, 110.0])), r=float(rng.choice([0.0, 0.03, 0.08])),
+                        sigma=float(rng.choice([0.2, 0.45])), T=float(rng.choice([0.25, 1.0])),
+                        p=float(rng.choice([0.0, 0.1, 0.5])), seed=int(rng.integers(1, 2 ** 31)),
+                        mask_seed=int(rng.integers(0, 2 ** 62)), net_seed=int(rng.integers(0, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("case", _pass2_cases(12 * _SCALE, 9090 + _SHIFT),
+                         ids=lambda c: f"{c['model']}-h{c['hidden']}x{c['layers']}-{c['M']}x{c['N']}-p{c['p']}")
+def test_network_pass2_returns_the_oracles_decisions(ctx, case):
+    """Round 5: mlp_apply_kernel (pass 2 of the NN flow, dropout on or off) with RANDOM networks on random path matrices
+    against the oracle's sticky sweep whose continuation values come from the float32 numpy forward pass under the same
+    masks: same allowance as on the reference's trained nets (<= 3 paths whose payoff sits within float32 rounding of the
+    network's output, <= 5 moved exercise dates)."""
+    import torch
+
+    from options_model_amd import nn_regressor as nnr
+    from oracle import reference_flow as rf
+    c = case
+    K = 100.0
+    if c["model"] == "gbm":
+        Sd = ctx.gbm_paths(c["M"], c["N"], c["S0"], c["r"], c["sigma"], c["T"], c["seed"], 0)
+    else:
+        Sd = ctx.heston_paths(c["M"], c["N"], c["S0"], c["r"], c["T"], 0.04, 2.0, 0.05, 0.4, -0.6, c["seed"], 0, scheme=0)
+    S32 = Sd.to_host()
+    Sd.free()
+    S = torch.from_numpy(S32).cuda().contiguous()
+    N, M = c["N"], c["M"]
+    rows = []
+    disc = np.exp(-c["r"] * c["T"] / N)
+    cfT = rf.payoff(S32[-1].astype(np.float64), K, c["is_put"])
+    for t in range(N - 1, 0, -1):
+        cfT = cfT * disc
+        itm = rf.payoff(S32[t].astype(np.float64), K, c["is_put"]) > 0
+        if itm.any():
+            rows.append((t, S32[t, itm].astype(np.float64), cfT[itm]))
+    if not rows:
+        pytest.skip("never in the money")
+    _, _, fm, fs, ym, ysd = rf.normalisers(rows, K, c["T"], c["T"] / N)
+    torch.manual_seed(c["net_seed"])
+    net = nnr.make_net(7, c["hidden"], c["layers"], c["p"]).cuda()
+    f64 = dict(dtype=torch.float64, device=S.device)
+    hip = nnr.pass2_fused(S, K, c["r"], c["T"], c["is_put"], net, torch.tensor(fm, **f64), torch.tensor(fs, **f64),
+                          torch.tensor(float(ym), **f64), torch.tensor(float(ysd), **f64), dropout_on=c["p"] > 0,
+                          want_state=True, seed=c["mask_seed"])
+    state = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    drop = dict(p=c["p"], seed=c["mask_seed"], hidden=c["hidden"], layers=c["layers"]) if c["p"] > 0 else None
+    regress, predict = rf.two_pass_frozen_mlp_regressor(K, c["T"], N, state, fm, fs, float(ym), float(ysd), dropout=drop)
+    cf, ex, _ = rf.lsm_two_pass(S32.astype(np.float64), K, c["r"], c["T"], c["is_put"], regress, predict)
+    sx = hip["sx"].astype(np.float64)
+    pay = np.maximum((K - sx) if c["is_put"] else (sx - K), 0)
+    cf_h = pay * np.exp(-c["r"] * (c["T"] / N) * (hip["tex"].astype(np.float64) - 1))
+    flips = int(((hip["tex"] < N) != ex).sum())
+    moved = int((np.abs(cf_h - cf) > 2e-5).sum())
+    assert flips <= 3 and moved <= 5, (flips, moved, M)
+    assert hip["price"] == pytest.approx(float(cf_h.mean()), rel=1e-9, abs=1e-300)
+    if not (flips or moved):
+        assert hip["price"] == pytest.approx(float(cf.mean()), rel=1e-6, abs=1e-12)
+
+
+def _rows_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append(dict(M=int(rng.choice([2, 4, 62, 64, 254, 256, 258, 1000, 1026, 4096, 4098, 20_000])),
+                        N=int(rng.choice([2, 3, 4, 5, 9, 17, 33, 64])), is_put=bool(rng.integers(0, 2)),
+                        model="heston" if rng.random() < 0.3 else "gbm", S0=float(rng.choice([80.0, 100.0, 125.0])),
+                        r=float(rng.choice([0.0, 0.03, 0.08])), sigma=float(rng.choice([0.1, 0.2, 0.45])),
+                        T=float(rng.choice([0.02, 0.25, 1.0, 2.5])), seed=int(rng.integers(1, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("case", _rows_cases(16 * _SCALE, 6060 + _SHIFT), ids=lambda c: f"{c['model']}-{c['M']}x{c['N']}")
+def test_rows_of_pass1_match_the_numpy_restatement(ctx, case):
+    """Round 5 (the fused row builder: count + statistics in one sweep, segmented scan, write): omc_nn_build_rows against
+    oracle.reference_flow on random matrices -- the row count exactly, the rows in the reference's order (t descending,
+    paths ascending), the normalisers (population std, zero std -> 1), the float32 normalised matrix."""
+    import torch
+
+    from options_model_amd import nn_regressor as nnr
+    from oracle import reference_flow as rf
+    c = case
+    K = 100.0
+    if c["model"] == "gbm":
+        Sd = ctx.gbm_paths(c["M"], c["N"], c["S0"], c["r"], c["sigma"], c["T"], c["seed"], 0)
+    else:
+        Sd = ctx.heston_paths(c["M"], c["N"], c["S0"], c["r"], c["T"], 0.04, 2.0, 0.05, 0.4, -0.6, c["seed"], 0, scheme=0)
+    S32 = Sd.to_host()
+    Sd.free()
+    N = c["N"]
+    rows = []
+    disc = np.exp(-c["r"] * c["T"] / N)
+    cfT = rf.payoff(S32[-1].astype(np.float64), K, c["is_put"])
+    for t in range(N - 1, 0, -1):
+        cfT = cfT * disc
+        itm = rf.payoff(S32[t].astype(np.float64), K, c["is_put"]) > 0
+        if itm.any():
+            rows.append((t, S32[t, itm].astype(np.float64), cfT[itm]))
+    S = torch.from_numpy(S32).cuda().contiguous()
+    built = nnr.build_rows_fused(S, K, c["r"], c["T"], c["is_put"])
+    if not rows:
+        assert built is None
+        return
+    X, Y, fm, fs, ym, ysd = rf.normalisers(rows, K, c["T"], c["T"] / N)
+    data, fm_d, fs_d, ym_d, ysd_d = built
+    assert data.shape == (X.shape[0], 8)
+    fm_d, fs_d = fm_d.cpu().numpy(), fs_d.cpu().numpy()
+    assert np.allclose(fm_d, fm, rtol=1e-9, atol=1e-13)
+    # a constant column: exactly 0 -> 1 on the device; numpy's std of a constant column may be rounding noise (see test_gpu_ols7.py)
+    const = fs <= 1e-12 * np.maximum(np.abs(fm), 1e-300)
+    assert np.all(fs_d[const] == 1.0) and np.allclose(fs_d[~const], fs[~const], rtol=1e-7, atol=0)
+    assert float(ym_d) == pytest.approx(float(ym), rel=1e-9, abs=1e-13)
+    ysd_ok = float(ysd) > 1e-12 * max(abs(float(ym)), 1e-300)
+    assert float(ysd_d) == (pytest.approx(float(ysd), rel=1e-7) if ysd_ok else 1.0)
+    fs_c = np.where(const, 1.0, fs)
+    want = np.concatenate([(X - fm) / fs_c, (Y - ym) / (float(ysd) if ysd_ok else 1.0)], axis=1)
+    got = data.cpu().numpy().astype(np.float64)
+    scale = np.maximum(np.abs(want), 1.0)
+    # float32 of a normalised value; a column with a tiny std amplifies the last bit of the float32 spot it came from
+    amp = np.concatenate([np.abs(fm) / fs_c, [abs(float(ym)) / (float(ysd) if ysd_ok else 1.0)]])
+    assert np.all(np.abs(got - want) <= scale * 2e-7 + 1e-9 * np.maximum(amp, 1.0)[None, :] + 2e-6), float(np.abs(got - want).max())
