@@ -98,7 +98,7 @@ tests)
   ;;
 soak)  # the seeded fuzz sweeps against the C oracle, 30 (or $4) times as many cases from seeds shifted by $3 (one process, no -x: count every failure)
   OMC_FUZZ_SCALE=${4:-30} OMC_FUZZ_SEED=${3:-1000} timeout -k 10 1100 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -p no:cacheprovider > gpurun_out/${TAG}_fuzz_soak.log 2>&1; rc=$?
-  grep -v "^\.*\( *\[ *[0-9]*%\]\)\?$" gpurun_out/${TAG}_fuzz_soak.log | tail -40; echo "pytest exit=$rc"
+  grep -v "^[.s]*\( *\[ *[0-9]*%\]\)\?$" gpurun_out/${TAG}_fuzz_soak.log | tail -40; echo "pytest exit=$rc"
   ;;
 *) echo "unknown step $WHAT"; exit 2;;
 esac
