@@ -1,8 +1,11 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Time of a pricing with regressor "ols7" (omc_price_american_ols7) and of its LSM part alone.  usage: time_ols7.py [M N ...]
+(default 10,000 x 50 and 1,000,000 x 252; 8,000,000 x 252 is one rank's shard of config 3: an 8 GB matrix, 9e8 rows)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from options_model_amd import price_american_option, _ffi
 ctx = _ffi.default_context(0)
-for M, N in ((10_000, 50), (1_000_000, 252)):
+a = [int(v) for v in sys.argv[1:]]
+for M, N in (list(zip(a[0::2], a[1::2])) or [(10_000, 50), (1_000_000, 252)]):
     price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, M, N, regressor="ols7", seed=1, ctx=ctx)
     t0 = time.perf_counter()
     for i in range(5):
