@@ -333,8 +333,10 @@ int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
  * (zero-variance columns get weight 0, as numpy's minimum-norm solution gives them); pass 2 applies it, strict >, sticky.
  * res->sum_nitm = rows of the regression; weights7 (host, may be NULL) = the fit, column 0 the constant; stats16 (host,
  * may be NULL) = feat_mean[7], feat_std[7], y_mean, y_std as omc_nn_build_rows returns them.  On a context with a
- * communicator / hook the call is collective: the fit is over ALL ranks' rows (two all-reduces of 8 and 28 doubles merge the
- * ranks' co-moments, one of 8 the result sums) and `res` is the job's. */
+ * communicator / hook the call is collective: the fit is over ALL ranks' rows (two all-reduces of 9 and 28 doubles merge the
+ * ranks' co-moments, one of 8 the result sums) and `res` is the job's; a failure only one rank can see (no memory for its
+ * workspace, a HIP error in its sweep) travels as a flag in the first all-reduce and EVERY rank returns an error -- the
+ * rank's own, 3103 on its peers -- instead of leaving them inside a collective. */
 int omc_lsm_ols7(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r, double T,
                  int is_put, omc_result* res, double* weights7, double* stats16, float* sx_out, int32_t* tex_out);
 /* the same as one fused call (paths into the context's own matrix, then omc_lsm_ols7): the facade's regressor="ols7" */

@@ -2203,30 +2203,56 @@ int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
     if (!res) return fail(-7, "null result pointer.");
+    // On a context with a communicator / hook the call is COLLECTIVE (two small all-reduces for the fit, one for the result).
+    // A failure only this rank can see -- no memory for its workspace, a HIP error in its sweep -- travels as a flag in the
+    // first all-reduce, and every rank returns an error together (the rank's own code there, 3103 on its peers), instead
+    // of leaving the peers inside a collective (as omc_nn_build_rows does).
+    const bool dist = c->distributed();
+    int lerr = 0;
+    std::string ltext;
+    auto local_failure = [&](int code) {
+        lerr = code;
+        ltext = g_err;
+    };
     omc::LsmWorkspace w;
-    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w))) return rc;
-    if ((rc = c->scratch.ensure(omc::ols7_scratch_bytes(n_paths, n_steps)))) return rc;
+    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w)) ||
+        (rc = c->scratch.ensure(omc::ols7_scratch_bytes(n_paths, n_steps)))) {
+        if (!dist) return rc;
+        local_failure(rc);
+    }
     omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
     // pass 1 (:482-516): one sweep -> (n, mean, co-moments) of the 6 non-constant features and the target
-    const double* stats_dev = nullptr;
-    double st[omc::kOls7Stats];
-    HIP_TRY(omc::ols7_comoments(c->stream, p, w.D, c->scratch.p, &stats_dev));
-    HIP_TRY(hipMemcpyAsync(st, stats_dev, sizeof st, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->distributed()) {
+    double st[omc::kOls7Stats] = {0.0};
+    if (!lerr) {
+        const double* stats_dev = nullptr;
+        hipError_t e = omc::ols7_comoments(c->stream, p, w.D, c->scratch.p, &stats_dev);
+        if (e == hipSuccess) e = hipMemcpyAsync(st, stats_dev, sizeof st, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            g_err = std::string("the co-moment sweep failed: ") + hipGetErrorString(e);
+            if (!dist) return (int)e;
+            local_failure((int)e);
+        }
+    }
+    if (dist) {
         // The fit is over ALL ranks' rows (paths shard by antithetic pair, the regression does not): the ranks' triples
         // (n_r, mean_r, C_r) are merged by Chan's formula for any number of ranks at once -- (1) sum of n_r mean_r and
         // n_r -> the global means; (2) sum of C_r + n_r (mean_r - mean)(mean_r - mean)^T -> the global co-moments -- the
-        // "regression moments" all-reduce of north_star, 8 + 28 doubles.  Every rank then solves the same 6 x 6 system.
-        if ((rc = c->seq_vote.ensure(sizeof(double) * 40))) return rc;
-        const double nr = st[0];
-        double v[8], mr[7];
+        // "regression moments" all-reduce of north_star, 9 + 28 doubles.  Every rank then solves the same 6 x 6 system.
+        if ((rc = c->seq_vote.ensure(sizeof(double) * 40))) return rc;  // (320 bytes: nothing left to do if this fails)
+        const double nr = lerr ? 0.0 : st[0];
+        double v[9], mr[7];
         for (int q = 0; q < 7; ++q) {
             mr[q] = st[1 + q];
             v[q] = nr * mr[q];
         }
         v[7] = nr;
-        if ((rc = allreduce_host(c, (double*)c->seq_vote.p, v, 8))) return rc;
+        v[8] = lerr ? 1.0 : 0.0;
+        if ((rc = allreduce_host(c, (double*)c->seq_vote.p, v, 9))) return rc;
+        if (v[8] > 0.0) {
+            if (lerr) return fail(lerr, ltext.c_str());
+            return fail(3103, "another rank of the job could not run its co-moment sweep.");
+        }
         const double ng = v[7];
         double cg[28];
         for (int i = 0, k = 0; i < 7; ++i)

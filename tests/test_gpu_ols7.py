@@ -156,3 +156,68 @@ def test_facade_regressor_ols7(ctx):
     assert 8.0 < h.price < 13.0
     with pytest.raises(ValueError, match="'poly', 'nn' or 'ols7'"):
         price_american_option(100.0, 100.0, 0.05, 0.2, 1.0, 1000, 10, regressor="spline")
+
+
+def test_collective_calls_fail_on_every_rank_together():
+    """On a context with a communicator / hook omc_lsm_ols7 and the full omc_nn_build_rows are collective.  A failure only
+    one rank can see travels as the ninth double of the first all-reduce: here the hook plays (a) a healthy peer with the
+    same data (doubling: the job's fit is this rank's fit, the job has twice the rows) and (b) a peer that reports a
+    failure -- this rank must come back with an error (3103 / 3102), not with a price, and only after it has taken part
+    in that all-reduce.  And (c) a LOCAL failure (a row buffer too small for this rank's rows) is reported with the
+    rank's own message after the all-reduce, not before it."""
+    import torch
+
+    from options_model_amd import _ffi
+    from options_model_amd.dist import _DevPtr
+    stream = torch.cuda.Stream()
+    c = _ffi.Context(0, stream=stream.cuda_stream)
+    try:
+        with torch.cuda.stream(stream):
+            S = c.gbm_paths(20_000, 20, 100.0, R, SIG, T, 3, 0)
+            alone = c.lsm_ols7(S, K, R, T, True)
+            calls = []
+
+            def doubling(dptr, count):
+                calls.append(count)
+                torch.as_tensor(_DevPtr(dptr, count), device="cuda").mul_(2.0)
+
+            c.set_allreduce_hook(doubling)
+            c.set_option("world_size", 2)
+            both = c.lsm_ols7(S, K, R, T, True)
+            assert calls == [9, 28, 8]
+            assert both["sum_nitm"] == 2 * alone["sum_nitm"] and both["price"] == pytest.approx(alone["price"], rel=1e-12)
+            assert np.allclose(both["weights"], alone["weights"], rtol=1e-9, atol=1e-12)
+            calls.clear()
+
+            def peer_failed(dptr, count):
+                calls.append(count)
+                t = torch.as_tensor(_DevPtr(dptr, count), device="cuda")
+                if count == 9:
+                    t[8] += 1.0  # the other rank's flag
+                else:
+                    t.mul_(2.0)
+
+            c.set_allreduce_hook(peer_failed)
+            with pytest.raises(_ffi.OmcError, match="another rank"):
+                c.lsm_ols7(S, K, R, T, True)
+            assert calls == [9]
+            calls.clear()
+            n = c.nn_build_rows(S.ptr, S.shape[1], 20_000, 20, K, R, T, True)  # the count alone is not collective
+            assert calls == [] and n == alone["sum_nitm"]
+            data = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+            with pytest.raises(_ffi.OmcError, match="another rank"):
+                c.nn_build_rows(S.ptr, S.shape[1], 20_000, 20, K, R, T, True, data.data_ptr(), n)
+            assert calls == [9]
+            calls.clear()
+            c.set_allreduce_hook(doubling)
+            with pytest.raises(ValueError, match="row buffer smaller"):
+                c.nn_build_rows(S.ptr, S.shape[1], 20_000, 20, K, R, T, True, data.data_ptr(), n - 1)
+            assert calls == [9]  # it entered the all-reduce before it reported
+            calls.clear()
+            got = c.nn_build_rows(S.ptr, S.shape[1], 20_000, 20, K, R, T, True, data.data_ptr(), n)
+            assert got[0] == n and calls == [9, 8]
+            c.set_allreduce_hook(None)
+            c.set_option("world_size", 1)
+            S.free()
+    finally:
+        c.close()
