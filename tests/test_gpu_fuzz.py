@@ -99,11 +99,12 @@ def test_fused_pricing_matches_oracle(ctx, case):
             and (res["n_exercised"], res["n_zero"], res["sum_nitm"]) == (ref["n_exercised"], ref["n_zero"], ref["sum_nitm"]))
     if not same:
         # Two soak runs (2 x 29,600 cases, profiles/r05_fuzz_soak.txt) found five such cases, all alike: Heston, r = 0, four
-        # or six paths, the variance clamped to 0 -- the spot stands still, the immediate payoff EQUALS the cash-flow the
+        # or six paths (or two in-the-money rows of 254 paths), the variance clamped to 0 -- the spot stands still, the immediate payoff EQUALS the cash-flow the
         # path gets later, a fit on three rows interpolates it: an exact tie, decided by the last bit of the fitted value
         # (and, through the sticky mask, moving the path's later decisions).  The device is deterministic there (60
         # repetitions, fresh contexts: one answer); it and the oracle just round differently.  Anything else is a failure.
-        assert c["M"] <= 64 and _smallest_margin(Sg, c["K"], c["r"], c["T"], c["is_put"], c["sem"]) <= 1e-10, (res, ref)
+        # (few in-the-money ROWS is what it takes, not few paths: a later soak found one with 254 paths, 2 rows)
+        assert _smallest_margin(Sg, c["K"], c["r"], c["T"], c["is_put"], c["sem"]) <= 1e-10, (res, ref)
 
 
 def _seq_cases(n, seed):
