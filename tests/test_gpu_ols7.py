@@ -53,8 +53,8 @@ def _compare(ctx, S_dev, S32, K_, r, T_, is_put, max_flips=2):
     # How well is the fit determined at all?  x, x^2, x^3 over a narrow range of spots are nearly collinear: the standardised
     # design matrix of a deep out-of-the-money option (a few hundred rows, all within a few percent of the strike) has
     # singular values down to 1e-13 of the largest -- numpy's SVD and the kernel's 6 x 6 normal equations (which square the
-    # condition number) then each return one of many near-solutions with weights of 1e6 and continuation values of 300 for
-    # payoffs of 7 (found by the fuzz soak, profiles/r05_fuzz_soak.txt).  Where cond > 1e6 only what is determined is
+    # condition number) then each return one of many near-solutions: in the case the fuzz soak found (profiles/r05_fuzz_soak.txt)
+    # lstsq gave continuation values of 320 for payoffs of 7, the kernel 13.  Where cond > 1e6 only what is determined is
     # compared: the row count, the normalisers, the price as the mean of the kernel's own decisions.
     X = np.vstack([rf.regression_features(S32[t][rf.payoff(S32[t].astype(np.float64), K_, is_put) > 0].astype(np.float64), K_, T_,
                                           t * T_ / N) for t in range(N - 1, 0, -1)])
