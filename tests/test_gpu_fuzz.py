@@ -397,3 +397,52 @@ def test_rows_of_pass1_match_the_numpy_restatement(ctx, case):
     # float32 of a normalised value; a column with a tiny std amplifies the last bit of the float32 spot it came from
     amp = np.concatenate([np.abs(fm) / fs_c, [abs(float(ym)) / (float(ysd) if ysd_ok else 1.0)]])
     assert np.all(np.abs(got - want) <= scale * 2e-7 + 1e-9 * np.maximum(amp, 1.0)[None, :] + 2e-6), float(np.abs(got - want).max())
+
+
+def _batch_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        model = "heston" if rng.random() < 0.3 else "gbm"
+        sizes = [64, 256, 1000, 2000, 4096, 10_000, 20_000] if rng.random() < 0.5 else [2, 4, 64, 254, 256, 1000, 1026, 2000, 4096, 10_000]
+        probs = []
+        for _ in range(int(rng.integers(1, 33))):
+            probs.append(dict(M=int(rng.choice(sizes)),
+                              N=int(rng.choice([1, 2, 3, 7, 10, 17, 33, 60, 130])), is_put=bool(rng.integers(0, 2)),
+                              S0=float(rng.uniform(70, 130)), sigma=float(rng.uniform(0.1, 0.5)), T=float(rng.uniform(0.003, 2.0)),
+                              r=float(rng.choice([0.0, 0.05])), seed=int(rng.integers(1, 2 ** 31)), stream=int(rng.integers(0, 4))))
+        out.append(dict(model=model, sem=str(rng.choice(["reference", "textbook", "two_pass"])), probs=probs))
+    return out
+
+
+@pytest.mark.parametrize("case", _batch_cases(10 * _SCALE, 3131 + _SHIFT), ids=lambda c: f"{c['model']}-{c['sem']}-n{len(c['probs'])}")
+def test_curve_batches_match_single_calls(ctx, case):
+    """SURVEY f-2: omc_price_american_batch / omc_price_european_batch (one set of launches for all points of a curve)
+    against the same pricings one by one, over random mixes of sizes (down to two paths, one step), flows and models:
+    bit for bit where the batch takes the 16-byte kernels, else counts equal and prices to 1e-12 (the scalar kernels' block
+    geometry)."""
+    from options_model_amd import _ffi
+    hp = dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7)
+    ps = []
+    for q in case["probs"]:
+        kw = dict(model=case["model"], semantics=case["sem"], is_put=q["is_put"], n_paths=q["M"], n_steps=q["N"], S0=q["S0"], K=100.0,
+                  r=q["r"], sigma=q["sigma"], T=q["T"], seed=q["seed"], stream=q["stream"])
+        if case["model"] == "heston":
+            kw.update(hp)
+        ps.append(_ffi.make_params(**kw))
+    # the batch takes the 16-byte kernels when EVERY member has whole groups of four antithetic pairs (M % 8 == 0), the
+    # scalar ones otherwise; a single call decides for itself (M % 4 == 0)
+    exact = all(q["M"] % 8 == 0 for q in case["probs"])
+    for one, many in ((ctx.price_american, ctx.price_american_batch), (ctx.price_european, ctx.price_european_batch)):
+        bat = many(ps)
+        assert len(bat) == len(ps)
+        for p, b, q in zip(ps, bat, case["probs"]):
+            a = one(p)
+            assert a["n_paths"] == b["n_paths"]
+            if exact:
+                assert all(a[k] == b[k] for k in ("price", "sum", "sumsq", "n_exercised", "n_zero", "sum_nitm"))
+            elif q["M"] >= 64:
+                assert (a["n_exercised"], a["n_zero"], a["sum_nitm"]) == (b["n_exercised"], b["n_zero"], b["sum_nitm"])
+                assert a["price"] == pytest.approx(b["price"], rel=1e-12, abs=1e-300)
+            # (a member of a handful of paths under the other block geometry: its 3-row fits interpolate, a decision can sit
+            # on an exact tie -- see test_fused_pricing_matches_oracle, which has the paths to tell; nothing to compare here)
