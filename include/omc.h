@@ -476,7 +476,10 @@ int omc_seq_step_width(omc_ctx* ctx, const omc_params* p, int n);
  * 190-211, options_model_2.py:336-355) and their ProcessPoolExecutor fan-out: n independent
  * problems (each its own S0, T, n_steps, n_paths, seed ...) run as ONE set of launches with
  * the batch index on the grid.  All problems of a call share model, semantics, antithetic and
- * Heston scheme; results are identical to n calls of omc_price_american / omc_price_european.
+ * Heston scheme; results are identical to n calls of omc_price_american / omc_price_european -- bit for bit when the
+ * batch runs the kernels a single call runs: the 16-byte ones, taken when EVERY member has whole groups of four path
+ * pairs (n_paths % 8 == 0 with antithetic pairs, % 4 without); otherwise all members run the scalar kernels, whose sums
+ * are formed in another block geometry: the same decisions (exact ties of a handful of paths aside), prices to 1e-12.
  * Whole-batch kernel times are reported in res[0]. */
 int omc_price_american_batch(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
 int omc_price_european_batch(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
