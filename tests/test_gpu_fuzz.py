@@ -446,3 +446,40 @@ def test_curve_batches_match_single_calls(ctx, case):
                 assert a["price"] == pytest.approx(b["price"], rel=1e-12, abs=1e-300)
             # (a member of a handful of paths under the other block geometry: its 3-row fits interpolate, a decision can sit
             # on an exact tie -- see test_fused_pricing_matches_oracle, which has the paths to tell; nothing to compare here)
+
+
+def _strike_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append(dict(M=int(rng.choice([2, 64, 1000, 1026, 20_000, 100_000, 100_002])), N=int(rng.choice([1, 2, 7, 33, 100])),
+                        S0=float(rng.uniform(50, 150)), r=float(rng.choice([0.0, 0.03, 0.08])), T=float(rng.uniform(0.02, 2.0)),
+                        v0=float(rng.choice([0.0, 0.01, 0.04, 0.25])), kappa=float(rng.uniform(0.1, 5.0)),
+                        theta=float(rng.choice([0.01, 0.04, 0.2])), xi=float(rng.choice([0.0, 0.1, 0.6, 1.5])),  # (1.5: far beyond Feller)
+                        rho=float(rng.choice([-0.99, -0.7, 0.0, 0.5, 0.99])), scheme=int(rng.integers(0, 3)), is_put=bool(rng.integers(0, 2)),
+                        nk=int(rng.integers(1, 61)), seed=int(rng.integers(1, 2 ** 31)), stream=int(rng.integers(0, 5))))
+    return out
+
+
+@pytest.mark.parametrize("case", _strike_cases(16 * _SCALE, 1717 + _SHIFT), ids=lambda c: f"s{c['scheme']}-{c['M']}x{c['N']}-k{c['nk']}")
+def test_calibrator_inner_monte_carlo_matches_the_oracle(ctx, case):
+    """SURVEY f-3 (heston_calibration.py:197-312): omc_heston_price_strikes -- one expiry, up to 60 strikes from ONE set of
+    terminal spots -- against the C oracle's terminal spots on the same Philox stream, over random Heston parameters (zero
+    and Feller-violating vol-of-vol, |rho| up to 0.99), all three schemes, ragged path counts."""
+    from oracle import reference_flow as rf
+    c = case
+    K = np.sort(np.random.default_rng(c["seed"]).uniform(0.5 * c["S0"], 1.5 * c["S0"], c["nk"]))
+    args = (c["S0"], c["r"], c["T"], c["v0"], c["kappa"], c["theta"], c["xi"], c["rho"])
+    M = c["M"] // 2 * 2
+    prices, errs = ctx.heston_price_strikes(M, c["N"], *args, K, is_put=c["is_put"], seed=c["seed"], stream=c["stream"], scheme=c["scheme"])
+    ST = orc.heston_terminal(M, c["N"], *args, seed=c["seed"], stream=c["stream"], scheme=c["scheme"])
+    ref = rf.strike_prices(ST, K, c["r"], c["T"], c["is_put"])
+    # float32 spots on both sides (5e-5 apart at most, the numerics contract): a strike within that of many spots moves its
+    # payoff mean by as much.  Far beyond the Feller condition (xi = 1.5: xi^2 = 2.25 against 2 kappa theta <= 2) the Euler
+    # recurrence ITSELF amplifies float32 rounding where the variance touches 0 (d sqrt(v) / dv is unbounded there): the soak
+    # found a case (v0 = 0, 1,000 paths) in which 44 paths of two correct float32 evaluations part ways by more than 1e-4,
+    # one by 7 % (tools/exp_heston_path_diff.py, profiles/r05_fuzz_soak.txt) -- there the prices are compared as two
+    # estimates of one expectation: a quarter of their standard error.
+    tol = 1e-4 * np.abs(ref) + 1e-4 * c["S0"] * 0.5 + (0.25 * errs if c["xi"] > 0.7 else 0.0)
+    assert np.all(np.abs(prices - ref) <= tol), float(np.abs(prices - ref).max())
+    assert np.all(np.isfinite(errs)) and np.all(errs >= 0)
