@@ -483,3 +483,41 @@ def test_calibrator_inner_monte_carlo_matches_the_oracle(ctx, case):
     tol = 1e-4 * np.abs(ref) + 1e-4 * c["S0"] * 0.5 + (0.25 * errs if c["xi"] > 0.7 else 0.0)
     assert np.all(np.abs(prices - ref) <= tol), float(np.abs(prices - ref).max())
     assert np.all(np.isfinite(errs)) and np.all(errs >= 0)
+
+
+def _localvol_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append(dict(L=int(rng.integers(1, 9)), M=int(rng.choice([2, 62, 64, 1000, 1026, 20_000])), N=int(rng.choice([1, 3, 7, 24, 60])),
+                        S0=float(rng.uniform(60, 140)), K=100.0, r=float(rng.choice([0.0, 0.03, 0.08])), T=float(rng.uniform(0.05, 2.0)),
+                        m_scale=float(rng.uniform(0.1, 1.0)), tau_scale=float(rng.uniform(0.2, 2.0)), eps=float(rng.choice([1e-4, 1e-2])),
+                        bias=float(rng.uniform(0.1, 0.5)), net_seed=int(rng.integers(0, 2 ** 31)), seed=int(rng.integers(1, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("case", _localvol_cases(8 * _SCALE, 2323 + _SHIFT), ids=lambda c: f"L{c['L']}-{c['M']}x{c['N']}")
+def test_local_vol_kernel_matches_the_torch_evaluation(ctx, case):
+    """SURVEY f-4 (options_model_3.py:263-333): the one-kernel local-vol simulator (the IV network 2 -> 64 -> 64 x L -> 1,
+    LayerNorm + GELU + residuals, evaluated inside the path loop on float32 MFMA) against the per-step PyTorch-ROCm
+    evaluation of the same RANDOM network on the same Philox normals: 1 ... 8 hidden layers, ragged path counts, random
+    scalers."""
+    import types
+
+    import torch
+
+    from options_model_amd import local_vol
+    c = case
+    torch.manual_seed(c["net_seed"])
+    net = local_vol.make_iv_network(64, c["L"], c["eps"])
+    with torch.no_grad():
+        net.output.bias.fill_(c["bias"])  # a volatility level of 10 ... 50 % around which the random net varies
+        net.output.weight.mul_(0.3)
+    net.scaler = types.SimpleNamespace(m_scale=c["m_scale"], tau_scale=c["tau_scale"])
+    model = local_vol.IVModel(net)
+    a = local_vol.simulate_local_vol_paths(c["S0"], c["r"], c["T"], c["M"], c["N"], model, c["K"], seed=c["seed"], backend="hip")
+    b = local_vol.simulate_local_vol_paths(c["S0"], c["r"], c["T"], c["M"], c["N"], model, c["K"], seed=c["seed"], backend="torch")
+    assert a.shape == b.shape == (c["N"] + 1, c["M"] // 2 * 2)
+    assert bool(torch.isfinite(a).all())
+    rel = float((a.double() / b.double() - 1).abs().max())
+    assert rel <= 5e-5, rel  # float32 paths, different summation orders (test_gpu_localvol.py: 2e-5 on the reference's net)
