@@ -1,8 +1,22 @@
-"""Seeded random sweep of the fused pricing entry point against the C oracle: shapes (ragged and
-aligned path counts, 1..70 steps), both option types, all three flows, both models, antithetic on
-and off, shard offsets.  Every case: same Philox stream on both sides -> paths within the
-numerics-contract tolerance, exercise state identical wherever the paths agree to the last bit,
-price within 1e-9 on the device's own paths."""
+"""Seeded random sweeps of the library's entry points against the oracles -- every kernel family has one:
+
+  1. the fused pricing entry point against the C oracle: shapes (ragged and aligned path counts, 1..70 steps), both option
+     types, all three flows, both models, antithetic on and off, shard offsets.  Same Philox stream on both sides -> paths
+     within the numerics-contract tolerance, exercise state and price (1e-9) on the device's own paths;
+  2. sequences of pricings sharing launches == the same pricings one by one, bit for bit;
+  3. batches of ContNet pricings (the v1 / v2 regressor) == single calls, bit for bit;
+  4. regressor "ols7" against the numpy restatement (lstsq on the materialised design matrix);
+  5. the dropout masks of all trainer kernels and of pass 2 == oracle/dropout.py, bit for bit;
+  6. loss and gradient of whichever trainer kernel the library picks against PyTorch autograd under those masks;
+  7. NN pass 2 with random networks, dropout on and off, against the oracle's sticky sweep;
+  8. the rows of NN pass 1 (count, order, normalisers, float32 matrix) against the numpy restatement;
+  9. curve batches (American and European) == single calls;
+ 10. the calibrator's inner Monte-Carlo (one expiry, many strikes) against the C oracle's terminal spots;
+ 11. the local-vol simulator with random IV networks against the per-step PyTorch evaluation.
+
+OMC_FUZZ_SCALE multiplies every sweep's case count and OMC_FUZZ_SEED shifts its seed: soak runs (profiles/r05_fuzz_soak.txt:
+what they found -- exact ties, ill-conditioned fits, units on their ReLU kink, an ill-conditioned recurrence -- and how
+the tests tell such an undecidable comparison from a failure)."""
 import os
 
 import numpy as np
