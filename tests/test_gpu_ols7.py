@@ -54,7 +54,7 @@ def _compare(ctx, S_dev, S32, K_, r, T_, is_put, max_flips=2):
     # design matrix of a deep out-of-the-money option (a few hundred rows, all within a few percent of the strike) has
     # singular values down to 1e-13 of the largest -- numpy's SVD and the kernel's 6 x 6 normal equations (which square the
     # condition number) then each return one of many near-solutions: in the case the fuzz soak found (profiles/r05_fuzz_soak.txt)
-    # lstsq gave continuation values of 320 for payoffs of 7, the kernel 13.  Where cond > 1e6 only what is determined is
+    # lstsq gave continuation values of 320 for payoffs of 7, the kernel 13.  Where cond > 1e4 only what is determined is
     # compared: the row count, the normalisers, the price as the mean of the kernel's own decisions.
     X = np.vstack([rf.regression_features(S32[t][rf.payoff(S32[t].astype(np.float64), K_, is_put) > 0].astype(np.float64), K_, T_,
                                           t * T_ / N) for t in range(N - 1, 0, -1)])
@@ -62,7 +62,9 @@ def _compare(ctx, S_dev, S32, K_, r, T_, is_put, max_flips=2):
     # drop it and the predictions on in-the-money spots do not depend on how; relative singular value ~1e-17)
     rel = np.linalg.svd(((X - m["fm"]) / m["fs"])[:, ~const], compute_uv=False)
     rel = rel / rel[0] if rel.size and rel[0] > 0 else np.zeros(1)
-    if m["R"] < 100 or ((rel > 1e-13) & (rel < 1e-6)).any():
+    # (the 6 x 6 normal equations carry eps * cond^2: a smallest relative singular value of 6e-5 / 4e-6 -- two cases of a
+    # 38,000-case soak -- leaves the predictions good to 1e-6 / 1e-5 only, which is neither wrong nor comparable at 1e-7)
+    if m["R"] < 100 or ((rel > 1e-13) & (rel < 1e-4)).any():
         return out, m
     # ... AT THE ROWS (a sample of them, every date represented): what the least-squares problem determines even when a
     # direction is null in this sample (a date with a single row: s and x s are then collinear) -- away from the rows two
