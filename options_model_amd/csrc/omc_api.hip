@@ -2274,18 +2274,54 @@ int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
     s16[14] = 0.0;
     for (int q = 0; q < 7; ++q) w7[q] = 0.0;
     if (n > 0.0) {
+        // The sweep's quantities are g = [u, u^2, u^3, max(u, 0), s, u s, y] with u = x - 1 (what the per-step polynomial uses):
+        // the same span as the reference's features f = [x, x^2, x^3, max(x - 1, 0), s, x s] plus the constant -- the same
+        // fit -- but a far better conditioned Gram matrix for in-the-money spots, which sit within a few tens of percent
+        // of the strike (the normal equations carry eps * cond^2).  f = B g + b with a unit lower-triangular B:
+        //   x = u + 1, x^2 = u^2 + 2 u + 1, x^3 = u^3 + 3 u^2 + 3 u + 1, x s = u s + s.
+        // The system is solved for g; means, stds and weights are then stated for f, the reference's features.
+        static const double B[6][6] = {{1, 0, 0, 0, 0, 0}, {2, 1, 0, 0, 0, 0}, {3, 3, 1, 0, 0, 0},
+                                       {0, 0, 0, 1, 0, 0}, {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 1, 1}};
+        static const double b0[6] = {1, 1, 1, 0, 0, 0};
+        auto Cg = [&](int i, int j) { return i <= j ? st[8 + i * 7 - i * (i - 1) / 2 + (j - i)] : st[8 + j * 7 - j * (j - 1) / 2 + (i - j)]; };
+        double sdg[7];
+        bool liveg[7];
         for (int q = 0; q < 7; ++q) {
-            const double mean = st[1 + q], v = std::sqrt(st[8 + q * 7 - q * (q - 1) / 2] / n);
-            live[q] = v > 1e-13 * std::fabs(mean);
-            sd[q] = live[q] ? v : 1.0;
+            const double mean = st[1 + q], v = std::sqrt(Cg(q, q) / n);
+            // (u is centred near 0: its own size is no yardstick for "constant" -- the spot's is, x = u + 1)
+            const double scale = q < 3 ? 1.0 : std::fabs(mean);
+            liveg[q] = v > 1e-13 * scale;
+            sdg[q] = liveg[q] ? v : 1.0;
         }
-        for (int q = 0; q < 6; ++q) {
-            s16[1 + q] = st[1 + q];
-            s16[8 + q] = sd[q];
+        double wg[7];
+        for (int q = 0; q < 7; ++q) wg[q] = 0.0;
+        if (liveg[6]) ols7_solve(st, n, sdg, liveg, wg);  // (a constant target: every weight 0, continuation = its mean)
+        // the reference's features: means, population stds (zero -> 1, :562), and the weights c = B^-T a, a = wg / sdg
+        double a[6], cf[6];
+        for (int q = 0; q < 6; ++q) a[q] = wg[1 + q] / sdg[q];
+        cf[5] = a[5];
+        cf[4] = a[4] - cf[5];
+        cf[3] = a[3];
+        cf[2] = a[2];
+        cf[1] = a[1] - 3.0 * cf[2];
+        cf[0] = a[0] - 2.0 * cf[1] - 3.0 * cf[2];
+        for (int i = 0; i < 6; ++i) {
+            double mean = b0[i], var = 0.0;
+            for (int j = 0; j < 6; ++j) {
+                mean += B[i][j] * st[1 + j];
+                for (int k = 0; k < 6; ++k) var += B[i][j] * B[i][k] * Cg(j, k);
+            }
+            const double v = std::sqrt(std::fmax(var, 0.0) / n);
+            live[i] = v > 1e-13 * std::fabs(mean);
+            sd[i] = live[i] ? v : 1.0;
+            s16[1 + i] = mean;
+            s16[8 + i] = sd[i];
+            w7[1 + i] = live[i] ? cf[i] * sd[i] : 0.0;  // (a constant column contributes (f - mean) = 0 whatever its weight)
         }
+        live[6] = liveg[6];
+        sd[6] = sdg[6];
         s16[14] = st[7];
         s16[15] = sd[6];
-        if (live[6]) ols7_solve(st, n, sd, live, w7);  // (a constant target: every weight 0, continuation = its mean)
     }
     // pass 2 (:615-651) with the fit, then the mean of the cash-flows valued at t = dt (:651)
     HIP_TRY(omc::ols7_pass2(c->stream, p, s16, s16 + 7, w7, s16[14], s16[15], w.sx, w.tex));

@@ -215,7 +215,7 @@ hipError_t localvol_paths(hipStream_t st, float* S, int64_t ld, int64_t M, int N
                           const float* Z, double S0, double r, double T, double K, double m_scale,
                           double tau_scale, double eps_out);
 // regressor "ols7" (omc_ols7.hip): ONE least-squares fit on the reference's seven features in the two-pass flow
-constexpr int kOls7Stats = 36;  // n, mean[7], C[28] (upper triangle, row-major) of [x, x^2, x^3, max(x-1,0), s, x*s, y]
+constexpr int kOls7Stats = 36;  // n, mean[7], C[28] (upper triangle, row-major) of [u, u^2, u^3, max(u,0), s, u*s, y], u = x - 1
 size_t ols7_scratch_bytes(int64_t M, int N);
 hipError_t ols7_comoments(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const double** stats_dev);
 hipError_t ols7_pass2(hipStream_t st, const LsmProblem& p, const double* feat_mean, const double* feat_std,

@@ -6,7 +6,8 @@
 // create_regression_features, and what oracle/reference_flow.py two_pass_ols7_regressor restates.
 //
 // Pass 1 never materialises the R x 7 design matrix (R ~ 0.46 N M rows): ONE sweep over the path matrix forms, per
-// thread, the sums of d_i and d_i d_j around the thread's first row (d = f - c: a constant column has d = 0 exactly),
+// lane, the sums of d_i and d_i d_j around the first row it sees (d = g - c: a constant column has d = 0 exactly) of
+// g = [u, u^2, u^3, max(u, 0), s, u s, y], u = x - 1 (the reference's features in a better conditioned basis),
 // turns them into (n, mean[7], C[28] = sum (f_i - mean_i)(f_j - mean_j)) and merges those pairwise by Chan's formula
 // in a fixed tree (bitwise reproducible, float64).  The host builds the normal equations of the STANDARDISED columns
 // from C -- the correlation matrix: the same fit as lstsq on (X - mean) / std, zero-variance columns (the constant,
@@ -25,7 +26,7 @@ constexpr int kCoIter = 4;     // such chunks per workgroup: one block merge (7 
 constexpr int kCoFold = 512;   // partials folded by one workgroup of the first merge stage
 constexpr int kCoGroup = 8;    // steps whose in-the-money rows a wave packs before it works on them
 static_assert(kCoChunk * kCoIter <= kCoBlock, "one thread per step fills the workgroup's per-step tables");
-constexpr int kCoQ = 7;        // x, x^2, x^3, max(x-1,0), s, x*s, y
+constexpr int kCoQ = 7;        // u, u^2, u^3, max(u,0), s, u*s, y with u = x - 1
 constexpr int kCoC = 28;       // upper triangle of the 7 x 7 co-moment matrix
 constexpr int kCo = 40;        // doubles per stored triple: n, mean[7], C[28], pad
 
@@ -100,17 +101,18 @@ struct CoArgs {
     const double* D;  // D[k] = exp(-r dt k)
 };
 
-// the seven quantities of one in-the-money (t, path): options_model_3.py:105-121 (columns 1..6; column 0 is the
-// constant) and the pass-1 target :491-516 (terminal payoff discounted to t)
+// the seven quantities of one in-the-money (t, path): the reference's features (options_model_3.py:105-121, columns 1..6;
+// column 0 is the constant) re-expressed in u = x - 1 -- the same span, a better conditioned Gram matrix; the host states
+// means, stds and weights for the reference's own features -- and the pass-1 target :491-516 (terminal payoff discounted to t)
 __device__ __forceinline__ void co_values(double sd, double payN, double inv_K, double st, double disc, double (&f)[kCoQ])
 {
-    const double x = sd * inv_K;
-    f[0] = x;
-    f[1] = x * x;
-    f[2] = x * x * x;
-    f[3] = fmax(x - 1.0, 0.0);
+    const double u = sd * inv_K - 1.0;  // x - 1: the powers of a number near 0 instead of a number near 1 (see omc_lsm_ols7)
+    f[0] = u;
+    f[1] = u * u;
+    f[2] = u * u * u;
+    f[3] = fmax(u, 0.0);
     f[4] = st;
-    f[5] = x * st;
+    f[5] = u * st;
     f[6] = payN * disc;
 }
 
@@ -301,7 +303,7 @@ size_t ols7_scratch_bytes(int64_t M, int N)
 }
 
 // -> *stats_dev: kOls7Stats doubles on the device: n, mean[7], C[28] (upper triangle, row-major) of
-// [x, x^2, x^3, max(x-1,0), s, x*s, y] over the in-the-money (step, path) pairs
+// [u, u^2, u^3, max(u,0), s, u*s, y], u = x - 1, over the in-the-money (step, path) pairs
 hipError_t ols7_comoments(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const double** stats_dev)
 {
     CoArgs a;

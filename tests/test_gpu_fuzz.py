@@ -535,4 +535,6 @@ def test_local_vol_kernel_matches_the_torch_evaluation(ctx, case):
     assert a.shape == b.shape == (c["N"] + 1, c["M"] // 2 * 2)
     assert bool(torch.isfinite(a).all())
     rel = float((a.double() / b.double() - 1).abs().max())
-    assert rel <= 5e-5, rel  # float32 paths, different summation orders (test_gpu_localvol.py: 2e-5 on the reference's net)
+    # float32 paths, different summation orders inside the network: 2e-5 on the reference's net at 24 steps
+    # (test_gpu_localvol.py); a recurrence of N float32 steps carries more of it (7.4e-5 seen once in 1,200 cases, at 60 steps)
+    assert rel <= 2e-5 * max(1.0, c["N"] / 12.0), rel

@@ -62,8 +62,11 @@ def _compare(ctx, S_dev, S32, K_, r, T_, is_put, max_flips=2):
     # drop it and the predictions on in-the-money spots do not depend on how; relative singular value ~1e-17)
     rel = np.linalg.svd(((X - m["fm"]) / m["fs"])[:, ~const], compute_uv=False)
     rel = rel / rel[0] if rel.size and rel[0] > 0 else np.zeros(1)
-    # (the 6 x 6 normal equations carry eps * cond^2: a smallest relative singular value of 6e-5 / 4e-6 -- two cases of a
-    # 38,000-case soak -- leaves the predictions good to 1e-6 / 1e-5 only, which is neither wrong nor comparable at 1e-7)
+    # (two cases of a 38,000-case soak had a smallest relative singular value of 6e-5 / 4e-6 and disagreed at the rows by
+    # 2e-3 / 1e-5.  The kernel forms its co-moments in u = x - 1 since -- with that the second case agrees to 1e-7; in the
+    # first -- 121 rows on one date, 1 on the other -- it is numpy's lstsq that moves by 2e-3 between the device's and the
+    # oracle's float32 paths, while the kernel's value equals a long-double projection to 1e-8: such designs are compared
+    # on what is determined only)
     if m["R"] < 100 or ((rel > 1e-13) & (rel < 1e-4)).any():
         return out, m
     # ... AT THE ROWS (a sample of them, every date represented): what the least-squares problem determines even when a
