@@ -329,7 +329,8 @@ int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
  * s, x*s] (create_regression_features, :105-121) in place of the network -- the reference validates `lsm_poly_degree`
  * and never uses it; this is the linear regressor its own features define, between the per-step 3-term
  * polynomial (omc_lsm_poly) and the network.  Pass 1 is one sweep over S (co-moments of the 6 non-constant features and
- * the target, float64, merged by Chan's formula in a fixed order); the fit is lstsq on the normalised design matrix
+ * the target -- accumulated for u = x - 1, the same span in a better conditioned basis --, float64, merged by Chan's
+ * formula in a fixed order); the fit is lstsq on the normalised design matrix
  * (zero-variance columns get weight 0, as numpy's minimum-norm solution gives them); pass 2 applies it, strict >, sticky.
  * res->sum_nitm = rows of the regression; weights7 (host, may be NULL) = the fit, column 0 the constant; stats16 (host,
  * may be NULL) = feat_mean[7], feat_std[7], y_mean, y_std as omc_nn_build_rows returns them.  On a context with a
