@@ -535,6 +535,31 @@ def test_local_vol_kernel_matches_the_torch_evaluation(ctx, case):
     assert a.shape == b.shape == (c["N"] + 1, c["M"] // 2 * 2)
     assert bool(torch.isfinite(a).all())
     rel = float((a.double() / b.double() - 1).abs().max())
-    # float32 paths, different summation orders inside the network: 2e-5 on the reference's net at 24 steps
-    # (test_gpu_localvol.py); a recurrence of N float32 steps carries more of it (7.4e-5 seen once in 1,200 cases, at 60 steps)
-    assert rel <= 2e-5 * max(1.0, c["N"] / 12.0), rel
+    if rel <= 2e-5:  # the bound of test_gpu_localvol.py on the reference's net (24 steps)
+        return
+    # A recurrence of N float32 steps through a network carries more (7.4e-5 seen once in 1,200 cases, at 60 steps).  Who is
+    # off?  The same recurrence in FLOAT64 (same float32 normals, the network's weights cast up) is the yardstick: the
+    # kernel may be no further from it than three times what PyTorch's own float32 evaluation is.
+    import copy
+    import math
+    N, M = c["N"], c["M"] // 2 * 2
+    P = M // 2
+    Z = torch.empty((N, P), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    from options_model_amd import _ffi
+    _ffi._check(ctx.lib, ctx.lib.omc_gbm_normals_f32(ctx.handle, Z.data_ptr(), P, P, N, int(c["seed"]), 0, 0))
+    ctx.sync()
+    net64 = copy.deepcopy(net).double().cuda().eval()
+    dt = c["T"] / N
+    S = torch.full((M,), c["S0"], dtype=torch.float64, device="cuda")
+    for t in range(1, N + 1):
+        tau = max(c["T"] - (t - 1) * dt, 1e-6)
+        m = torch.log(c["K"] / S.clamp(min=1e-8))
+        X = torch.stack([m / c["m_scale"], torch.full_like(m, tau / c["tau_scale"])], dim=1)
+        with torch.no_grad():
+            sig = net64(X).squeeze(1).clamp_min(1e-6)
+        z = torch.cat([Z[t - 1], -Z[t - 1]]).double()
+        S = S * torch.exp((c["r"] - 0.5 * sig * sig) * dt + sig * math.sqrt(dt) * z)
+    err_hip = float((a[-1].double() / S - 1).abs().max())
+    err_torch = float((b[-1].double() / S - 1).abs().max())
+    assert err_hip <= max(2e-5, 3.0 * err_torch), (rel, err_hip, err_torch)
