@@ -192,7 +192,7 @@ def _ols7_cases(n, seed):
     out = []
     for _ in range(n):
         out.append(dict(model="heston" if rng.random() < 0.3 else "gbm",
-                        M=int(rng.choice([200, 254, 1000, 1026, 4096, 10_000, 20_002])), N=int(rng.choice([2, 3, 5, 8, 16, 33, 50])),
+                        M=int(rng.choice([200, 254, 1000, 1026, 4096, 10_000, 20_002])), N=int(rng.choice([1, 2, 3, 5, 8, 16, 33, 50])),
                         is_put=bool(rng.integers(0, 2)), S0=float(rng.choice([85.0, 100.0, 115.0])), K=100.0,
                         r=float(rng.choice([0.0, 0.03, 0.08])), sigma=float(rng.choice([0.1, 0.2, 0.45])),
                         T=float(rng.choice([0.1, 1.0, 2.5])), seed=int(rng.integers(1, 2 ** 31))))
