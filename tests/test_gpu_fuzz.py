@@ -355,7 +355,7 @@ def _rows_cases(n, seed):
     out = []
     for _ in range(n):
         out.append(dict(M=int(rng.choice([2, 4, 62, 64, 254, 256, 258, 1000, 1026, 4096, 4098, 20_000])),
-                        N=int(rng.choice([2, 3, 4, 5, 9, 17, 33, 64])), is_put=bool(rng.integers(0, 2)),
+                        N=int(rng.choice([1, 2, 3, 4, 5, 9, 17, 33, 64])), is_put=bool(rng.integers(0, 2)),
                         model="heston" if rng.random() < 0.3 else "gbm", S0=float(rng.choice([80.0, 100.0, 125.0])),
                         r=float(rng.choice([0.0, 0.03, 0.08])), sigma=float(rng.choice([0.1, 0.2, 0.45])),
                         T=float(rng.choice([0.02, 0.25, 1.0, 2.5])), seed=int(rng.integers(1, 2 ** 31))))
