@@ -209,3 +209,64 @@ def test_pass1_time_partition_changes_no_number():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_tchunk.py")], capture_output=True, text=True,
                          timeout=900, cwd=root)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_the_maximum_number_of_time_steps(ctx):
+    """n_steps = 4094, the most the library takes (4095 is refused): every flow once on a small path set against the
+    oracles -- the fused polynomial pricings, "ols7" (whose pass 2 keeps its per-step table for the first 1,024 steps
+    only: the rest takes the other branch), the rows of NN pass 1."""
+    import torch
+
+    from options_model_amd import _ffi
+    from options_model_amd import nn_regressor as nnr
+    from oracle import cpu as orc
+    from oracle import reference_flow as rf
+    from test_gpu_ols7 import _compare
+    with pytest.raises(ValueError, match="exceeds the supported maximum"):
+        ctx.price_american(_ffi.make_params(n_paths=64, n_steps=4095, seed=1))
+    M, N, K, r, T = 512, 4094, 100.0, 0.05, 2.0
+    for sem in ("two_pass", "reference", "textbook"):
+        keep = ctx.empty((N + 1, M), np.float32)
+        res = ctx.price_american(_ffi.make_params(semantics=sem, n_paths=M, n_steps=N, S0=100.0, K=K, r=r, sigma=0.3, T=T, seed=9), keep)
+        Sg = keep.to_host()
+        keep.free()
+        So = orc.gbm_paths(M, N, 100.0, r, 0.3, T, 9, 0, 0, 1)
+        assert np.abs(Sg / So - 1).max() <= 2e-4  # 4,094 float32 steps: the contract's 2e-5 is for 252
+        ref = orc.lsm_poly(Sg, K, r, T, True, sem)
+        assert res["price"] == pytest.approx(ref["price"], rel=1e-9)
+        assert (res["n_exercised"], res["n_zero"], res["sum_nitm"]) == (ref["n_exercised"], ref["n_zero"], ref["sum_nitm"])
+    S = ctx.gbm_paths(M, N, 100.0, r, 0.3, T, 9, 0)
+    S32 = S.to_host()
+    _compare(ctx, S, S32, K, r, T, True)
+    S.free()
+    St = torch.from_numpy(S32).cuda().contiguous()
+    data, fm, fs, ym, ysd = nnr.build_rows_fused(St, K, r, T, True)
+    itm = rf.payoff(S32[1:N].astype(np.float64), K, True) > 0
+    assert data.shape[0] == int(itm.sum())
+    # the rows of the LAST decision date come first (t descending), paths ascending: their first feature is x = S / K
+    x_first = S32[N - 1][itm[N - 2]].astype(np.float64) / K
+    got = data[: x_first.size, 1].double().cpu().numpy() * float(fs[1]) + float(fm[1])
+    assert np.allclose(got, x_first, rtol=0, atol=5e-7)
+    # NN pass 2 over all 4,093 decision dates, dropout on (the time step is part of the mask's Philox counter)
+    torch.manual_seed(5)
+    net = nnr.make_net(7, 64, 2, 0.1).cuda()
+    rows = []
+    disc = np.exp(-r * T / N)
+    cfT = rf.payoff(S32[-1].astype(np.float64), K, True)
+    for t in range(N - 1, 0, -1):
+        cfT = cfT * disc
+        sel = rf.payoff(S32[t].astype(np.float64), K, True) > 0
+        if sel.any():
+            rows.append((t, S32[t, sel].astype(np.float64), cfT[sel]))
+    _, _, fm_o, fs_o, ym_o, ysd_o = rf.normalisers(rows, K, T, T / N)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    hip = nnr.pass2_fused(St, K, r, T, True, net, torch.tensor(fm_o, **f64), torch.tensor(fs_o, **f64), torch.tensor(float(ym_o), **f64),
+                          torch.tensor(float(ysd_o), **f64), dropout_on=True, want_state=True, seed=77)
+    state = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    regress, predict = rf.two_pass_frozen_mlp_regressor(K, T, N, state, fm_o, fs_o, float(ym_o), float(ysd_o),
+                                                        dropout=dict(p=0.1, seed=77, hidden=64, layers=2))
+    cf, ex, _ = rf.lsm_two_pass(S32.astype(np.float64), K, r, T, True, regress, predict)
+    assert int(((hip["tex"] < N) != ex).sum()) <= 3
+    sx = hip["sx"].astype(np.float64)
+    cf_h = np.maximum(K - sx, 0) * np.exp(-r * (T / N) * (hip["tex"].astype(np.float64) - 1))
+    assert int((np.abs(cf_h - cf) > 2e-5).sum()) <= 5
