@@ -20,6 +20,9 @@ import math
 from . import _ffi
 
 
+_warned = set()
+
+
 def _torch():
     import torch
     if not torch.cuda.is_available():
@@ -152,6 +155,13 @@ def simulate_local_vol_paths(S0, r, T, num_simulations, num_time_steps, iv_model
                 params.data_ptr(), iv_model.m_scale, iv_model.tau_scale, float(iv_model.model.epsilon),
                 Z.contiguous().data_ptr()))
             return S
+        if backend == "auto" and "localvol" not in _warned:
+            _warned.add("localvol")
+            import warnings
+            warnings.warn("options_model_amd: this implied-vol network is not the shape localvol_paths_kernel covers "
+                          "(ImprovedIVNetwork with hidden_dim 64, LayerNorm eps 1e-5, exact GELU): simulating through "
+                          "PyTorch-ROCm, one batched network evaluation per time step (several times slower)",
+                          RuntimeWarning, stacklevel=2)
         S[0] = S0
         sq = math.sqrt(dt)
         for t in range(1, N + 1):

@@ -36,6 +36,16 @@ from . import _ffi
 from .api import heston_defaults
 
 _ctx_cache = {}
+_warned = set()
+
+
+def _warn_once(key: str, msg: str):
+    """A shape the hand-written kernels do not cover runs through PyTorch-ROCm: correct, and several times slower.
+    Say so once per process and kind (the result's info["trainer"] / ["pass2"] says it every time)."""
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def _torch():
@@ -413,6 +423,10 @@ def train_on_matrix(net, data, epochs, lr, nn_batch=None, verbose=False, use_gra
         raise ValueError("trainer='hip' covers SingleLSMNet(7, 64 | 128, 2 | 3)")
     if trainer != "torch" and fused_trainer_supports(net, bs):
         return _train_fused(net, data, epochs, lr, bs, verbose)
+    if trainer == "auto":
+        _warn_once("trainer", f"options_model_amd: SingleLSMNet shape {_linear_shape(net)} (hidden units, hidden layers) is not "
+                              "covered by the HIP trainer kernels (64 | 128 units x 2 | 3 layers): training through PyTorch-ROCm "
+                              "autograd instead (same arithmetic, several times slower); info['trainer'] == 'torch'")
     # state snapshots for the warm-up steps of the graph capture must not leak into training
     init_state = copy.deepcopy(net.state_dict())
     lr_t = torch.tensor(float(lr), dtype=torch.float32, device=dev)
@@ -560,6 +574,10 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
     if trainer != "torch" and fused_apply_supports(net):
         res = pass2_fused(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
     else:
+        if trainer != "torch":
+            _warn_once("pass2", f"options_model_amd: SingleLSMNet shape {_linear_shape(net)} is not covered by the HIP pass-2 "
+                                "kernel (64 | 128 units x 2 | 3 layers): the backward sweep evaluates the network through "
+                                "PyTorch-ROCm; info['pass2'] == 'torch'")
         cf, ex = pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
         price = float(cf.mean())
         var = float(((cf - price) ** 2).mean())

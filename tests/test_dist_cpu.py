@@ -377,3 +377,127 @@ def test_rank_table_over_gloo_world_size_2(tmp_path):
     t0, t1 = np.load(tmp_path / "table0.npy"), np.load(tmp_path / "table1.npy")
     assert np.array_equal(t0, t1) and np.array_equal(t0, [[0, 0, 0.5], [1, 1, 1.5]])  # every rank holds the whole table
     assert (tmp_path / "pci0.txt").read_text() == (tmp_path / "pci1.txt").read_text() == "0000:c1:00.0,0000:c2:00.0"
+
+
+# ---- bench.py's `config3` block at the sizes no one-GPU rehearsal reaches: 8 ranks x 8M paths ---
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_c3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+class _FakeFfi:
+    """Stands where options_model_amd._ffi stands in bench.config3_block: records what each context was asked to price."""
+
+    class OmcError(RuntimeError):
+        pass
+
+    def __init__(self, ms_per_path=1e-6, fail_at=None):
+        self.calls, self.ms_per_path, self.fail_at = [], ms_per_path, fail_at
+        outer = self
+
+        class Context:
+            def __init__(self, device):
+                self.device = device
+
+            def price_american_seq(self, plist):
+                import time as _t
+                if outer.fail_at is not None and plist[0]["n_paths"] >= outer.fail_at:
+                    raise outer.OmcError("out of memory (test)")
+                outer.calls.append(("plain", [(p["n_paths"], p["pair_offset"], p["stream"]) for p in plist]))
+                _t.sleep(1e-3 * outer.ms_per_path * plist[0]["n_paths"] * len(plist) / 1e3)
+                return [dict(price=7.0 + 1e-3 * p["stream"]) for p in plist]
+
+            def sync(self):
+                pass
+
+            def close(self):
+                pass
+
+        self.Context = Context
+
+    @staticmethod
+    def make_params(**kw):
+        return dict(kw)
+
+
+class _FakePricer:
+    def __init__(self, ffi, rank, world, others_ms=0.0, rank0_one=None):
+        self.ffi, self.rank, self.world, self.others_ms, self.rank0_one = ffi, rank, world, others_ms, rank0_one
+
+    def price_american_seq(self, n_global, streams, **kw):
+        n_local, off = omc_dist.shard(n_global, self.world, self.rank)
+        self.ffi.calls.append(("sharded", [(n_global, n_local, off, s) for s in streams]))
+        return [dict(price=7.0 + 1e-3 * s, n_paths=n_global, n_exercised=1, n_zero=2, sum_nitm=3) for s in streams]
+
+    def allreduce_max(self, x):
+        return x
+
+    def allreduce_sum(self, v):
+        v = list(v)
+        if len(v) == self.world:      # the shard-alone table: the other ranks' entries
+            return [x if i == self.rank else self.others_ms for i, x in enumerate(v)]
+        if self.rank != 0 and self.rank0_one is not None:  # rank 0's one-GPU figures reach everybody
+            return list(self.rank0_one)
+        return v
+
+
+def _args(**kw):
+    import argparse
+    d = dict(config3_paths=None, config3_steps=4, paths_per_gpu=None)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_config3_block_is_baseline_configs2_at_eight_ranks():
+    bench = _bench_module()
+    ffi = _FakeFfi(ms_per_path=0.0)
+    kw = dict(model="gbm", is_put=True, semantics="two_pass", n_steps=252, seed=42, heston_scheme="reference")
+    ctx = ffi.Context(5)
+    pr = _FakePricer(ffi, 5, 8, others_ms=4.0, rank0_one=[32.0, 12.003, 1.0])
+    b = bench.config3_block(_args(), ffi, ctx, pr, 5, 8, 5, 252, kw, lambda: None, "rccl-native (test)", "on")
+    assert (b["total_paths"], b["paths_per_gpu"], b["n_gpus"], b["n_steps"]) == (64_000_000, 8_000_000, 8, 252)
+    sharded = [c for c in ffi.calls if c[0] == "sharded"]
+    # warm-up then the timed pricings, the whole 64M-path problem, rank 5's shard at pair offset 5 x 4M
+    assert sharded[0][1] == [(64_000_000, 8_000_000, 20_000_000, s) for s in (4900, 4901, 4902)]
+    assert sharded[1][1] == [(64_000_000, 8_000_000, 20_000_000, s) for s in (5000, 5001, 5002, 5003)]
+    plain = [c for c in ffi.calls if c[0] == "plain"]
+    # ... the same shard, same streams, through a communicator-free context; and no one-GPU leg on a rank other than 0
+    assert plain[1][1] == [(8_000_000, 20_000_000, s) for s in (5000, 5001, 5002, 5003)] and len(plain) == 2
+    assert b["one_gpu"] == {"ms_per_step": 32.0, "rank": 0, "price": 12.003}
+    assert b["speedup_vs_one_gpu"] == pytest.approx(32.0 / b["ms_per_step"])
+    assert b["efficiency_vs_one_gpu"] == pytest.approx(b["speedup_vs_one_gpu"] / 8)
+    assert b["price"] == 12.003 and b["price_equals_one_gpu"] is True
+    assert len(b["shard_alone_ms"]) == 8 and b["shard_alone_ms_max"] >= 4.0
+    assert b["scaling_efficiency"] == pytest.approx(b["shard_alone_ms_mean"] / b["ms_per_step"])
+
+
+def test_config3_block_rank0_runs_the_whole_problem_and_survives_a_card_without_room():
+    bench = _bench_module()
+    kw = dict(model="gbm", is_put=True, semantics="two_pass", n_steps=252, seed=42, heston_scheme="reference")
+    ffi = _FakeFfi(ms_per_path=0.0)
+    b = bench.config3_block(_args(config3_steps=7), ffi, ffi.Context(0), _FakePricer(ffi, 0, 4), 0, 4, 0, 252, kw,
+                            lambda: None, "c", "on")
+    plain = [c for c in ffi.calls if c[0] == "plain"]
+    # rank 0: its shard alone (16M paths at offset 0), then ALL 64M paths on its card: 2 warm-ups, the LAST 5 streams timed,
+    # so that its last price is the sharded job's last price (stream 5006)
+    assert plain[1][1][0][:2] == (16_000_000, 0)
+    assert plain[2][1] == [(64_000_000, 0, 4900), (64_000_000, 0, 4901)]
+    assert plain[3][1] == [(64_000_000, 0, s) for s in (5002, 5003, 5004, 5005, 5006)]
+    assert b["one_gpu"]["price"] == b["price"] == 7.0 + 1e-3 * 5006 and b["price_equals_one_gpu"] is True
+    # a card without room for 65 GB: the one-GPU leg is skipped, the block and the job go on
+    ffi = _FakeFfi(ms_per_path=0.0, fail_at=64_000_000)
+    b = bench.config3_block(_args(), ffi, ffi.Context(0), _FakePricer(ffi, 0, 4), 0, 4, 0, 252, kw, lambda: None, "c", "on")
+    assert b["one_gpu"] is None and b["speedup_vs_one_gpu"] is None and b["scaling_efficiency"] > 0
+    # sizes: 64 x the headline's paths per GPU unless given; rounded down to whole groups of 4 pairs per rank
+    b = bench.config3_block(_args(paths_per_gpu=1000), ffi, ffi.Context(0), _FakePricer(ffi, 2, 3), 2, 3, 0, 50, kw,
+                            lambda: None, "c", "on")
+    assert b["total_paths"] == 64_000 // 24 * 24 and b["paths_per_gpu"] == b["total_paths"] // 3
+    # one rank (the N = 1 line of a scaling run): the whole problem through the line's own context
+    ffi = _FakeFfi(ms_per_path=0.0)
+    b = bench.config3_block(_args(), ffi, ffi.Context(0), None, 0, 1, 0, 252, kw, lambda: None, "none", "n/a")
+    assert b["total_paths"] == 64_000_000 and b["speedup_vs_one_gpu"] == 1.0 and b["n_gpus"] == 1
+    assert [c[1][0][0] for c in ffi.calls] == [64_000_000, 64_000_000]

@@ -277,6 +277,29 @@ def test_native_rccl_communicator_world_size_one(ctx):
         sp.close()
 
 
+def test_bench_single_gpu_line_carries_config3(ctx):
+    """The N = 1 line of a scaling run: the same headline as ever plus the `config3` block -- BASELINE configs[2]'s whole
+    problem (64 x the headline's paths per GPU) on this one card, the denominator of the strong-scaling curve the N > 1
+    lines continue (tests/test_gpu_multirank.py checks those through the stand-in)."""
+    import os
+    import sys
+    from options_model_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                     "--paths-per-gpu", "50000", "--n-steps", "40", "--no-variants", "--no-cpu-baseline", "--no-sustained",
+                     "--config3-steps", "2"], root)
+    c3 = d["config3"]
+    assert (c3["total_paths"], c3["n_gpus"], c3["paths_per_gpu"], c3["scaling"]) == (3_200_000, 1, 3_200_000, "strong")
+    ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=3_200_000, n_steps=40, seed=42, stream=5001))
+    assert c3["price"] == ref["price"] and c3["speedup_vs_one_gpu"] == 1.0
+    assert c3["value"] == pytest.approx(3_200_000 * 40 / (c3["ms_per_step"] * 1e-3))
+    assert d["config"]["paths_per_gpu"] == 50000 and d["scaling"] == "weak"  # the headline is untouched
+    d = _bench_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                     "--paths-per-gpu", "50000", "--n-steps", "40", "--no-variants", "--no-cpu-baseline", "--no-sustained",
+                     "--no-config3"], root)
+    assert "config3" not in d
+
+
 def test_bench_force_dist_uses_native_rccl():
     import os
     import sys

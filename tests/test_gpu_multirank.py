@@ -50,7 +50,8 @@ def test_ranks_sharing_one_gpu_equal_the_unsharded_pricing(ctx, standin, world, 
     from options_model_amd import _ffi
     out, _ = _bench(["--gpus", str(world), "--single-device", "--backend", "rccl", "--steps", "4", "--warmup", "2",
                      "--paths-per-gpu", str(M_PER_GPU), "--n-steps", str(N), "--semantics", sem, "--group", "4",
-                     "--min-warmup-seconds", "0.05", "--no-variants", "--no-cpu-baseline", "--no-sustained"], standin)
+                     "--min-warmup-seconds", "0.05", "--no-variants", "--no-cpu-baseline", "--no-sustained",
+                     "--config3-steps", "3"], standin)
     d = _line(out)
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["comm"].startswith("rccl-native")
     # the line says who ran where (gathered through the communicator): `world` distinct ranks, here all on this one card
@@ -74,6 +75,23 @@ def test_ranks_sharing_one_gpu_equal_the_unsharded_pricing(ctx, standin, world, 
         assert ps["price"] == pytest.approx(ref2["price"], rel=1e-12)
         assert ps["last_pricing"]["sum_nitm"] == ref2["sum_nitm"]
         assert ps["last_pricing"]["n_exercised"] == ref2["n_exercised"]
+        # the `config3` block: BASELINE configs[2]'s FIXED problem (64 x the headline's paths per GPU: 64M paths when the
+        # headline is config 2's 1M) sharded over this job's ranks = strong scaling, with every rank's communicator-free
+        # time for its own shard and rank 0's one-GPU time of the whole problem beside it
+        c3 = d["config3"]
+        total = 64 * M_PER_GPU
+        assert (c3["total_paths"], c3["paths_per_gpu"], c3["n_gpus"], c3["scaling"]) == (total, total // world, world, "strong")
+        assert c3["comm"].startswith("rccl-native") and c3["seq_overlap"] == "on" and c3["steps"] == 3
+        ref3 = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=total, n_steps=N, seed=42, stream=5002))
+        assert c3["price"] == pytest.approx(ref3["price"], rel=1e-12)
+        assert c3["one_gpu"]["price"] == ref3["price"] and c3["price_equals_one_gpu"] is True
+        assert c3["last_pricing"]["sum_nitm"] == ref3["sum_nitm"] and c3["last_pricing"]["n_paths"] == total
+        assert len(c3["shard_alone_ms"]) == world and all(t > 0 for t in c3["shard_alone_ms"])
+        assert c3["scaling_efficiency"] == pytest.approx(c3["shard_alone_ms_mean"] / c3["ms_per_step"])
+        assert c3["speedup_vs_one_gpu"] == pytest.approx(c3["one_gpu"]["ms_per_step"] / c3["ms_per_step"])
+        assert c3["value"] == pytest.approx(total * N / (c3["ms_per_step"] * 1e-3))
+    else:
+        assert "config3" not in d  # the block belongs to the headline flow
 
 
 def test_a_rank_whose_init_fails_ends_the_job_within_the_deadline(standin):

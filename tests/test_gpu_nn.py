@@ -255,6 +255,25 @@ def test_facade_nn_regressor_2x64(torch_cuda):
     assert 5.6 < res.price < 8.0 and res.n_paths == 40_000 and res.sum_nitm > 0
 
 
+def test_a_shape_outside_the_kernels_says_so_once(torch_cuda):
+    """`trainer="auto"` with a width the HIP kernels do not cover (96 units) trains and sweeps through PyTorch-ROCm: correct,
+    slower -- and no longer silent: one RuntimeWarning per process and kind, info["trainer"] / ["pass2"] every time."""
+    import warnings
+    from options_model_amd import nn_regressor as nnr
+    nnr._warned.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        outs = [nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 4000, 10, seed=3 + i, nn_hidden=96, nn_epochs=2)
+                for i in range(2)]
+    msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning) and "options_model_amd" in str(x.message)]
+    assert len(msgs) == 2 and sum("HIP trainer kernels" in m for m in msgs) == 1 and sum("pass-2" in m for m in msgs) == 1
+    assert all(o.info["trainer"] == "torch" and o.info["pass2"] == "torch" and 4.0 < o.price < 9.0 for o in outs)
+    with warnings.catch_warnings(record=True) as w:  # a covered shape stays quiet
+        warnings.simplefilter("always")
+        o = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 4000, 10, seed=3, nn_hidden=64, nn_epochs=2)
+    assert o.info["trainer"] == "hip" and not [x for x in w if "options_model_amd" in str(x.message)]
+
+
 def test_bench_c1nn_line_is_the_references_default_call(torch_cuda):
     """`python bench.py --config c1nn`: ONE JSON line for the reference's default call (3 x 128, minibatch 256, dropout on)
     with the contract's fields, the trainer's MFMA roofline and the reference's own time as the quoted CPU baseline."""

@@ -189,6 +189,30 @@ def test_lsm_poly_against_golden_flows(ctx, golden, tag, name, pc):
     assert out["n_zero"] == int((cf == 0).sum())
 
 
+def test_config1_known_answers_on_the_references_seed42_paths(ctx, golden):
+    """BASELINE.md section 2's anchors at configs[0]'s OWN size, on the device: the reference's seed-42 normals
+    (RNGManager(42) child generator, 50 x 5,000, checksummed against the capture), the paths built from them by
+    omc_gbm_paths_from_normals_f32, and the three polynomial flows through the HIP kernels: 6.480186144667078 (per-step
+    sticky flow, 13,046 in-the-money regression rows, 89.91 % exercised), 5.983503863373407 (textbook), 7.444611934789268
+    (two-pass; 225,057 pass-1 rows = the reference's own R).  2e-5: float32 paths against the float64 anchors."""
+    c1 = golden["scalars"]["c1_seed42_gbm_put"]
+    z_half = rf.RNGManager(42).get_child_rng().standard_normal((50, 5000))
+    assert z_half.sum() == c1["zhalf_sum"] and list(z_half.ravel()[:4]) == c1["zhalf_first4"]
+    S = ctx.gbm_paths_from_normals(z_half, 100.0, R, SIG, T)
+    Sh = S.to_host()
+    assert Sh.shape == (51, 10000) and Sh[-1].astype(np.float64).sum() == pytest.approx(c1["S_T_sum"], rel=1e-6)
+    got = {}
+    for sem, key in (("reference", "poly_ref_price"), ("textbook", "poly_textbook_price"), ("two_pass", "poly_twopass_price")):
+        out = got[sem] = ctx.lsm_poly(S, K, R, T, True, sem, want_state=True)
+        assert out["price"] == pytest.approx(c1[key], rel=2e-5), sem
+        o = orc.lsm_poly(Sh, K, R, T, True, sem)  # the C oracle on the very same float32 paths: same decisions
+        assert out["price"] == pytest.approx(o["price"], rel=1e-9) and out["sum_nitm"] == o["sum_nitm"]
+    S.free()
+    assert got["reference"]["sum_nitm"] == c1["poly_ref_sum_nitm"] == 13046
+    assert got["reference"]["n_exercised"] / 10000 == pytest.approx(c1["poly_ref_exercised_frac"], abs=2e-4)
+    assert got["two_pass"]["sum_nitm"] == c1["poly_twopass_sum_nitm_pass1"] == c1["R"] == 225057
+
+
 @pytest.mark.parametrize("sem", ["reference", "textbook", "two_pass"])
 @pytest.mark.parametrize("is_put", [True, False])
 @pytest.mark.parametrize("M,N", [(20000, 50), (1001, 7), (10, 4), (6, 1), (4096, 252)])
