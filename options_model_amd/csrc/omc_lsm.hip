@@ -340,7 +340,7 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
         const int t = (p.N - 1 + chunks - 1) / chunks;
         if (t <= 126 && t >= 32) tchunk = t;
     }
-    a.tchunk = (tch_env >= 2 && tch_env <= 126) ? tch_env : tchunk;
+    a.tchunk = (tch_env >= 2 && tch_env <= kPass1MaxChunk) ? tch_env : tchunk;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
     auto launch = [&](auto vec, auto tp) {

@@ -406,6 +406,8 @@ __device__ __forceinline__ float itm_threshold(double K, int is_put)
     return (double)Kf > K ? next_float(Kf, false) : Kf;
 }
 
+constexpr int kPass1MaxChunk = 256;  // time steps a pass-1 workgroup may take (its discount factors live in LDS)
+
 struct Pass1Args {
     const float* S;
     int64_t ld, M;
@@ -428,7 +430,7 @@ template <int VEC, int TPW, int PUT = -1>
 __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
 {
     __shared__ double wl[kBlock / 64][kWaveRedDoubles];
-    __shared__ double shD[kBlock / 64][128];
+    __shared__ double shD[kBlock / 64][kPass1MaxChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Tile groups are numbered XCD-aware: the workgroups that run on one XCD walk one contiguous eighth of every row
     // (measured: pass 1 202 -> 195 us at C2, 1.53 -> 1.47 ms at C3's shard; the same renumbering does nothing for the

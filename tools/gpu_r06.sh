@@ -1,0 +1,83 @@
+#!/bin/bash
+# Round-6 GPU steps, one per gpurun call:  bash tools/gpu_r06.sh WHAT [TAG]
+set -u
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+WHAT=${1:-new}
+TAG=${2:-r06}
+R="$GRAFT_REPO_ROOT"
+ok() { [ "$1" -ne 124 ] && [ "$1" -ne 137 ]; }
+prof() {  # prof NAME program args...: rocprofv3 kernel stats of a python program -> gpurun_out/${TAG}_NAME_kernel_stats.csv
+  local name=$1; shift
+  local OUT="$R/gpurun_out/prof_${TAG}_$name"
+  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 "$@" \
+      > "$R/gpurun_out/${TAG}_${name}_under_rocprof.json" 2> "$OUT.err" ); local rc=$?
+  echo "rocprof $name exit=$rc"; ok $rc || return 1
+  local f=$(find "$OUT" -name "*kernel_stats.csv" | head -1); cp "$f" "$R/gpurun_out/${TAG}_${name}_kernel_stats.csv"; head -8 "$f" | cut -c1-170
+  rm -rf "$OUT"
+}
+pmc() {  # pmc NAME "COUNTERS" program args...: one rocprofv3 --pmc pass (kernel trace only) -> gpurun_out/pmc_${TAG}_NAME/
+  local name=$1 ctrs=$2; shift 2
+  local OUT="$R/gpurun_out/pmc_${TAG}_$name"
+  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$OUT" -- python3 "$@" \
+      > /dev/null 2> "$OUT.err" ); local rc=$?
+  echo "pmc $name [$ctrs] exit=$rc"; ok $rc || return 1
+  [ $rc -eq 0 ] || tail -3 "$OUT.err"
+  return 0
+}
+case "$WHAT" in
+new)  # what round 6 added so far: the config-1 known answers, the config3 block (N = 1 and 2 / 4 ranks through the stand-in),
+      # the fallback warnings; then the driver's command (does the 64M-path block fit and how long does it take?)
+  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_nn.py::test_a_shape_outside_the_kernels_says_so_once \
+      tests/test_gpu_dist.py tests/test_gpu_multirank.py -x -q -m gpu --durations=8 > gpurun_out/${TAG}_new_tests.log 2>&1; rc=$?
+  tail -25 gpurun_out/${TAG}_new_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
+  timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_driver.json 2> gpurun_out/bench_${TAG}_driver.err; rc=$?
+  echo "bench (driver's command) exit=$rc"; tail -3 gpurun_out/bench_${TAG}_driver.err
+  python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/bench_r06_driver.json"))
+print("value", d["value"], "ms", d["ms_per_step"], "roofline", d["roofline"]["frac"])
+print("config3", json.dumps(d.get("config3"))[:1500])
+PY
+  ;;
+sq)  # SQ counters of the three c2 kernels on the current library, one pass per counter group
+  for PASS in "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+              "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_LDS" \
+              "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM"; do
+    N=$(echo $PASS | cut -d' ' -f1)
+    pmc "sqc2_$N" "$PASS" "$R/bench.py" --config c2 --steps 6 --warmup 2 --min-warmup-seconds 0.05 --only-timed || exit 1
+  done
+  python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_sqc2_" | tee "$R/gpurun_out/pmc_sq_summary_${TAG}_c2.txt"
+  for d in "$R"/gpurun_out/pmc_${TAG}_sqc2_*; do [ -d "$d" ] && rm -rf "$d"; done
+  ;;
+tch)  # pass 1's reads by time-chunk length: every (tile, chunk) re-reads the terminal row and its last prefetches are clamped
+      # duplicates -> exact request-size counters + timing at c3 and c2 for OMC_PASS1_TCHUNK = auto / 32 / 63 / 126 / 251
+  for CFG in c3 c2; do
+    for TCH in 0 32 63 126 251; do
+      export OMC_PASS1_TCHUNK=$TCH
+      timeout -k 10 300 python bench.py --config $CFG --steps 12 --warmup 4 --only-timed > gpurun_out/${TAG}_tch_${CFG}_${TCH}.json 2> gpurun_out/${TAG}_tch_${CFG}_${TCH}.err; rc=$?
+      ok $rc || exit 1
+      python3 -c "
+import json; d=json.load(open('gpurun_out/${TAG}_tch_${CFG}_${TCH}.json')); k={x['kernel']:x for x in d['roofline_kernels']}
+print('$CFG tchunk=$TCH ms_per_step', round(d['ms_per_step'],4), 'pass1 ms', round(k['lsm_pass1_kernel']['ms_per_launch'],4), 'frac', round(k['lsm_pass1_kernel']['frac'],4), 'gen', round(k['gbm_paths_kernel']['ms_per_launch'],4), 'pass2', round(k['lsm_pass2_kernel']['ms_per_launch'],4))" | tee -a gpurun_out/${TAG}_tchunk_sweep.txt
+    done
+  done
+  for TCH in 0 126 251; do
+    export OMC_PASS1_TCHUNK=$TCH
+    pmc "tch_c3_${TCH}_a" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
+    pmc "tch_c3_${TCH}_b" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
+    pmc "tch_c3_${TCH}_c" "TCC_HIT_sum TCC_MISS_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
+    pmc "tch_c3_${TCH}_d" "FETCH_SIZE" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
+  done
+  unset OMC_PASS1_TCHUNK
+  python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_tch_c3_" --by-dir | tee "$R/gpurun_out/${TAG}_pass1_reads_by_tchunk.txt"
+  for d in "$R"/gpurun_out/pmc_${TAG}_tch_c3_*; do [ -d "$d" ] && rm -rf "$d"; done
+  ;;
+tests)
+  timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
+  tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
+  timeout -k 10 300 python __graft_entry__.py --smoke > gpurun_out/${TAG}_smoke.log 2>&1; rc=$?
+  tail -4 gpurun_out/${TAG}_smoke.log; echo "smoke exit=$rc"
+  ;;
+*) echo "unknown step $WHAT"; exit 2;;
+esac
