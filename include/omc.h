@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OMC_ABI_VERSION 7
+#define OMC_ABI_VERSION 8
 
 typedef struct omc_ctx omc_ctx;
 
@@ -114,7 +114,11 @@ int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
  * 0 = one pricing after the other; -1 = default: off -- a job turns it on after it has checked, on its live
  * communicator, that both forms return the same bits, as bench.py does),
  * "seq_event_stride" (omc_price_american_seq: k > 0 = every k-th pricing of a sequence carries its own HIP
- * events, so a sequence yields several samples of the per-kernel times; 0 = default: the first pricing only) */
+ * events, so a sequence yields several samples of the per-kernel times; 0 = default: the first pricing only),
+ * "alloc_limit" (PER PROCESS, bytes; 0 = none: no single buffer of the library -- path matrix, workspace, row scratch --
+ * may grow beyond it; a larger request fails like a hipMalloc that found no room, code 2 = hipErrorOutOfMemory.  A
+ * budget for a card shared with other tenants; on a distributed context such a rank-local failure is reported on
+ * EVERY rank, see "failures only one rank can see" below) */
 int omc_set_option(omc_ctx* ctx, const char* key, int64_t value);
 /* ---- per-step flows across GPUs without a collective per step ------------------------------ */
 /* The per-step flows exchange 8 doubles per pricing after every time step.  Instead of an all-reduce per step, every
@@ -260,6 +264,16 @@ int omc_heston_price_strikes(omc_ctx* ctx, int64_t n_paths, int n_steps, double 
                              double T, double v0, double kappa, double theta, double xi, double rho,
                              uint64_t seed, uint64_t stream, int scheme, const double* strikes,
                              int n_strikes, int is_put, double* prices, double* stderrs);
+/* the same for a whole quote SURFACE -- what ONE evaluation of the calibrator's objective asks for
+ * (heston_calibration.py:283-312 loops `for T in unique_T`; :404-472 calls it once per optimizer iteration): n_expiries
+ * expiries (host, expiries[e] > 0) each simulated on its own Philox sub-stream streams[e] (host), n_quotes quotes with
+ * strike strikes[q] on expiry expiry_of[q] (host int32, 0 .. n_expiries-1).  One launch for all simulations (expiry on
+ * grid.y), one for all quotes, one table upload, one read-back, one wait.  Every quote has the bits of its own
+ * omc_heston_price_strikes(T = expiries[expiry_of[q]], stream = streams[expiry_of[q]], strike = strikes[q]) call. */
+int omc_heston_price_surface(omc_ctx* ctx, int64_t n_paths, int n_steps, double S0, double r, double v0, double kappa,
+                             double theta, double xi, double rho, uint64_t seed, int scheme, const double* expiries,
+                             const uint64_t* streams, int n_expiries, const double* strikes, const int32_t* expiry_of,
+                             int n_quotes, int is_put, double* prices, double* stderrs);
 
 /* ---- NN continuation-value regressor: fused training of the network ------------------------ */
 /* replaces the minibatch loop of price_american_enhanced_lsm (options_model_3.py:565-600:
@@ -336,8 +350,11 @@ int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths,
  * may be NULL) = feat_mean[7], feat_std[7], y_mean, y_std as omc_nn_build_rows returns them.  On a context with a
  * communicator / hook the call is collective: the fit is over ALL ranks' rows (two all-reduces of 9 and 28 doubles merge the
  * ranks' co-moments, one of 8 the result sums) and `res` is the job's; a failure only one rank can see (no memory for its
- * workspace, a HIP error in its sweep) travels as a flag in the first all-reduce and EVERY rank returns an error -- the
- * rank's own, 3103 on its peers -- instead of leaving them inside a collective. */
+ * path matrix -- omc_price_american_ols7's largest allocation -- or workspace, a HIP error in its sweep: the ninth double
+ * of the first all-reduce; a HIP error in its pass 2: slot 7 of the result sums, which the kernels leave at zero) travels
+ * as a flag and EVERY rank returns an error -- the rank's own, 3103 on its peers -- instead of leaving them inside a
+ * collective.  No allocation stands between a rank and a collective its peers have entered: the few hundred bytes the
+ * flags travel through exist from omc_comm_init / omc_set_allreduce_hook on. */
 int omc_lsm_ols7(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r, double T,
                  int is_put, omc_result* res, double* weights7, double* stats16, float* sx_out, int32_t* tex_out);
 /* the same as one fused call (paths into the context's own matrix, then omc_lsm_ols7): the facade's regressor="ols7" */

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
 MODELS = {"gbm": 0, "heston": 1}
@@ -95,6 +95,7 @@ SIGNATURES = {
     "omc_price_american": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result), _P, _I64]),
     "omc_price_european": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Result)]),
     "omc_heston_price_strikes": (C.c_int, [_P, _I64, _I] + [_D] * 8 + [_U64, _U64, _I, _P, _I, _I, _P, _P]),
+    "omc_heston_price_surface": (C.c_int, [_P, _I64, _I] + [_D] * 7 + [_U64, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P]),
     "omc_price_american_seq": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
     "omc_seq_step_width": (C.c_int, [_P, C.POINTER(Params), _I]),
     "omc_price_american_batch": (C.c_int, [_P, C.POINTER(Params), _I, C.POINTER(Result)]),
@@ -545,6 +546,25 @@ class Context:
         _check(self.lib, self.lib.omc_heston_price_strikes(
             self.handle, int(n_paths), int(n_steps), S0, r, T, v0, kappa, theta, xi, rho, int(seed),
             int(stream), int(scheme), k.ctypes.data, k.size, int(is_put), prices.ctypes.data,
+            errs.ctypes.data))
+        return prices, errs
+
+    def heston_price_surface(self, n_paths, n_steps, S0, r, v0, kappa, theta, xi, rho, expiries, streams, strikes,
+                             expiry_of, is_put=False, seed=42, scheme=2):
+        """Many expiries x many strikes in one launch set (one objective evaluation of the calibrator): quote q = strike
+        strikes[q] on expiry expiries[expiry_of[q]], simulated on Philox sub-stream streams[expiry_of[q]]
+        -> (prices, stderrs), each quote bit-equal to its own heston_price_strikes call."""
+        T = np.ascontiguousarray(expiries, np.float64)
+        st = np.ascontiguousarray(streams, np.uint64)
+        k = np.ascontiguousarray(strikes, np.float64)
+        eo = np.ascontiguousarray(expiry_of, np.int32)
+        if st.shape != T.shape or eo.shape != k.shape or T.ndim != 1 or k.ndim != 1:
+            raise ValueError("expiries / streams and strikes / expiry_of must be matching 1-d arrays")
+        prices = np.empty_like(k)
+        errs = np.empty_like(k)
+        _check(self.lib, self.lib.omc_heston_price_surface(
+            self.handle, int(n_paths), int(n_steps), S0, r, v0, kappa, theta, xi, rho, int(seed), int(scheme),
+            T.ctypes.data, st.ctypes.data, T.size, k.ctypes.data, eo.ctypes.data, k.size, int(is_put), prices.ctypes.data,
             errs.ctypes.data))
         return prices, errs
 

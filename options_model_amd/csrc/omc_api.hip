@@ -39,12 +39,22 @@ int fail(int code, const char* msg)
         }                                                                                  \
     } while (0)
 
+// Option "alloc_limit" (omc_set_option; per process, 0 = none): a single buffer of the library may not grow beyond this many
+// bytes -- a request above it fails like a hipMalloc that found no room (hipErrorOutOfMemory).  A memory budget for a
+// card shared with other tenants, and the way the tests make ONE rank of a job run out of memory.
+static size_t g_alloc_limit = 0;
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return 0;
+        if (g_alloc_limit && bytes > g_alloc_limit) {
+            g_err = "hipMalloc refused: " + std::to_string(bytes) + " bytes asked for, option alloc_limit is " +
+                    std::to_string(g_alloc_limit) + " (out of memory)";
+            return (int)hipErrorOutOfMemory;
+        }
         if (p) {
             hipError_t e = hipFree(p);
             p = nullptr;
@@ -76,6 +86,8 @@ struct DevBuf {
 };
 
 }  // namespace
+
+constexpr size_t kVoteBytes = 1024;  // omc_ctx::seq_vote once a communicator / hook is installed (largest use: 40 doubles)
 
 struct omc_ctx {
     int device = 0;
@@ -643,6 +655,7 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
 {
     if (!c || !key) return fail(-7, "null pointer.");
     if (!strcmp(key, "gbm_vec")) c->gbm_vec = (int)value;
+    else if (!strcmp(key, "alloc_limit")) g_alloc_limit = value > 0 ? (size_t)value : 0;
     else if (!strcmp(key, "heston_vec")) c->heston_vec = (int)value;
     else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
     else if (!strcmp(key, "step_graph")) c->step_graph = value < 0 ? -1 : (value ? 1 : 0);
@@ -663,6 +676,13 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
 int omc_set_allreduce_hook(omc_ctx* c, omc_allreduce_fn fn, void* user)
 {
     if (!c) return fail(-7, "null context.");
+    if (fn) {
+        // the few hundred bytes every collective vote / flag exchange goes through: allocated HERE, so that no allocation
+        // -- nothing that can fail on one rank alone -- stands between a rank and a collective its peers have entered
+        int rc;
+        if ((rc = bind(c))) return rc;
+        if ((rc = c->seq_vote.ensure(kVoteBytes))) return rc;
+    }
     c->hook = fn;
     c->hook_user = user;
     return 0;
@@ -687,6 +707,7 @@ int omc_comm_init(omc_ctx* c, int rank, int world, const void* uid, size_t bytes
     if (c->comm) return fail(-4, "this context already has a communicator.");
     std::string err;
     omc::Comm* comm = nullptr;
+    if ((rc = c->seq_vote.ensure(kVoteBytes))) return rc;  // (see omc_set_allreduce_hook; before the collective bring-up)
     rc = omc::comm_create(rank, world, uid, &comm, &err);
     if (rc) return fail(rc, err.c_str());
     c->comm = comm;
@@ -1501,7 +1522,7 @@ static int seq_multi_reserve(omc_ctx* c, const omc_params* p, int n, int* K_out)
         double vote[kVote] = {0};
         vote[K] = 1.0;
         vote[33] = err ? 1.0 : 0.0;
-        if ((rc = c->seq_vote.ensure(sizeof vote))) return rc;  // (a failure HERE leaves the peers waiting: 272 bytes)
+        if ((rc = c->seq_vote.ensure(sizeof vote))) return rc;  // (never allocates: the buffer exists since the communicator / hook was installed)
         if ((rc = allreduce_host(c, (double*)c->seq_vote.p, vote, kVote))) return rc;
         if (vote[33] > 0.0) {
             if (err) return fail(err, err_text.c_str());
@@ -1755,6 +1776,63 @@ int omc_heston_price_strikes(omc_ctx* c, int64_t n_paths, int n_steps, double S0
         const double var = h[2 * (size_t)k + 1] / M - mean * mean;
         prices[k] = df * mean;
         if (stderrs) stderrs[k] = df * std::sqrt((var > 0 ? var : 0.0) / M);
+    }
+    return 0;
+}
+
+// A whole quote surface in one launch set: what one evaluation of the calibrator's objective asks for
+// (heston_calibration.py:283-312, 404-472: ~60 quotes over a handful of expiries, per optimizer iteration).  Every
+// expiry is simulated on its own Philox sub-stream (streams[e]) and every quote averaged over ITS expiry's terminal
+// spots -- two launches, one table upload, one read-back, one wait, instead of that per expiry; each quote comes back
+// with the bits of its own omc_heston_price_strikes(T = expiries[expiry_of[q]], stream = streams[expiry_of[q]]) call.
+int omc_heston_price_surface(omc_ctx* c, int64_t n_paths, int n_steps, double S0, double r, double v0, double kappa,
+                             double theta, double xi, double rho, uint64_t seed, int scheme, const double* expiries,
+                             const uint64_t* streams, int n_expiries, const double* strikes, const int32_t* expiry_of,
+                             int n_quotes, int is_put, double* prices, double* stderrs)
+{
+    int rc;
+    if ((rc = bind_in(c))) return rc;
+    if (!(S0 > 0)) return fail(-1, "S0, K, T must be positive.");
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if (n_paths & 1) return fail(-3, "antithetic layout needs an even n_paths.");
+    if (scheme < 0 || scheme > 2) return fail(-4, "unknown Heston scheme.");
+    if (!(rho >= -1.0 && rho <= 1.0) || !(v0 >= 0)) return fail(-5, "invalid Heston parameters.");
+    if (!expiries || !streams || n_expiries <= 0 || n_expiries > 65535) return fail(-7, "bad expiry arguments (1 .. 65535 expiries).");
+    if (!strikes || !expiry_of || !prices || n_quotes <= 0) return fail(-7, "bad strike arguments.");
+    for (int e = 0; e < n_expiries; ++e)
+        if (!(expiries[e] > 0)) return fail(-1, "S0, K, T must be positive.");
+    for (int q = 0; q < n_quotes; ++q)
+        if (expiry_of[q] < 0 || expiry_of[q] >= n_expiries) return fail(-4, "expiry_of[q] must index the expiries.");
+    const int64_t ldst = (n_paths + 63) / 64 * 64;
+    const size_t st_bytes = sizeof(float) * (size_t)ldst * (size_t)n_expiries;
+    const size_t tab_bytes = (omc::heston_surface_table_bytes(n_expiries) + 255) / 256 * 256;
+    const size_t k_bytes = sizeof(double) * (size_t)n_quotes, e_bytes = (sizeof(int32_t) * (size_t)n_quotes + 255) / 256 * 256;
+    if ((rc = c->scratch.ensure(st_bytes + 256 + tab_bytes + e_bytes + 3 * k_bytes))) return rc;
+    char* base = (char*)c->scratch.p;
+    float* ST = (float*)base;
+    void* tab = base + (st_bytes + 255) / 256 * 256;
+    int32_t* eo = (int32_t*)((char*)tab + tab_bytes);
+    double* Kd = (double*)((char*)eo + e_bytes);
+    double* out = Kd + n_quotes;
+    // host images that must outlive the asynchronous copies (pageable memory): the context keeps them until the wait below
+    c->h_table.resize(tab_bytes + sizeof(uint32_t) * (size_t)n_expiries);
+    uint32_t* st32 = (uint32_t*)(c->h_table.data() + tab_bytes);
+    for (int e = 0; e < n_expiries; ++e) st32[e] = (uint32_t)streams[e];
+    HIP_TRY(hipMemcpyAsync(Kd, strikes, k_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(eo, expiry_of, sizeof(int32_t) * (size_t)n_quotes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(omc::launch_heston_terminal_surface(c->stream, ST, ldst, n_paths, n_steps, S0, r, expiries, st32, n_expiries, v0,
+                                                kappa, theta, xi, rho, seed, 0, scheme, c->h_table.data(), tab));
+    HIP_TRY(omc::launch_payoff_means_surface(c->stream, ST, ldst, n_paths, Kd, eo, n_quotes, is_put ? 1 : 0, out));
+    std::vector<double> h(2 * (size_t)n_quotes);
+    HIP_TRY(hipMemcpyAsync(h.data(), out, 2 * k_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double M = (double)n_paths;
+    for (int q = 0; q < n_quotes; ++q) {
+        const double df = std::exp(-r * expiries[expiry_of[q]]);
+        const double mean = h[2 * (size_t)q] / M;
+        const double var = h[2 * (size_t)q + 1] / M - mean * mean;
+        prices[q] = df * mean;
+        if (stderrs) stderrs[q] = df * std::sqrt((var > 0 ? var : 0.0) / M);
     }
     return 0;
 }
@@ -2118,7 +2196,7 @@ int omc_nn_build_rows(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, i
         // (1) sum over the ranks of n_r mean_r and n_r -> the global means; (2) sum of M2_r + n_r (mean_r - mean)^2 ->
         // the global sum of squared deviations (Chan's merge, for any number of ranks at once).  A rank without rows
         // contributes zeros; when NO rank has a row every rank returns the defaults together.
-        if ((rc = c->seq_vote.ensure(sizeof(double) * 16))) return rc;  // (128 bytes: nothing left to do if this fails)
+        if ((rc = c->seq_vote.ensure(sizeof(double) * 16))) return rc;  // (never allocates: exists since the communicator / hook was installed)
         const double nr = lerr ? 0.0 : st[0];
         double v[9];
         for (int q = 0; q < 7; ++q) v[q] = nr * st[1 + q];
@@ -2194,32 +2272,31 @@ static void ols7_solve(const double* st, double n, const double* sd, const bool*
     for (int k = 0; k < rank; ++k) w7[1 + idx[order[k]]] = A[order[k]][m] / A[order[k]][order[k]];
 }
 
-int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r, double T,
-                 int is_put, omc_result* res, double* weights7, double* stats16, float* sx_out, int32_t* tex_out)
+// The body of omc_lsm_ols7 / omc_price_american_ols7 behind their argument checks (which are the same on every rank).
+// On a context with a communicator / hook the call is COLLECTIVE (two small all-reduces for the fit, one for the result).
+// A failure only this rank can see -- no memory for its path matrix or workspace (`pre_err` / `pre_text`: what the caller
+// already ran into), a HIP error in its sweep or in its pass 2 -- travels as a flag: in the ninth double of the first
+// all-reduce, resp. in slot 7 of the result sums (which the kernels leave at zero), and every rank returns an error
+// together (the rank's own code there, 3103 on its peers) instead of leaving the peers inside a collective.
+static int lsm_ols7_run(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r, double T,
+                        int is_put, omc_result* res, double* weights7, double* stats16, float* sx_out, int32_t* tex_out,
+                        int pre_err, const std::string& pre_text)
 {
     int rc;
-    if ((rc = bind_in(c))) return rc;
-    if ((rc = check_market(1.0, K, T, r))) return rc;
-    if ((rc = check_sizes(n_paths, n_steps))) return rc;
-    if ((rc = check_matrix(S, ld, n_paths))) return rc;
-    if (!res) return fail(-7, "null result pointer.");
-    // On a context with a communicator / hook the call is COLLECTIVE (two small all-reduces for the fit, one for the result).
-    // A failure only this rank can see -- no memory for its workspace, a HIP error in its sweep -- travels as a flag in the
-    // first all-reduce, and every rank returns an error together (the rank's own code there, 3103 on its peers), instead
-    // of leaving the peers inside a collective (as omc_nn_build_rows does).
     const bool dist = c->distributed();
-    int lerr = 0;
-    std::string ltext;
+    int lerr = pre_err;
+    std::string ltext = pre_text;
     auto local_failure = [&](int code) {
         lerr = code;
         ltext = g_err;
     };
     omc::LsmWorkspace w;
-    if ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w)) ||
-        (rc = c->scratch.ensure(omc::ols7_scratch_bytes(n_paths, n_steps)))) {
+    if (!lerr && ((rc = prepare_lsm(c, n_paths, n_steps, r, T, false, true, &w)) ||
+                  (rc = c->scratch.ensure(omc::ols7_scratch_bytes(n_paths, n_steps))))) {
         if (!dist) return rc;
         local_failure(rc);
     }
+    if (lerr && !dist) return fail(lerr, ltext.c_str());
     omc::LsmProblem p{S, ld, n_paths, n_steps, is_put ? 1 : 0, K, r, T};
     // pass 1 (:482-516): one sweep -> (n, mean, co-moments) of the 6 non-constant features and the target
     double st[omc::kOls7Stats] = {0.0};
@@ -2239,7 +2316,7 @@ int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
         // (n_r, mean_r, C_r) are merged by Chan's formula for any number of ranks at once -- (1) sum of n_r mean_r and
         // n_r -> the global means; (2) sum of C_r + n_r (mean_r - mean)(mean_r - mean)^T -> the global co-moments -- the
         // "regression moments" all-reduce of north_star, 9 + 28 doubles.  Every rank then solves the same 6 x 6 system.
-        if ((rc = c->seq_vote.ensure(sizeof(double) * 40))) return rc;  // (320 bytes: nothing left to do if this fails)
+        if ((rc = c->seq_vote.ensure(sizeof(double) * 40))) return rc;  // (never allocates: exists since the communicator / hook was installed)
         const double nr = lerr ? 0.0 : st[0];
         double v[9], mr[7];
         for (int q = 0; q < 7; ++q) {
@@ -2324,18 +2401,41 @@ int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_
         s16[15] = sd[6];
     }
     // pass 2 (:615-651) with the fit, then the mean of the cash-flows valued at t = dt (:651)
-    HIP_TRY(omc::ols7_pass2(c->stream, p, s16, s16 + 7, w7, s16[14], s16[15], w.sx, w.tex));
-    HIP_TRY(omc::lsm_final_reduce(c->stream, p, w, 1));
-    if (c->distributed() && (rc = allreduce(c, w.result, 8))) return rc;  // the discounted-payoff sums of all ranks
+    hipError_t e2 = omc::ols7_pass2(c->stream, p, s16, s16 + 7, w7, s16[14], s16[15], w.sx, w.tex);
+    if (e2 == hipSuccess) e2 = omc::lsm_final_reduce(c->stream, p, w, 1);
+    if (e2 != hipSuccess) {
+        g_err = std::string("pass 2 with the fit failed: ") + hipGetErrorString(e2);
+        if (!dist) return (int)e2;
+        local_failure((int)e2);
+        static const double kOne = 1.0;  // this rank's flag rides in slot 7 of the sums about to be all-reduced
+        (void)hipMemcpyAsync(w.result + 7, &kOne, sizeof kOne, hipMemcpyHostToDevice, c->stream);
+    }
+    if (dist && (rc = allreduce(c, w.result, 8))) return rc;  // the discounted-payoff sums of all ranks (+ the flag)
     HIP_TRY(hipMemcpyAsync(c->hres, w.result, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-    if ((rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
+    if (!lerr && (rc = copy_outputs(c, w, n_paths, n_steps, nullptr, sx_out, tex_out))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (dist && (lerr || c->hres[7] > 0.0)) {
+        if (lerr) return fail(lerr, ltext.c_str());
+        return fail(3103, "another rank of the job could not run its pass 2.");
+    }
     memset(res, 0, sizeof *res);
     fill_result(res, c->hres, c->distributed() ? n_paths * c->world : n_paths, c->distributed() ? c->world : 1);
     res->sum_nitm = (int64_t)llround(n);  // rows of the regression (of the job)
     if (weights7) memcpy(weights7, w7, sizeof w7);
     if (stats16) memcpy(stats16, s16, sizeof s16);
     return 0;
+}
+
+int omc_lsm_ols7(omc_ctx* c, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K, double r, double T,
+                 int is_put, omc_result* res, double* weights7, double* stats16, float* sx_out, int32_t* tex_out)
+{
+    int rc;
+    if ((rc = bind_in(c))) return rc;
+    if ((rc = check_market(1.0, K, T, r))) return rc;
+    if ((rc = check_sizes(n_paths, n_steps))) return rc;
+    if ((rc = check_matrix(S, ld, n_paths))) return rc;
+    if (!res) return fail(-7, "null result pointer.");
+    return lsm_ols7_run(c, S, ld, n_paths, n_steps, K, r, T, is_put, res, weights7, stats16, sx_out, tex_out, 0, std::string());
 }
 
 int omc_price_american_ols7(omc_ctx* c, const omc_params* p, omc_result* res, double* weights7, double* stats16)
@@ -2345,10 +2445,18 @@ int omc_price_american_ols7(omc_ctx* c, const omc_params* p, omc_result* res, do
     if ((rc = check_params(p))) return rc;
     if (!res) return fail(-7, "null result pointer.");
     const int64_t ld = (p->n_paths + 63) / 64 * 64;
-    if ((rc = c->S.ensure(sizeof(float) * (size_t)ld * (size_t)(p->n_steps + 1)))) return rc;  // the context's own path matrix
-    if ((rc = enqueue_paths(c, p, (float*)c->S.p, ld))) return rc;
-    return omc_lsm_ols7(c, (const float*)c->S.p, ld, p->n_paths, p->n_steps, p->K, p->r, p->T, p->is_put ? 1 : 0, res, weights7,
-                        stats16, nullptr, nullptr);
+    // the context's own path matrix: the largest allocation of the call and the likeliest to fail on a card shared with
+    // other tenants -- on a distributed context that failure must reach the peers (lsm_ols7_run), not strand them
+    int pre = 0;
+    std::string text;
+    if ((rc = c->S.ensure(sizeof(float) * (size_t)ld * (size_t)(p->n_steps + 1))) ||
+        (rc = enqueue_paths(c, p, (float*)c->S.p, ld))) {
+        if (!c->distributed()) return rc;
+        pre = rc;
+        text = g_err;
+    }
+    return lsm_ols7_run(c, (const float*)c->S.p, ld, p->n_paths, p->n_steps, p->K, p->r, p->T, p->is_put ? 1 : 0, res, weights7,
+                        stats16, nullptr, nullptr, pre, text);
 }
 
 int omc_nn_feature_stats(omc_ctx* c, const double* x, const int32_t* t, const double* y, int64_t n_rows,

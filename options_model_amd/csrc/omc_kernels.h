@@ -46,6 +46,15 @@ hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_pat
 // out_dev [n_strikes][2] = {sum, sumsq} of max(+-(S_T - K), 0)
 hipError_t launch_payoff_means(hipStream_t st, const float* ST, int64_t n_paths, const double* K_dev,
                                int n_strikes, int is_put, double* out_dev);
+// a whole quote surface: the expiry on grid.y (its constants and Philox sub-stream from a 64-byte-per-expiry table that
+// the launcher fills in `tab_host` and copies to `tab_dev`), ST device [n_expiries][ldst]; then one workgroup per quote
+size_t heston_surface_table_bytes(int n_expiries);
+hipError_t launch_heston_terminal_surface(hipStream_t st, float* ST, int64_t ldst, int64_t n_paths, int n_steps, double S0,
+                                          double r, const double* T_host, const uint32_t* stream_host, int n_expiries,
+                                          double v0, double kappa, double theta, double xi, double rho, uint64_t seed,
+                                          uint64_t pair_offset, int scheme, void* tab_host, void* tab_dev);
+hipError_t launch_payoff_means_surface(hipStream_t st, const float* ST, int64_t ldst, int64_t n_paths, const double* K_dev,
+                                       const int32_t* expiry_of_dev, int n_quotes, int is_put, double* out_dev);
 hipError_t launch_philox_kat(hipStream_t st, const uint32_t* in, uint32_t* out, int n);
 hipError_t launch_gbm_normals(hipStream_t st, float* Z, int64_t ldz, int64_t n_pairs, int n_steps,
                               uint64_t seed, uint32_t stream, uint64_t pair_offset);

@@ -2698,13 +2698,12 @@ static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
     return hipGetLastError();
 }
 
-int64_t mlp_plan_kernel_batch(const MlpTrainPlan& t)
-{
-    if (!t.step_off) return t.batch;
-    int64_t mx = 1;  // sharded: the kernel (and its partial buffer) must cover this rank's largest step
-    for (int64_t k = 0, n = plan_steps(t); k < n; ++k) mx = std::max(mx, t.step_off[k + 1] - t.step_off[k]);
-    return mx;
-}
+// The minibatch size that picks the trainer kernel and sizes its partial buffer: the GLOBAL one, sharded or not.  A rank's
+// own part of a minibatch is never larger (omc_mlp_train_epoch_sharded checks step_off against it), so the buffer covers
+// it; and every rank of a job -- and the unsharded run of the same job -- picks the SAME kernel, hence the same dropout
+// tags and unit map: a rank's masks are those of the unsharded run whatever its share of a minibatch is (a choice by the
+// local share used to split ranks at the 4,096-row limit of the 16-row kernel: ADVICE r5).
+int64_t mlp_plan_kernel_batch(const MlpTrainPlan& t) { return t.batch; }
 
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
 {

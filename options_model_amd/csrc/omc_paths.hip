@@ -227,27 +227,63 @@ hipError_t launch_heston_from_normals(hipStream_t st, float* S, int64_t ld, int6
 // HestonPricer.price_options_batch (heston_calibration.py:283-312): one simulation per expiry,
 // then one mean payoff per strike.  Terminal spots of all paths go to a small buffer (4 bytes
 // per path, no path matrix); a second launch reduces one strike per workgroup over it.
+// one antithetic pair from t = 0 to the expiry: the terminal spots of both partners (shared by the one-expiry kernel and
+// the surface kernel, so that a surface's expiry has the bits of its own omc_heston_price_strikes call)
+template <int SCHEME>
+__device__ __forceinline__ void heston_terminal_pair(const HestonC& hc, int n_steps, float s_init, float v_init, uint64_t pair,
+                                                     uint32_t stream, uint32_t k0, uint32_t k1, float& s_out, float& sa_out)
+{
+    float s = s_init, sa = s_init, va = v_init, vb = v_init, z[4];
+    for (int t = 0; t < n_steps; ++t) {
+        const int i = t & 1;
+        if (i == 0) normals4(pair, (uint32_t)(t >> 1), stream, k0, k1, z);
+        heston_pair_step<SCHEME>(hc, z[2 * i], z[2 * i + 1], s, va, sa, vb);
+    }
+    s_out = s;
+    sa_out = sa;
+}
+
 template <int SCHEME>
 __global__ __launch_bounds__(kBlock) void heston_terminal_store_kernel(float* __restrict__ ST, PathArgs g)
 {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= g.P) return;
-    float s = g.s_init, sa = g.s_init, va = g.v_init, vb = g.v_init, z[4];
-    for (int t = 0; t < g.n_steps; ++t) {
-        const int i = t & 1;
-        if (i == 0) normals4(g.pair_offset + (uint64_t)p, (uint32_t)(t >> 1), g.stream, g.k0, g.k1, z);
-        heston_pair_step<SCHEME>(g.hc, z[2 * i], z[2 * i + 1], s, va, sa, vb);
-    }
+    float s, sa;
+    heston_terminal_pair<SCHEME>(g.hc, g.n_steps, g.s_init, g.v_init, g.pair_offset + (uint64_t)p, g.stream, g.k0, g.k1, s, sa);
     ST[p] = s;
     ST[p + g.P] = sa;
 }
 
-__global__ __launch_bounds__(kBlock) void payoff_means_kernel(const float* __restrict__ ST, int64_t M,
-                                                              const double* __restrict__ K, int is_put,
-                                                              double* __restrict__ out)
+// A whole quote surface in ONE launch set (HestonPricer.price_options_batch, heston_calibration.py:283-312: the calibrator's
+// objective simulates every distinct expiry and averages every strike of it): the expiry on grid.y -- its own dt-dependent
+// constants and Philox sub-stream from a small device table --, terminal spots into ST[expiry][ldst]; then one workgroup
+// per QUOTE reduces its strike over its expiry's row, in payoff_means_kernel's order.
+struct SurfaceExpiry {
+    HestonC hc;
+    uint32_t stream, pad[2];
+};
+static_assert(sizeof(SurfaceExpiry) == 64, "omc::heston_surface_table_bytes");
+
+template <int SCHEME>
+__global__ __launch_bounds__(kBlock) void heston_terminal_surface_kernel(float* __restrict__ ST, int64_t ldst, PathArgs g,
+                                                                         const SurfaceExpiry* __restrict__ tab)
+{
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= g.P) return;
+    const SurfaceExpiry e = tab[blockIdx.y];
+    float s, sa;
+    heston_terminal_pair<SCHEME>(e.hc, g.n_steps, g.s_init, g.v_init, g.pair_offset + (uint64_t)p, e.stream, g.k0, g.k1, s, sa);
+    float* row = ST + (int64_t)blockIdx.y * ldst;
+    row[p] = s;
+    row[p + g.P] = sa;
+}
+
+// {sum, sumsq} of one strike's payoffs over one row of terminal spots: thread j adds spots j, j + 256, ... in order, then
+// the workgroup tree -- the summation order of a quote is fixed by (M, block size) alone
+__device__ __forceinline__ void payoff_means_body(const float* __restrict__ ST, int64_t M, double k, int is_put,
+                                                  double* __restrict__ out2)
 {
     __shared__ double red[kNQ * kRedStride];
-    const double k = K[blockIdx.x];
     double acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.0;
@@ -258,8 +294,22 @@ __global__ __launch_bounds__(kBlock) void payoff_means_kernel(const float* __res
         acc[1] += p * p;
     }
     const double s = block_reduce8(acc, red);
-    if (threadIdx.x < 64 && (threadIdx.x & 7) == 0 && (threadIdx.x >> 3) < 2)
-        out[2 * (size_t)blockIdx.x + (threadIdx.x >> 3)] = s;
+    if (threadIdx.x < 64 && (threadIdx.x & 7) == 0 && (threadIdx.x >> 3) < 2) out2[threadIdx.x >> 3] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void payoff_means_kernel(const float* __restrict__ ST, int64_t M,
+                                                              const double* __restrict__ K, int is_put,
+                                                              double* __restrict__ out)
+{
+    payoff_means_body(ST, M, K[blockIdx.x], is_put, out + 2 * (size_t)blockIdx.x);
+}
+
+__global__ __launch_bounds__(kBlock) void payoff_means_surface_kernel(const float* __restrict__ ST, int64_t ldst, int64_t M,
+                                                                      const double* __restrict__ K,
+                                                                      const int32_t* __restrict__ expiry_of, int is_put,
+                                                                      double* __restrict__ out)
+{
+    payoff_means_body(ST + (int64_t)expiry_of[blockIdx.x] * ldst, M, K[blockIdx.x], is_put, out + 2 * (size_t)blockIdx.x);
 }
 
 hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_paths, int n_steps,
@@ -276,6 +326,42 @@ hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_pat
     if (scheme == 0) hipLaunchKernelGGL((heston_terminal_store_kernel<0>), grid, block, 0, st, ST, g);
     else if (scheme == 1) hipLaunchKernelGGL((heston_terminal_store_kernel<1>), grid, block, 0, st, ST, g);
     else hipLaunchKernelGGL((heston_terminal_store_kernel<2>), grid, block, 0, st, ST, g);
+    return hipGetLastError();
+}
+
+size_t heston_surface_table_bytes(int n_expiries) { return sizeof(SurfaceExpiry) * (size_t)(n_expiries > 0 ? n_expiries : 0); }
+
+hipError_t launch_heston_terminal_surface(hipStream_t st, float* ST, int64_t ldst, int64_t n_paths, int n_steps, double S0,
+                                          double r, const double* T_host, const uint32_t* stream_host, int n_expiries,
+                                          double v0, double kappa, double theta, double xi, double rho, uint64_t seed,
+                                          uint64_t pair_offset, int scheme, void* tab_host, void* tab_dev)
+{
+    PathArgs g{};
+    g.P = n_paths / 2; g.n_steps = n_steps; g.s_init = (float)S0; g.v_init = (float)v0;
+    g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.pair_offset = pair_offset;
+    if (g.P <= 0 || n_expiries <= 0) return hipSuccess;
+    SurfaceExpiry* h = (SurfaceExpiry*)tab_host;
+    for (int e = 0; e < n_expiries; ++e) {
+        h[e] = SurfaceExpiry{};
+        h[e].hc = make_heston(r, T_host[e], n_steps, kappa, theta, xi, rho);
+        h[e].stream = stream_host[e];
+    }
+    hipError_t err = hipMemcpyAsync(tab_dev, tab_host, heston_surface_table_bytes(n_expiries), hipMemcpyHostToDevice, st);
+    if (err != hipSuccess) return err;
+    const dim3 grid(grid_for(g.P), (unsigned)n_expiries), block(kBlock);
+    const SurfaceExpiry* tab = (const SurfaceExpiry*)tab_dev;
+    if (scheme == 0) hipLaunchKernelGGL((heston_terminal_surface_kernel<0>), grid, block, 0, st, ST, ldst, g, tab);
+    else if (scheme == 1) hipLaunchKernelGGL((heston_terminal_surface_kernel<1>), grid, block, 0, st, ST, ldst, g, tab);
+    else hipLaunchKernelGGL((heston_terminal_surface_kernel<2>), grid, block, 0, st, ST, ldst, g, tab);
+    return hipGetLastError();
+}
+
+hipError_t launch_payoff_means_surface(hipStream_t st, const float* ST, int64_t ldst, int64_t n_paths, const double* K_dev,
+                                       const int32_t* expiry_of_dev, int n_quotes, int is_put, double* out_dev)
+{
+    if (n_quotes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(payoff_means_surface_kernel, dim3(n_quotes), dim3(kBlock), 0, st, ST, ldst, n_paths, K_dev, expiry_of_dev,
+                       is_put, out_dev);
     return hipGetLastError();
 }
 

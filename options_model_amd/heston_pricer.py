@@ -84,14 +84,41 @@ class HestonPricer:
 
     def price_options_batch(self, params, S0: float, K_array, T_array,
                             r: float = 0.05) -> np.ndarray:
-        """Calls only, grouped by expiry: one simulation per distinct T (:289-306)."""
+        """Calls only, grouped by expiry: one simulation per distinct T (:289-306) -- here ALL of them in one launch set
+        (omc_heston_price_surface: the expiry on grid.y, every quote one workgroup, one wait), each expiry on the Philox
+        sub-stream the reference's loop `for T in unique_T` would have reached it on.  Quote for quote the bits of the
+        per-expiry calls (`per_expiry=True` keeps that form: one synchronous call per expiry, as the reference's loop)."""
+        return self._batch(params, S0, K_array, T_array, r, per_expiry=False)
+
+    def price_options_batch_per_expiry(self, params, S0: float, K_array, T_array, r: float = 0.05) -> np.ndarray:
+        """The reference's own loop shape (:291-310): one simulation + one host wait per distinct expiry."""
+        return self._batch(params, S0, K_array, T_array, r, per_expiry=True)
+
+    def _batch(self, params, S0, K_array, T_array, r, per_expiry):
         K_array = np.asarray(K_array, np.float64)
         T_array = np.asarray(T_array, np.float64)
         prices = np.zeros(len(K_array))
-        for T in np.unique(T_array):
+        if len(K_array) == 0:
+            return prices
+        uniq, expiry_of = np.unique(T_array, return_inverse=True)
+        if not per_expiry:
+            try:
+                prm = as_params(params)
+                cfg = self.config
+                n_paths = int(getattr(cfg, "n_mc_paths", 100000)) // 2 * 2
+                streams = self._stream + 1 + np.arange(len(uniq), dtype=np.uint64)
+                got, _ = _ffi.default_context(self.device).heston_price_surface(
+                    n_paths, int(getattr(cfg, "n_time_steps", 100)), float(S0), float(r), float(prm.v0), float(prm.kappa),
+                    float(prm.theta), float(prm.sigma), float(prm.rho), uniq, streams, K_array, expiry_of, is_put=False,
+                    seed=int(getattr(cfg, "seed", 42)), scheme=_ffi.HESTON_SCHEMES["calibrator"])
+                self._stream += len(uniq)
+                return got
+            except Exception as e:  # noqa: BLE001  (the reference prints and returns nan for what failed, :308-310)
+                print(f"Warning: Batch pricing failed: {e}")
+                self._stream += len(uniq)
+                return np.full(len(K_array), np.nan)
+        for T in uniq:
             mask = T_array == T
-            if not mask.any():
-                continue
             try:
                 p, _ = self._strikes(params, S0, K_array[mask], float(T), r, False)
                 prices[mask] = p

@@ -77,3 +77,77 @@ def test_heston_pricer_drop_in(ctx, cal):
     assert np.isnan(pr.price_european_option(SimpleNamespace(kappa=2.0), 100.0, 100.0, 0.75, 0.03))
     # consecutive calls draw fresh normals, like the reference's advancing rng
     assert pr.price_european_option(prm, 100.0, 100.0, 0.75, 0.03) != pr.price_european_option(prm, 100.0, 100.0, 0.75, 0.03)
+
+
+# ---- a whole quote surface in one launch set (omc_heston_price_surface) ---------------------------
+def _surface_case(rng, n_exp, max_strikes):
+    T = np.sort(rng.uniform(0.05, 2.0, n_exp))
+    quotes = [(e, k) for e in range(n_exp) for k in rng.uniform(60.0, 150.0, rng.integers(1, max_strikes + 1))]
+    order = rng.permutation(len(quotes))  # quotes arrive in the caller's order, not grouped by expiry
+    eo = np.array([quotes[i][0] for i in order], np.int32)
+    K = np.array([quotes[i][1] for i in order])
+    return T, eo, K
+
+
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_surface_equals_the_per_expiry_calls_bit_for_bit(ctx, scheme):
+    """One objective evaluation of the calibrator (heston_calibration.py:283-312 loops over the distinct expiries): all
+    expiries simulated by ONE launch (expiry on grid.y), all quotes reduced by one more, one wait -- and every quote must
+    carry the bits of its own per-expiry call (same Philox sub-stream, same stepper, same summation order), for calls and
+    puts, ragged strike counts, quotes in any order, a path count that is not a multiple of the block size."""
+    rng = np.random.default_rng(11 + scheme)
+    args = dict(S0=100.0, r=0.03, v0=0.05, kappa=1.7, theta=0.045, xi=0.55, rho=-0.6)
+    for n_paths, n_steps, n_exp in ((100_000, 100, 6), (30_002, 37, 3), (2, 1, 1)):
+        T, eo, K = _surface_case(rng, n_exp, 17)
+        streams = 40 + np.arange(n_exp)
+        for is_put in (False, True):
+            got, err = ctx.heston_price_surface(n_paths, n_steps, args["S0"], args["r"], args["v0"], args["kappa"], args["theta"],
+                                                args["xi"], args["rho"], T, streams, K, eo, is_put=is_put, seed=9, scheme=scheme)
+            for e in range(n_exp):
+                m = eo == e
+                one, one_err = ctx.heston_price_strikes(n_paths, n_steps, args["S0"], args["r"], float(T[e]), args["v0"],
+                                                        args["kappa"], args["theta"], args["xi"], args["rho"], K[m],
+                                                        is_put=is_put, seed=9, stream=int(streams[e]), scheme=scheme)
+                assert np.array_equal(got[m], one) and np.array_equal(err[m], one_err), (scheme, n_paths, e, is_put)
+    # and against the oracle on the same stream, like the single-expiry entry point
+    T, eo, K = _surface_case(rng, 3, 5)
+    got, _ = ctx.heston_price_surface(200_000, 40, 100.0, 0.03, 0.04, 2.0, 0.04, 0.6, -0.7, T, [3, 4, 5], K, eo, seed=42, scheme=scheme)
+    for e in range(3):
+        ST = orc.heston_terminal(200_000, 40, 100.0, 0.03, float(T[e]), 0.04, 2.0, 0.04, 0.6, -0.7, seed=42, stream=3 + e, scheme=scheme)
+        assert np.allclose(got[eo == e], rf.strike_prices(ST, K[eo == e], 0.03, float(T[e]), False), rtol=2e-5, atol=1e-6)
+
+
+def test_surface_argument_errors(ctx):
+    from options_model_amd import _ffi
+    a = (1000, 10, 100.0, 0.03, 0.04, 2.0, 0.04, 0.3, -0.7)
+    with pytest.raises(ValueError, match="expiry_of"):
+        ctx.heston_price_surface(*a, [0.5, 1.0], [1, 2], [100.0], [2])
+    with pytest.raises(ValueError, match="positive"):
+        ctx.heston_price_surface(*a, [0.5, 0.0], [1, 2], [100.0], [0])
+    with pytest.raises(ValueError, match="matching"):
+        ctx.heston_price_surface(*a, [0.5, 1.0], [1], [100.0], [0])
+    with pytest.raises((ValueError, _ffi.OmcError)):
+        ctx.heston_price_surface(*a, [], [], [100.0], [0])
+
+
+def test_heston_pricer_batch_is_the_surface_call_with_the_loops_bits(ctx):
+    """HestonPricer.price_options_batch now prices the whole surface in one launch set; the reference's loop shape stays
+    available (price_options_batch_per_expiry).  Same sub-streams in the same order -> the same bits, and the pricer's
+    stream counter -- the stand-in for the reference's advancing generator -- moves by one per distinct expiry either way."""
+    from types import SimpleNamespace
+
+    from options_model_amd.heston_pricer import HestonPricer
+    cfg = SimpleNamespace(n_mc_paths=100_000, n_time_steps=100, seed=42)
+    prm = SimpleNamespace(kappa=2.0, theta=0.04, sigma=0.3, rho=-0.7, v0=0.04)
+    rng = np.random.default_rng(5)
+    T = rng.choice([30 / 365, 60 / 365, 91 / 365, 0.5, 1.0, 2.0], 60)
+    K = rng.uniform(80.0, 125.0, 60)
+    a, b = HestonPricer(cfg), HestonPricer(cfg)
+    for _ in range(2):  # consecutive evaluations keep drawing fresh sub-streams, in step
+        pa, pb = a.price_options_batch(prm, 100.0, K, T, 0.03), b.price_options_batch_per_expiry(prm, 100.0, K, T, 0.03)
+        assert np.array_equal(pa, pb) and np.all(pa > 0) and a._stream == b._stream
+    assert a._stream == 12
+    assert not np.array_equal(pa, HestonPricer(cfg).price_options_batch(prm, 100.0, K, T, 0.03))  # (streams 1-6, not 7-12)
+    # a failure is the reference's behaviour: a warning on stdout and nan, never an exception (:308-310)
+    bad = a.price_options_batch(SimpleNamespace(kappa=2.0), 100.0, K[:3], T[:3], 0.03)
+    assert np.isnan(bad).all() and a.price_options_batch(prm, 100.0, [], [], 0.03).shape == (0,)

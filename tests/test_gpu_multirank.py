@@ -297,6 +297,58 @@ def test_a_memory_tight_rank_votes_the_whole_job_down(ctx, standin, tmp_path, tr
     assert got[0]["prices"][0] == pytest.approx(ref["price"], rel=1e-12)
 
 
+_OLS7_TIGHT = r"""
+import json, os, sys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+sys.path.insert(0, %r)
+from options_model_amd import _ffi
+from options_model_amd.dist import RcclPricer
+sp = RcclPricer(0, rank, world)
+kw = dict(semantics="two_pass", n_steps=40, seed=11, stream=2)
+if rank == 1:
+    sp.ctx.set_option("alloc_limit", 16 << 20)   # this rank's card "has no room" for its 32.8 MB path matrix
+try:
+    sp.price_american_ols7(400_000, **kw)
+    err = None
+except _ffi.OmcError as e:
+    err = str(e)
+sp.ctx.set_option("alloc_limit", 0)
+out = sp.price_american_ols7(400_000, **kw)      # the communicator is still in step: the next collective call works
+print("RESULT" + str(rank) + " " + json.dumps(dict(err=err, price=out["price"], sum_nitm=out["sum_nitm"])))
+sp.close()
+"""
+
+
+def test_ols7_a_rank_without_room_for_its_paths_fails_the_call_on_every_rank(ctx, standin, tmp_path):
+    """omc_price_american_ols7 is collective on a distributed context; rank 1's path matrix does not fit
+    (option "alloc_limit").  It used to return before any collective and leave rank 0 inside the first all-reduce for
+    ever.  Now the failure travels as a flag: rank 1 reports its own error, rank 0 "another rank ..." (3103), both AFTER the
+    all-reduce -- and the very next collective call of the two ranks prices the unsharded problem."""
+    from options_model_amd import _ffi
+    script = tmp_path / "ols7_tight.py"
+    script.write_text(_OLS7_TIGHT % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(29890 + os.getpid() % 60), OMC_RCCL_LIB=standin, OMC_RDZV_NONCE=f"ols7tight{os.getpid()}")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    try:
+        outs = [p.communicate(timeout=200) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    got = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2500:]
+        got.append(json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT")][0].split(" ", 1)[1]))
+    assert "another rank of the job" in got[0]["err"] and "alloc_limit" in got[1]["err"]
+    one = ctx.price_american_ols7(_ffi.make_params(semantics="two_pass", n_paths=400_000, n_steps=40, seed=11, stream=2))
+    assert got[0]["price"] == got[1]["price"] == pytest.approx(one["price"], rel=1e-12)
+    assert got[0]["sum_nitm"] == one["sum_nitm"]
+
+
 def test_the_drivers_launch_form_torchrun_native_communicator(ctx, standin):
     """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...`: the ranks are torchrun's children (common parent = its agent, which names

@@ -221,8 +221,40 @@ def test_collective_calls_fail_on_every_rank_together():
             calls.clear()
             got = c.nn_build_rows(S.ptr, S.shape[1], 20_000, 20, K, R, T, True, data.data_ptr(), n)
             assert got[0] == n and calls == [9, 8]
+            # (d) ADVICE r5 (medium): the fused call's OWN path matrix -- its largest allocation -- does not fit on this rank
+            # alone (option "alloc_limit"): the rank must still enter the first all-reduce (its peers are in it) and
+            # then report its own error; the same budget on a plain context fails at once, without any collective
+            calls.clear()
+            big = _ffi.make_params(semantics="two_pass", n_paths=400_000, n_steps=40, seed=3)  # 65.6 MB of paths
+            c.set_option("alloc_limit", 32 << 20)
+            with pytest.raises(_ffi.OmcError, match="alloc_limit"):
+                c.price_american_ols7(big)
+            assert calls == [9]
+            c.set_option("alloc_limit", 0)
+            calls.clear()
+            ok = c.price_american_ols7(big)
+            assert calls == [9, 28, 8] and 5.0 < ok["price"] < 9.0
+            # (e) a peer whose PASS 2 failed: its flag arrives in slot 7 of the result sums (zero from the kernels)
+            calls.clear()
+
+            def peer_failed_late(dptr, count):
+                calls.append(count)
+                t = torch.as_tensor(_DevPtr(dptr, count), device="cuda")
+                t.mul_(2.0)
+                if count == 8:
+                    t[7] += 1.0
+
+            c.set_allreduce_hook(peer_failed_late)
+            with pytest.raises(_ffi.OmcError, match="another rank of the job could not run its pass 2"):
+                c.price_american_ols7(big)
+            assert calls == [9, 28, 8]
             c.set_allreduce_hook(None)
             c.set_option("world_size", 1)
+            c.set_option("alloc_limit", 32 << 20)
+            with pytest.raises(_ffi.OmcError, match="alloc_limit"):
+                c.price_american_ols7(big)  # one rank: no collective to enter, the error comes back directly
+            c.set_option("alloc_limit", 0)
             S.free()
     finally:
+        c.set_option("alloc_limit", 0)
         c.close()

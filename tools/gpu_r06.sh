@@ -49,6 +49,7 @@ sq)  # SQ counters of the three c2 kernels on the current library (VERDICT r5 it
   done
   python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_sqc2_" | tee "$R/gpurun_out/pmc_sq_summary_${TAG}_c2.txt"
   for d in "$R"/gpurun_out/pmc_${TAG}_sqc2_*; do [ -d "$d" ] && rm -rf "$d"; done
+  true
   ;;
 tch)  # pass 1's reads by time-chunk length: every (tile, chunk) re-reads the terminal row and its last prefetches are clamped
       # duplicates -> exact request-size counters + timing at c3 and c2 for OMC_PASS1_TCHUNK = auto / 32 / 63 / 126 / 251
@@ -72,6 +73,43 @@ print('$CFG tchunk=$TCH ms_per_step', round(d['ms_per_step'],4), 'pass1 ms', rou
   unset OMC_PASS1_TCHUNK
   python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_tch_c3_" --by-dir | tee "$R/gpurun_out/${TAG}_pass1_reads_by_tchunk.txt"
   for d in "$R"/gpurun_out/pmc_${TAG}_tch_c3_*; do [ -d "$d" ] && rm -rf "$d"; done
+  true
+  ;;
+calib)  # f-3 measured: the calibrator's objective evaluation, surface call vs per-expiry loop; kernel stats; VALU share of the simulation
+  timeout -k 10 600 python -m pytest tests/test_gpu_calibrator.py tests/test_gpu_ols7.py tests/test_gpu_multirank.py::test_ols7_a_rank_without_room_for_its_paths_fails_the_call_on_every_rank tests/test_gpu_nn_dist.py -x -q -m gpu --durations=5 > gpurun_out/${TAG}_calib_tests.log 2>&1; rc=$?
+  tail -12 gpurun_out/${TAG}_calib_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
+  [ $rc -eq 0 ] || exit 1
+  timeout -k 10 300 python tools/bench_calibrator.py > gpurun_out/${TAG}_calibrator.json 2> gpurun_out/${TAG}_calibrator.err; rc=$?
+  cat gpurun_out/${TAG}_calibrator.json; tail -2 gpurun_out/${TAG}_calibrator.err; ok $rc || exit 1
+  prof calibrator "$R/tools/bench_calibrator.py" --evals 100 --no-cpu || exit 1
+  pmc "calib_a" "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "$R/tools/bench_calibrator.py" --evals 20 --no-cpu || exit 1
+  pmc "calib_b" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU" "$R/tools/bench_calibrator.py" --evals 20 --no-cpu || exit 1
+  python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_calib_" | tee "$R/gpurun_out/${TAG}_pmc_calibrator.txt" | head -60
+  for d in "$R"/gpurun_out/pmc_${TAG}_calib_*; do [ -d "$d" ] && rm -rf "$d"; done
+  true
+  ;;
+dup)  # pass 1: where the chunk's last two (unused) prefetches point -- its last row (0) or the row being processed (1)
+  for REP in 1 2; do
+    for CFG in c3 c2; do
+      for DUP in 0 1; do
+        export OMC_PASS1_DUP=$DUP
+        timeout -k 10 300 python bench.py --config $CFG --steps 12 --warmup 4 --only-timed > gpurun_out/${TAG}_dup_${CFG}_${DUP}.json 2> gpurun_out/${TAG}_dup_${CFG}_${DUP}.err; rc=$?
+        ok $rc || exit 1
+        python3 -c "
+import json; d=json.load(open('gpurun_out/${TAG}_dup_${CFG}_${DUP}.json')); k={x['kernel']:x for x in d['roofline_kernels']}
+print('$CFG dup=$DUP rep $REP ms_per_step', round(d['ms_per_step'],4), 'pass1 ms', round(k['lsm_pass1_kernel']['ms_per_launch'],4), 'frac', round(k['lsm_pass1_kernel']['frac'],4))" | tee -a gpurun_out/${TAG}_pass1_dup.txt
+      done
+    done
+  done
+  for DUP in 0 1; do
+    export OMC_PASS1_DUP=$DUP
+    pmc "dup_c3_${DUP}_a" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
+    pmc "dup_c3_${DUP}_b" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
+  done
+  unset OMC_PASS1_DUP
+  python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_dup_c3_" --by-dir | grep -A3 "====\|pass1" | tee -a "$R/gpurun_out/${TAG}_pass1_dup.txt"
+  for d in "$R"/gpurun_out/pmc_${TAG}_dup_c3_*; do [ -d "$d" ] && rm -rf "$d"; done
+  true
   ;;
 tests)
   timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
