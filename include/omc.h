@@ -332,9 +332,13 @@ int omc_lsm_apply_mlp_shard(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_
  * too small, no memory for its scratch) travels as a flag in the first of them and EVERY rank returns an error -- the
  * rank's own, 3102 on its peers -- instead of leaving them inside a collective; a job without any in-the-money row
  * returns the default statistics (means 0, stds 1) on every rank.
- * S is read twice: one sweep counts the rows of every (step, 256-path tile) and forms the statistics -- per-thread sums
- * around the thread's first row, merged as (n, mean, M2) triples by Chan's formula in a fixed tree: the two-pass values
- * of :550-563 to ~1e-15, a constant column's variance exactly 0 -- and one sweep writes the rows. */
+ * S is read twice IN ALL: one sweep counts the rows of every (step, 256-path tile) and forms the statistics -- power sums
+ * around centres shared by a workgroup (its first spot over the strike; sqrt(tau) of its first step), added over its lanes
+ * in a fixed order, turned into (n, mean, M2) triples per workgroup and merged by Chan's formula in a fixed two-level
+ * tree: the two-pass values of :550-563 to ~1e-14, a constant column's variance exactly 0 -- and one sweep writes the
+ * rows.  The count call (data == NULL) makes the first sweep and leaves its results in the context; the call with `data`
+ * starts from them when it is the NEXT call on this context with the same arguments and S has not been written in
+ * between (any other call on the context drops them, and the call with `data` then sweeps again itself). */
 int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,
                       double r, double T, int is_put, float* data, int64_t cap_rows, int64_t* n_rows,
                       double* stats16);

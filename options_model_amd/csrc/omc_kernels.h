@@ -168,6 +168,12 @@ struct MlpTrainPlan {
     // global minibatch k, which has min(batch, rows_global - k * batch) rows over all ranks -- scales by the GLOBAL
     // minibatch size, and the gradient sums (+ loss) of all ranks are added through `allreduce` before Adam, so every
     // rank applies the same update.  nrows = this rank's rows; batch = the GLOBAL minibatch size.
+    // EXPERIMENT (round 6; OMC_MLP_FUSED): the 16-row trainer applies Adam in the tile workgroups -- 1 = one launch per
+    // optimizer step, 2 = one launch per epoch; 0 = the product's two launches per step.  Needs a device workspace and a
+    // host image of mlp_fused_ws_bytes(steps of the call) bytes; only unsharded minibatches of <= kMlpFusedMaxTiles tiles.
+    int fused = 0;
+    void* fused_dev = nullptr;
+    void* fused_host = nullptr;
     const int64_t* step_off = nullptr;   // HOST, [steps + 1]; null: not sharded
     int64_t rows_global = 0;
     const uint32_t* drop_pos = nullptr;  // device [nrows]: position of row i inside its global minibatch (dropout key)
@@ -232,7 +238,7 @@ hipError_t ols7_pass2(hipStream_t st, const LsmProblem& p, const double* feat_me
 // pass 1 of the NN flow straight from the path matrix (omc_rows.hip): count -> scan -> statistics -> rows
 size_t nn_rows_scratch_bytes(int64_t M, int N);
 hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const int64_t** total_dev,
-                         bool with_stats = false, const double** stats_dev = nullptr);
+                         const double** stats_dev);
 hipError_t nn_rows_write(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const double* feat_mean,
                          const double* feat_std, double y_mean, double y_std, float* data, int64_t cap);
 // float64 means / population variances of the regression features and the target over n rows
@@ -264,6 +270,8 @@ hipError_t mlp_shard_gather(hipStream_t st, const float* data, const int64_t* se
                             int64_t* step_off);
 // one epoch: ceil(nrows / batch) optimizer steps (forward+backward kernel, reduce+Adam kernel)
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t);
+constexpr int kMlpFusedMaxTiles = 64;  // all workgroups of a fused launch must be resident together
+size_t mlp_fused_ws_bytes(int64_t nsteps);
 int64_t mlp_plan_kernel_batch(const MlpTrainPlan& t);  // the minibatch size that picks the kernel / sizes the partials
 
 // ---- omc_contnet.hip: the per-step ContNet(1 -> h -> h -> 1) regressor of the reference's v1 / v2 pricers

@@ -13,6 +13,7 @@
 // throughout, agreeing with the two-pass values to ~1e-15 relative.
 #include "omc_device.h"
 #include "omc_kernels.h"
+#include "omc_lsm_dev.h"  // itm_threshold: the float32 in-the-money test of the polynomial pass 1
 
 namespace omc {
 
@@ -40,28 +41,6 @@ __device__ __forceinline__ void load_chunk(const float* col, int64_t ld, int t0,
 {
 #pragma unroll
     for (int i = 0; i < kTChunk; ++i) sv[i] = t0 + i < t1 ? __builtin_nontemporal_load(col + (int64_t)(t0 + i) * ld) : 0.0f;
-}
-
-// cnt[(N-1-t) * ntiles + tile] = in-the-money paths of the tile at step t  (t = 1 .. N-1)
-__global__ __launch_bounds__(kBlock) void rows_count_kernel(RowsArgs a, int32_t* __restrict__ cnt)
-{
-    __shared__ int wsum[kTChunk][kBlock / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
-    const int64_t p = (int64_t)tile * kBlock + tid;
-    const bool live = p < a.M;
-    const float* col = a.S + (live ? p : 0);
-    const int t0 = 1 + blockIdx.y * kTChunk, t1 = min(t0 + kTChunk, a.N);
-    float sv[kTChunk];
-    load_chunk(col, a.ld, t0, t1, sv);
-#pragma unroll
-    for (int i = 0; i < kTChunk; ++i) {
-        const bool f = live && t0 + i < t1 && itm(sv[i], a.K, a.is_put);
-        const int wc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
-        if (lane == 0) wsum[i][wave] = wc;
-    }
-    __syncthreads();
-    if (tid < t1 - t0) cnt[(size_t)(a.N - 1 - (t0 + tid)) * a.ntiles + tile] = wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
 }
 
 // Exclusive prefix of counts, one workgroup of 1024 threads per SEGMENT: workgroup b scans cnt[b * seg .. b * seg + len)
@@ -215,12 +194,32 @@ __device__ __forceinline__ void trip_block_merge(Trip& t, double* lds)
     }
 }
 
-// ONE sweep: cnt[(N-1-t) * ntiles + tile] as rows_count_kernel, and the workgroup's (n, mean, M2) triple of the seven
-// quantities [x, x^2, x^3, max(x-1,0), s, x*s, y] over its in-the-money (step, path) pairs -> part[wg][kTrip]
+// ONE sweep: cnt[(N-1-t) * ntiles + tile] = in-the-money paths of the tile at step t (t = 1 .. N-1), and the workgroup's (n, mean, M2) triple of the seven
+// quantities [x, x^2, x^3, max(x-1,0), s, x*s, y] over its in-the-money (step, path) pairs -> part[wg][kTrip].
+//
+// Round 6: the sweep was float64-issue-bound at 0.15 of the HBM roofline (0.84 ms at config 5: per lane and step a
+// float64 division, a float64 square root, 21 operations of per-feature deviation sums behind a divergent branch, then
+// 8 levels of Chan merges per workgroup).  Now, branch-free, per lane and step:
+//   * in the money <=> a float32 compare against the threshold of the polynomial pass 1 (exactly payoff > 0 in float64),
+//     the count on the scalar unit (popcount of the compare mask);
+//   * sqrt(tau) and the discount factor of the step from a table in LDS (32 entries per workgroup);
+//   * POWER SUMS of u = x - c around a centre c that is uniform in the workgroup (the spot of its first path at its
+//     first step, over the strike) -- sum u .. u^6, and with e = s_t - s_t0 (uniform per step): sum e, e^2, u e, u^2 e,
+//     u e^2, u^2 e^2 --, raw sums of y and max(x-1, 0): 17 accumulators, 24 fused operations.  Centres shared by the
+//     workgroup let the lanes' sums be ADDED (three fixed-order block reductions) instead of merged; one thread turns
+//     the workgroup's sums into (n, mean, M2) of the seven quantities by the binomial expansions below.
+// A constant column still has variance exactly 0 where the reference's rule needs it (:562): max(x-1,0) of a put is a
+// sum of exact zeros; s on a one-step problem has e = 0 throughout; identical spots give u = 0 throughout.  Float64
+// throughout; deterministic (fixed summation trees); agrees with the two-pass statistics to ~1e-14 relative (the sums are
+// centred inside the workgroup's own data, so the expansions cancel at most a digit).
+constexpr int kNS = 17;  // n U1 U2 U3 U4 U5 U6 UE U2E UE2 U2E2 ME ME2 Y Y2 MX MX2
 __global__ __launch_bounds__(kBlock) void rows_count_stats_kernel(RowsArgs a, int32_t* __restrict__ cnt, double* __restrict__ part)
 {
     __shared__ int wsum[kTChunk][kBlock / 64];
-    __shared__ double lds[kBlock * kTrip];
+    __shared__ double red[kNQ * kRedStride];
+    __shared__ double tab[3][kTChunk];  // e_t = s_t - s_t0, g = discount, (spare)
+    __shared__ double tot[24];
+    __shared__ double centre[2];        // c (x of the first path at t0), s_t0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int64_t p = (int64_t)tile * kBlock + tid;
@@ -231,64 +230,111 @@ __global__ __launch_bounds__(kBlock) void rows_count_stats_kernel(RowsArgs a, in
     load_chunk(col, a.ld, t0, t1, sv);
     const double pn = payoff_d(col[(int64_t)a.N * a.ld], a.K, a.is_put);
     const double payN = pn > 0.0 ? pn : 0.0;
-    double c[7], sd[7], sq[7];
+    const double invK = 1.0 / a.K;
+    if (tid < kTChunk) {
+        const int t = min(t0 + tid, a.N - 1);
+        const double s0 = sqrt(fmax(a.T - (double)t0 * a.dt, 1e-6));
+        tab[0][tid] = sqrt(fmax(a.T - (double)t * a.dt, 1e-6)) - s0;
+        tab[1][tid] = a.D[a.N - t];
+        if (tid == 0) {
+            centre[0] = (double)sv[0] * invK;
+            centre[1] = s0;
+        }
+    }
+    __syncthreads();
+    const double c = centre[0];
+    const float thr = live ? itm_threshold(a.K, a.is_put) : (a.is_put ? -__builtin_inff() : __builtin_inff());
+    const bool is_put = a.is_put != 0;
+    double acc[kNS];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) c[q] = sd[q] = sq[q] = 0.0;
-    double n = 0.0;
+    for (int q = 0; q < kNS; ++q) acc[q] = 0.0;
 #pragma unroll 4
     for (int i = 0; i < kTChunk; ++i) {
-        const int t = t0 + i;
         const float s = sv[i];
-        const bool f = live && t < t1 && itm(s, a.K, a.is_put);
+        const bool f = (is_put ? s < thr : s > thr) && t0 + i < t1;
         const int wc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
         if (lane == 0) wsum[i][wave] = wc;
-        if (!f) continue;
-        double v[8];
-        row_values((double)s, payN, a.K, sqrt(fmax(a.T - (double)t * a.dt, 1e-6)), a.D[a.N - t], v);
-        if (n == 0.0) {
-#pragma unroll
-            for (int q = 0; q < 7; ++q) c[q] = v[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            const double d = v[q] - c[q];
-            sd[q] += d;
-            sq[q] = __builtin_fma(d, d, sq[q]);
-        }
-        n += 1.0;
+        const double m = f ? 1.0 : 0.0;          // (masking by multiplication: u m and y m are exact)
+        const double e = tab[0][i], g = tab[1][i];
+        const double x1 = fma((double)s, invK, -1.0);
+        const double u = fma((double)s, invK, -c) * m;
+        const double mx = fmax(x1, 0.0) * m;
+        const double y = payN * g * m;
+        const double u2 = u * u, u3 = u2 * u, ue = u * e, me = m * e;
+        acc[0] += m;
+        acc[1] += u;
+        acc[2] += u2;
+        acc[3] += u3;
+        acc[4] = fma(u2, u2, acc[4]);
+        acc[5] = fma(u3, u2, acc[5]);
+        acc[6] = fma(u3, u3, acc[6]);
+        acc[7] += ue;
+        acc[8] = fma(u2, e, acc[8]);
+        acc[9] = fma(ue, e, acc[9]);
+        acc[10] = fma(ue, ue, acc[10]);
+        acc[11] += me;
+        acc[12] = fma(me, e, acc[12]);
+        acc[13] += y;
+        acc[14] = fma(y, y, acc[14]);
+        acc[15] += mx;
+        acc[16] = fma(mx, mx, acc[16]);
     }
     __syncthreads();
     if (tid < t1 - t0) cnt[(size_t)(a.N - 1 - (t0 + tid)) * a.ntiles + tile] = wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
-    Trip tr;
-    tr.n = n;
-    const double inv = n > 0.0 ? 1.0 / n : 0.0;
+    // the workgroup's sums: three fixed-order reductions of eight quantities each
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double a8[kNQ];
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) a8[q] = 8 * r + q < kNS ? acc[8 * r + q] : 0.0;
+        const double sum = block_reduce8(a8, red);
+        if (tid < 64 && (tid & 7) == 0) tot[8 * r + (tid >> 3)] = sum;
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    double* o = part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kTrip;
+    const double n = tot[0];
+    if (!(n > 0.0)) {
+#pragma unroll
+        for (int q = 0; q < kTrip; ++q) o[q] = 0.0;
+        return;
+    }
+    const double U1 = tot[1], U2 = tot[2], U3 = tot[3], U4 = tot[4], U5 = tot[5], U6 = tot[6], UE = tot[7], U2E = tot[8],
+                 UE2 = tot[9], U2E2 = tot[10], ME = tot[11], ME2 = tot[12], Y = tot[13], Y2 = tot[14], MX = tot[15], MX2 = tot[16];
+    const double sc = centre[1], inv = 1.0 / n, c2 = c * c, c3 = c2 * c, c4 = c2 * c2;
+    double sd[7], sq[7], base[7];  // sum of deviations from `base`, sum of their squares
+    base[0] = c;       sd[0] = U1;                              sq[0] = U2;
+    base[1] = c2;      sd[1] = 2.0 * c * U1 + U2;               sq[1] = 4.0 * c2 * U2 + 4.0 * c * U3 + U4;
+    base[2] = c3;      sd[2] = 3.0 * c2 * U1 + 3.0 * c * U2 + U3;
+    sq[2] = 9.0 * c4 * U2 + 18.0 * c3 * U3 + 15.0 * c2 * U4 + 6.0 * c * U5 + U6;
+    base[3] = 0.0;     sd[3] = MX;                              sq[3] = MX2;
+    base[4] = sc;      sd[4] = ME;                              sq[4] = ME2;
+    base[5] = c * sc;  sd[5] = c * ME + sc * U1 + UE;
+    sq[5] = c2 * ME2 + sc * sc * U2 + U2E2 + 2.0 * c * sc * UE + 2.0 * c * UE2 + 2.0 * sc * U2E;
+    base[6] = 0.0;     sd[6] = Y;                               sq[6] = Y2;
+    o[0] = n;
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
-        tr.mean[q] = c[q] + sd[q] * inv;
+        o[1 + q] = base[q] + sd[q] * inv;
         const double m2 = sq[q] - sd[q] * sd[q] * inv;
-        tr.m2[q] = m2 > 0.0 ? m2 : 0.0;
+        o[8 + q] = m2 > 0.0 ? m2 : 0.0;
     }
-    trip_block_merge(tr, lds);
-    if (tid == 0) {
-        double* o = part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kTrip;
-        o[0] = tr.n;
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            o[1 + q] = tr.mean[q];
-            o[8 + q] = tr.m2[q];
-        }
-    }
+    o[15] = 0.0;
 }
 
-// part[0 .. nwg) -> out[kTrip]: thread i folds partials i, i + 256, ... in index order, then the same tree
-__global__ __launch_bounds__(kBlock) void rows_merge_kernel(const double* __restrict__ part, int nwg, double* __restrict__ out)
+// Workgroup b folds partials [b * per, min((b + 1) * per, nwg)) into out[b][kTrip]: thread i takes partials i, i + 256, ...
+// of the slice in index order, then the block tree.  Two levels (round 6): config 5's 31k workgroup partials through ONE
+// workgroup were 122 dependent Chan merges per thread (0.12 ms); slices of 256 -- one partial per thread -- then one
+// workgroup over the slice results.  The tree is fixed by (nwg, per): bitwise reproducible.
+__global__ __launch_bounds__(kBlock) void rows_merge_kernel(const double* __restrict__ part, int nwg, int per, double* __restrict__ out)
 {
     __shared__ double lds[kBlock * kTrip];
     Trip t;
     t.n = 0.0;
 #pragma unroll
     for (int q = 0; q < 7; ++q) t.mean[q] = t.m2[q] = 0.0;
-    for (int i = threadIdx.x; i < nwg; i += kBlock) {
+    const int lo = (int)blockIdx.x * per, hi = lo + per < nwg ? lo + per : nwg;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += kBlock) {
         const double* o = part + (size_t)i * kTrip;
         Trip b;
         b.n = o[0];
@@ -301,27 +347,31 @@ __global__ __launch_bounds__(kBlock) void rows_merge_kernel(const double* __rest
     }
     trip_block_merge(t, lds);
     if (threadIdx.x == 0) {
-        out[0] = t.n;
+        double* dst = out + (size_t)blockIdx.x * kTrip;
+        dst[0] = t.n;
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            out[1 + q] = t.mean[q];
-            out[8 + q] = t.m2[q];
+            dst[1 + q] = t.mean[q];
+            dst[8 + q] = t.m2[q];
         }
-        out[15] = 0.0;
+        dst[15] = 0.0;
     }
 }
 
 struct RowsNorm {
-    double fm[7], rs[7];  // feature means and reciprocal stds (feature 0 is the constant 1)
-    double ym, rys;
+    double rs[7], nb[7];  // (f - mean) / std as fma(f, rs, nb): rs = 1 / std, nb = -mean / std (feature 0 is the constant 1)
+    double rys, nby;
 };
 
 // rows in the reference's order: rowbase[N-1-t] (rows of the later steps) + offs[(N-1-t) * ntiles + tile] (rows of the
-// step's earlier tiles) + rank of the path among the tile's in-the-money paths at step t
+// step's earlier tiles) + rank of the path among the tile's in-the-money paths at step t.  Round 6: sqrt(tau) and the
+// discount factor of a step from a table in LDS (they were a float64 square root and a load per lane and step), x = S / K
+// as a multiplication by 1 / K, the in-the-money test as pass 1's float32 compare, (f - mean) / std as one fma.
 __global__ __launch_bounds__(kBlock) void rows_write_kernel(RowsArgs a, RowsNorm nm, const int64_t* __restrict__ offs,
                                                             const int64_t* __restrict__ rowbase, float* __restrict__ data, int64_t cap)
 {
     __shared__ int wsum[kTChunk][kBlock / 64];
+    __shared__ double tab[2][kTChunk];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int64_t p = (int64_t)tile * kBlock + tid;
@@ -332,18 +382,27 @@ __global__ __launch_bounds__(kBlock) void rows_write_kernel(RowsArgs a, RowsNorm
     load_chunk(col, a.ld, t0, t1, sv);
     const double pn = payoff_d(col[(int64_t)a.N * a.ld], a.K, a.is_put);
     const double payN = pn > 0.0 ? pn : 0.0;
+    const double invK = 1.0 / a.K;
+    const float thr = live ? itm_threshold(a.K, a.is_put) : (a.is_put ? -__builtin_inff() : __builtin_inff());
+    const bool is_put = a.is_put != 0;
+    if (tid < kTChunk) {
+        const int t = min(t0 + tid, a.N - 1);
+        tab[0][tid] = sqrt(fmax(a.T - (double)t * a.dt, 1e-6));
+        tab[1][tid] = a.D[a.N - t];
+    }
 #pragma unroll
     for (int i = 0; i < kTChunk; ++i) {
-        const bool f = live && t0 + i < t1 && itm(sv[i], a.K, a.is_put);
+        const bool f = (is_put ? sv[i] < thr : sv[i] > thr) && t0 + i < t1;
         const int wc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
         if (lane == 0) wsum[i][wave] = wc;
     }
     __syncthreads();
+    const float c0 = (float)fma(1.0, nm.rs[0], nm.nb[0]);
 #pragma unroll 4
     for (int i = 0; i < kTChunk; ++i) {
         const int t = t0 + i;
         const float s = sv[i];
-        const bool f = live && t < t1 && itm(s, a.K, a.is_put);
+        const bool f = (is_put ? s < thr : s > thr) && t < t1;
         const uint64_t b = __builtin_amdgcn_ballot_w64(f);
         if (!f) continue;
         int woff = 0;
@@ -352,17 +411,16 @@ __global__ __launch_bounds__(kBlock) void rows_write_kernel(RowsArgs a, RowsNorm
         const int r = a.N - 1 - t;
         const int64_t row = rowbase[r] + offs[(size_t)r * a.ntiles + tile] + rank;
         if (row >= cap) continue;
-        double v[8];
-        row_values((double)s, payN, a.K, sqrt(fmax(a.T - (double)t * a.dt, 1e-6)), a.D[a.N - t], v);
+        const double st = tab[0][i], x = (double)s * invK, x2 = x * x;
         float4 lo, hi;
-        lo.x = (float)((1.0 - nm.fm[0]) * nm.rs[0]);
-        lo.y = (float)((v[0] - nm.fm[1]) * nm.rs[1]);
-        lo.z = (float)((v[1] - nm.fm[2]) * nm.rs[2]);
-        lo.w = (float)((v[2] - nm.fm[3]) * nm.rs[3]);
-        hi.x = (float)((v[3] - nm.fm[4]) * nm.rs[4]);
-        hi.y = (float)((v[4] - nm.fm[5]) * nm.rs[5]);
-        hi.z = (float)((v[5] - nm.fm[6]) * nm.rs[6]);
-        hi.w = (float)((v[6] - nm.ym) * nm.rys);
+        lo.x = c0;
+        lo.y = (float)fma(x, nm.rs[1], nm.nb[1]);
+        lo.z = (float)fma(x2, nm.rs[2], nm.nb[2]);
+        lo.w = (float)fma(x2 * x, nm.rs[3], nm.nb[3]);
+        hi.x = (float)fma(fmax(x - 1.0, 0.0), nm.rs[4], nm.nb[4]);
+        hi.y = (float)fma(st, nm.rs[5], nm.nb[5]);
+        hi.z = (float)fma(x * st, nm.rs[6], nm.nb[6]);
+        hi.w = (float)fma(payN * tab[1][i], nm.rys, nm.nby);
         float4* dst = reinterpret_cast<float4*>(data + row * 8);
         dst[0] = lo;
         dst[1] = hi;
@@ -380,7 +438,7 @@ size_t nn_rows_scratch_bytes(int64_t M, int N)
 {
     const size_t n = (size_t)(N - 1 > 0 ? N - 1 : 0) * (size_t)((M + kBlock - 1) / kBlock);
     return sizeof(int64_t) * (n + 2 + 2 * ((size_t)N + 2)) + sizeof(int32_t) * (n + 2) +
-           sizeof(double) * (kTrip * (rows_nwg(M, N, kTChunk) + 2) + 32);
+           sizeof(double) * (kTrip * (rows_nwg(M, N, kTChunk) + rows_nwg(M, N, kTChunk) / kBlock + 4) + 32);
 }
 
 // scratch layout: offs int64[n+2] | rowtot int64[N+2] | rowbase int64[N+2] | cnt int32[n] | part double[nwg][kTrip] | out double[kTrip]
@@ -410,12 +468,12 @@ static RowsArgs make_args(const LsmProblem& p, const double* D)
     return a;
 }
 
-// counts + scan; *total_dev points at the device int64 holding R afterwards.  with_stats: the same sweep also forms the
-// statistics, *stats_dev then points at 16 device doubles: n, mean[7], M2[7] (sum of squared deviations) of
-// [x, x^2, x^3, max(x-1,0), s, x*s, y].
+// counts + scan + statistics, ONE sweep over S; *total_dev points at the device int64 holding R afterwards, *stats_dev at
+// 16 device doubles: n, mean[7], M2[7] (sum of squared deviations) of [x, x^2, x^3, max(x-1,0), s, x*s, y].
 hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, void* scratch, const int64_t** total_dev,
-                         bool with_stats, const double** stats_dev)
+                         const double** stats_dev)
 {
+    constexpr bool with_stats = true;
     const RowsArgs a = make_args(p, D);
     const size_t n = (size_t)(p.N - 1) * a.ntiles, nwg = rows_nwg(p.M, p.N, a.tchunk);
     int64_t *offs, *rowtot, *rowbase; int32_t* cnt; double *part, *out;
@@ -423,8 +481,7 @@ hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, v
     const int nrow = p.N - 1 > 0 ? p.N - 1 : 0;
     const dim3 grid(a.ntiles, (p.N - 1 + a.tchunk - 1) / a.tchunk);
     if (n > 0) {
-        if (with_stats) hipLaunchKernelGGL(rows_count_stats_kernel, grid, dim3(kBlock), 0, st, a, cnt, part);
-        else hipLaunchKernelGGL(rows_count_kernel, grid, dim3(kBlock), 0, st, a, cnt);
+        hipLaunchKernelGGL(rows_count_stats_kernel, grid, dim3(kBlock), 0, st, a, cnt, part);
         // two-level scan: every time step's tiles in their own workgroup, then the per-step totals
         hipLaunchKernelGGL(rows_scan_kernel<int32_t>, dim3((unsigned)nrow), dim3(1024), 0, st, (const int32_t*)cnt, (int64_t)n,
                            (int64_t)a.ntiles, offs, rowtot);
@@ -432,7 +489,15 @@ hipError_t nn_rows_count(hipStream_t st, const LsmProblem& p, const double* D, v
     hipLaunchKernelGGL(rows_scan_kernel<int64_t>, dim3(1), dim3(1024), 0, st, (const int64_t*)rowtot, (int64_t)nrow,
                        (int64_t)(nrow > 0 ? nrow : 1), rowbase, (int64_t*)nullptr);
     if (with_stats) {
-        hipLaunchKernelGGL(rows_merge_kernel, dim3(1), dim3(kBlock), 0, st, part, n > 0 ? (int)(grid.x * grid.y) : 0, out);
+        const int np = n > 0 ? (int)(grid.x * grid.y) : 0;
+        if (np > kBlock) {  // slices of 256 partials, then the slice results (behind `out` in the scratch)
+            const int slices = (np + kBlock - 1) / kBlock;
+            double* part2 = out + kTrip;
+            hipLaunchKernelGGL(rows_merge_kernel, dim3(slices), dim3(kBlock), 0, st, (const double*)part, np, kBlock, part2);
+            hipLaunchKernelGGL(rows_merge_kernel, dim3(1), dim3(kBlock), 0, st, (const double*)part2, slices, slices, out);
+        } else {
+            hipLaunchKernelGGL(rows_merge_kernel, dim3(1), dim3(kBlock), 0, st, (const double*)part, np, np > 0 ? np : 1, out);
+        }
         *stats_dev = out;
     }
     *total_dev = rowbase + nrow;
@@ -463,11 +528,11 @@ hipError_t nn_rows_write(hipStream_t st, const LsmProblem& p, const double* D, v
     carve(scratch, n, rows_nwg(p.M, p.N, a.tchunk), p.N, &offs, &rowtot, &rowbase, &cnt, &part, &out);
     RowsNorm nm;
     for (int i = 0; i < 7; ++i) {
-        nm.fm[i] = feat_mean[i];
         nm.rs[i] = 1.0 / feat_std[i];
+        nm.nb[i] = -feat_mean[i] * nm.rs[i];
     }
-    nm.ym = y_mean;
     nm.rys = 1.0 / y_std;
+    nm.nby = -y_mean * nm.rys;
     hipLaunchKernelGGL(rows_write_kernel, dim3(a.ntiles, (p.N - 1 + a.tchunk - 1) / a.tchunk), dim3(kBlock), 0, st, a,
                        nm, offs, rowbase, data, cap);
     return hipGetLastError();

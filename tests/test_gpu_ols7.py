@@ -251,8 +251,9 @@ def test_collective_calls_fail_on_every_rank_together():
             c.set_allreduce_hook(None)
             c.set_option("world_size", 1)
             c.set_option("alloc_limit", 32 << 20)
+            bigger = _ffi.make_params(semantics="two_pass", n_paths=900_000, n_steps=40, seed=3)  # (the 65.6 MB matrix exists by now)
             with pytest.raises(_ffi.OmcError, match="alloc_limit"):
-                c.price_american_ols7(big)  # one rank: no collective to enter, the error comes back directly
+                c.price_american_ols7(bigger)  # one rank: no collective to enter, the error comes back directly
             c.set_option("alloc_limit", 0)
             S.free()
     finally:

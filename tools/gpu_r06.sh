@@ -111,6 +111,13 @@ print('$CFG dup=$DUP rep $REP ms_per_step', round(d['ms_per_step'],4), 'pass1 ms
   for d in "$R"/gpurun_out/pmc_${TAG}_dup_c3_*; do [ -d "$d" ] && rm -rf "$d"; done
   true
   ;;
+fused)  # EXPERIMENT: the default call's optimizer step without its Adam launch (OMC_MLP_FUSED = 1 | 2) vs the product
+  for CASE in "225057 256 4 128 3 0.1" "225057 256 4 64 2 0.1" "5000 256 8 128 3 0.1" "225057 1024 4 128 3 0.1" "225057 256 4 128 3 0.0"; do
+    timeout -k 10 900 python tools/exp_fused_step.py $CASE 2>&1 | tee -a gpurun_out/${TAG}_fused_step_experiment.txt; rc=${PIPESTATUS[0]}
+    ok $rc || exit 1
+  done
+  true
+  ;;
 tests)
   timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
   tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
