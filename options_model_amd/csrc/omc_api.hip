@@ -155,8 +155,7 @@ struct omc_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_moments[2] = {nullptr, nullptr}, ev_reduced[2] = {nullptr, nullptr};
     RowsCache rows_cache;
-    DevBuf S2, seq_local, part1b, gmomb, seq_vote, mlp_fused;
-    std::vector<char> h_fused;
+    DevBuf S2, seq_local, part1b, gmomb, seq_vote;
     int seq_overlap = -1;  // -1: default (on when the communicator has more than one rank), 0 off, 1 on
     bool defer_result_allreduce = false;  // inside omc_price_american_seq: one collective for all result sums
     // captured per-step sweep (N launches + valuation + finalize), replayed for every pricing of the
@@ -579,7 +578,7 @@ int omc_ctx_destroy(omc_ctx* c)
     c->p2p = nullptr;
     for (DevBuf* b : {&c->S, &c->sx, &c->tex, &c->ex, &c->D, &c->part, &c->gmom, &c->betas, &c->part1,
                       &c->result, &c->scratch, &c->sweep_args, &c->bslab, &c->btable, &c->bres, &c->bdisc,
-                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->mlp_gred, &c->shard, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->seq_vote, &c->mlp_fused, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
+                      &c->mlp_part, &c->mlp_loss, &c->mlp_wt, &c->mlp_gred, &c->shard, &c->S2, &c->seq_local, &c->part1b, &c->gmomb, &c->seq_vote, &c->cn_scratch, &c->cn_data, &c->cn_net, &c->cn_cont,
                       &c->mS, &c->mstate, &c->mtable, &c->mb_slab, &c->mb_table, &c->mb_bc})
         b->release();
     if (c->sweep_pin) (void)hipHostFree(c->sweep_pin);
@@ -1775,14 +1774,15 @@ int omc_heston_price_strikes(omc_ctx* c, int64_t n_paths, int n_steps, double S0
     if (!strikes || !prices || n_strikes <= 0) return fail(-7, "bad strike arguments.");
     const size_t st_bytes = sizeof(float) * (size_t)n_paths;
     const size_t k_bytes = sizeof(double) * (size_t)n_strikes;
-    if ((rc = c->scratch.ensure(st_bytes + 256 + 3 * k_bytes))) return rc;
+    if ((rc = c->scratch.ensure(st_bytes + 256 + 3 * k_bytes + omc::payoff_partial_bytes(n_paths, n_strikes)))) return rc;
     float* ST = (float*)c->scratch.p;
     double* Kd = (double*)((char*)c->scratch.p + (st_bytes + 255) / 256 * 256);
     double* out = Kd + n_strikes;
+    double* part = out + 2 * (size_t)n_strikes;
     HIP_TRY(hipMemcpyAsync(Kd, strikes, k_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(omc::launch_heston_terminal_store(c->stream, ST, n_paths, n_steps, S0, r, T, v0, kappa, theta,
                                               xi, rho, seed, (uint32_t)stream, 0, scheme));
-    HIP_TRY(omc::launch_payoff_means(c->stream, ST, n_paths, Kd, n_strikes, is_put ? 1 : 0, out));
+    HIP_TRY(omc::launch_payoff_means(c->stream, ST, n_paths, Kd, n_strikes, is_put ? 1 : 0, part, out));
     std::vector<double> h(2 * (size_t)n_strikes);
     HIP_TRY(hipMemcpyAsync(h.data(), out, 2 * k_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1823,13 +1823,14 @@ int omc_heston_price_surface(omc_ctx* c, int64_t n_paths, int n_steps, double S0
     const size_t st_bytes = sizeof(float) * (size_t)ldst * (size_t)n_expiries;
     const size_t tab_bytes = (omc::heston_surface_table_bytes(n_expiries) + 255) / 256 * 256;
     const size_t k_bytes = sizeof(double) * (size_t)n_quotes, e_bytes = (sizeof(int32_t) * (size_t)n_quotes + 255) / 256 * 256;
-    if ((rc = c->scratch.ensure(st_bytes + 256 + tab_bytes + e_bytes + 3 * k_bytes))) return rc;
+    if ((rc = c->scratch.ensure(st_bytes + 256 + tab_bytes + e_bytes + 3 * k_bytes + omc::payoff_partial_bytes(n_paths, n_quotes)))) return rc;
     char* base = (char*)c->scratch.p;
     float* ST = (float*)base;
     void* tab = base + (st_bytes + 255) / 256 * 256;
     int32_t* eo = (int32_t*)((char*)tab + tab_bytes);
     double* Kd = (double*)((char*)eo + e_bytes);
     double* out = Kd + n_quotes;
+    double* part = out + 2 * (size_t)n_quotes;
     // host images that must outlive the asynchronous copies (pageable memory): the context keeps them until the wait below
     c->h_table.resize(tab_bytes + sizeof(uint32_t) * (size_t)n_expiries);
     uint32_t* st32 = (uint32_t*)(c->h_table.data() + tab_bytes);
@@ -1838,7 +1839,7 @@ int omc_heston_price_surface(omc_ctx* c, int64_t n_paths, int n_steps, double S0
     HIP_TRY(hipMemcpyAsync(eo, expiry_of, sizeof(int32_t) * (size_t)n_quotes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(omc::launch_heston_terminal_surface(c->stream, ST, ldst, n_paths, n_steps, S0, r, expiries, st32, n_expiries, v0,
                                                 kappa, theta, xi, rho, seed, 0, scheme, c->h_table.data(), tab));
-    HIP_TRY(omc::launch_payoff_means_surface(c->stream, ST, ldst, n_paths, Kd, eo, n_quotes, is_put ? 1 : 0, out));
+    HIP_TRY(omc::launch_payoff_means_surface(c->stream, ST, ldst, n_paths, Kd, eo, n_quotes, is_put ? 1 : 0, part, out));
     std::vector<double> h(2 * (size_t)n_quotes);
     HIP_TRY(hipMemcpyAsync(h.data(), out, 2 * k_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2569,22 +2570,10 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
     t.dropout = dropout; t.seed = seed; t.shuffle_key = shuffle_key;
     t.allow_q16 = true;
     const int64_t nb = (n_rows + batch - 1) / batch;
-    // EXPERIMENT (profiles/r06_fused_step_experiment.txt): OMC_MLP_FUSED = 1 | 2 routes the 16-row trainer through the
-    // launch that applies Adam itself (omc_mlp.hip, mlp_train_q16_fused_kernel); default 0 = two launches per step
-    static const int fused_env = getenv("OMC_MLP_FUSED") ? atoi(getenv("OMC_MLP_FUSED")) : 0;
-    if (fused_env == 1 || fused_env == 2) {
-        const size_t ws = omc::mlp_fused_ws_bytes(nb);
-        if ((rc = c->mlp_fused.ensure(ws))) return rc;
-        c->h_fused.resize(ws);
-        t.fused = fused_env; t.fused_dev = c->mlp_fused.p; t.fused_host = c->h_fused.data();
-    }
     HIP_TRY(omc::mlp_train_steps(c->stream, t));
     double acc = 0.0;
-    uint32_t tmo = 0;
     HIP_TRY(hipMemcpyAsync(&acc, c->mlp_loss.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (t.fused) HIP_TRY(hipMemcpyAsync(&tmo, (uint32_t*)c->mlp_fused.p + 32, sizeof tmo, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (tmo) return fail(3200, "fused optimizer step (OMC_MLP_FUSED): a workgroup waited for its peers for too long.");
     *step += nb;
     *mean_loss = acc / (double)nb;
     return 0;

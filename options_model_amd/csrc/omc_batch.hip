@@ -327,7 +327,7 @@ void batch_build(const BatchItem* items, int n, bool american, bool two_pass, ch
         s.t = 0; s.nblk = L.nblk_sweep; s.external = 0; s.pstride = L.pstride; s.gstride = 8; s.cont = nullptr; s.ldc = 0;
         Pass1Args& a1 = p.p1;
         a1.S = s.S; a1.ld = L.ld; a1.M = M; a1.N = N; a1.is_put = it.is_put; a1.K = it.K; a1.invK = s.invK;
-        a1.D = D; a1.part1 = two_pass ? (double*)(slab + L.part1) : nullptr; a1.ntiles = L.ntiles; a1.tchunk = 16; a1.dup_mode = 0;
+        a1.D = D; a1.part1 = two_pass ? (double*)(slab + L.part1) : nullptr; a1.ntiles = L.ntiles; a1.tchunk = 16;
         Pass2Args& a2 = p.p2;
         a2.S = s.S; a2.ld = L.ld; a2.M = M; a2.N = N; a2.is_put = it.is_put; a2.K = it.K; a2.invK = s.invK;
         a2.D = D; a2.betas = s.betas; a2.sx = s.sx; a2.tex = s.tex; a2.part = part;

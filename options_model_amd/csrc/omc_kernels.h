@@ -43,9 +43,10 @@ hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_pat
                                         double S0, double r, double T, double v0, double kappa,
                                         double theta, double xi, double rho, uint64_t seed,
                                         uint32_t stream, uint64_t pair_offset, int scheme);
-// out_dev [n_strikes][2] = {sum, sumsq} of max(+-(S_T - K), 0)
+// out_dev [n_strikes][2] = {sum, sumsq} of max(+-(S_T - K), 0); part_dev: payoff_partial_bytes(n_paths, n_strikes) of scratch
+size_t payoff_partial_bytes(int64_t n_paths, int n_quotes);
 hipError_t launch_payoff_means(hipStream_t st, const float* ST, int64_t n_paths, const double* K_dev,
-                               int n_strikes, int is_put, double* out_dev);
+                               int n_strikes, int is_put, double* part_dev, double* out_dev);
 // a whole quote surface: the expiry on grid.y (its constants and Philox sub-stream from a 64-byte-per-expiry table that
 // the launcher fills in `tab_host` and copies to `tab_dev`), ST device [n_expiries][ldst]; then one workgroup per quote
 size_t heston_surface_table_bytes(int n_expiries);
@@ -54,7 +55,7 @@ hipError_t launch_heston_terminal_surface(hipStream_t st, float* ST, int64_t lds
                                           double v0, double kappa, double theta, double xi, double rho, uint64_t seed,
                                           uint64_t pair_offset, int scheme, void* tab_host, void* tab_dev);
 hipError_t launch_payoff_means_surface(hipStream_t st, const float* ST, int64_t ldst, int64_t n_paths, const double* K_dev,
-                                       const int32_t* expiry_of_dev, int n_quotes, int is_put, double* out_dev);
+                                       const int32_t* expiry_of_dev, int n_quotes, int is_put, double* part_dev, double* out_dev);
 hipError_t launch_philox_kat(hipStream_t st, const uint32_t* in, uint32_t* out, int n);
 hipError_t launch_gbm_normals(hipStream_t st, float* Z, int64_t ldz, int64_t n_pairs, int n_steps,
                               uint64_t seed, uint32_t stream, uint64_t pair_offset);
@@ -168,12 +169,6 @@ struct MlpTrainPlan {
     // global minibatch k, which has min(batch, rows_global - k * batch) rows over all ranks -- scales by the GLOBAL
     // minibatch size, and the gradient sums (+ loss) of all ranks are added through `allreduce` before Adam, so every
     // rank applies the same update.  nrows = this rank's rows; batch = the GLOBAL minibatch size.
-    // EXPERIMENT (round 6; OMC_MLP_FUSED): the 16-row trainer applies Adam in the tile workgroups -- 1 = one launch per
-    // optimizer step, 2 = one launch per epoch; 0 = the product's two launches per step.  Needs a device workspace and a
-    // host image of mlp_fused_ws_bytes(steps of the call) bytes; only unsharded minibatches of <= kMlpFusedMaxTiles tiles.
-    int fused = 0;
-    void* fused_dev = nullptr;
-    void* fused_host = nullptr;
     const int64_t* step_off = nullptr;   // HOST, [steps + 1]; null: not sharded
     int64_t rows_global = 0;
     const uint32_t* drop_pos = nullptr;  // device [nrows]: position of row i inside its global minibatch (dropout key)
@@ -270,8 +265,6 @@ hipError_t mlp_shard_gather(hipStream_t st, const float* data, const int64_t* se
                             int64_t* step_off);
 // one epoch: ceil(nrows / batch) optimizer steps (forward+backward kernel, reduce+Adam kernel)
 hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t);
-constexpr int kMlpFusedMaxTiles = 64;  // all workgroups of a fused launch must be resident together
-size_t mlp_fused_ws_bytes(int64_t nsteps);
 int64_t mlp_plan_kernel_batch(const MlpTrainPlan& t);  // the minibatch size that picks the kernel / sizes the partials
 
 // ---- omc_contnet.hip: the per-step ContNet(1 -> h -> h -> 1) regressor of the reference's v1 / v2 pricers

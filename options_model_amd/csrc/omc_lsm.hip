@@ -341,8 +341,6 @@ hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorks
         if (t <= 126 && t >= 32) tchunk = t;
     }
     a.tchunk = (tch_env >= 2 && tch_env <= kPass1MaxChunk) ? tch_env : tchunk;
-    static const int dup_env = getenv("OMC_PASS1_DUP") ? atoi(getenv("OMC_PASS1_DUP")) : 0;
-    a.dup_mode = dup_env;
     const dim3 grid((unsigned)((a.ntiles + 3) / 4), (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
     auto launch = [&](auto vec, auto tp) {

@@ -417,7 +417,6 @@ struct Pass1Args {
     double* part1;
     int64_t ntiles;
     int tchunk;
-    int dup_mode;  // where a chunk's last two (unused) prefetches point: 0 = the chunk's last row, 1 = the row being processed
 };
 
 // Pass 1 (options_model_3.py:482-516): no decisions, so every time step is independent.
@@ -551,21 +550,19 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
     // sched_barrier: hipcc otherwise sinks the prefetch loads below the arithmetic they are
     // meant to overlap (seen in the ISA as vmcnt(0) right before the late-issued loads)
     auto sweep = [&](auto put_tag) {
-        const bool dup_cur = a.dup_mode == 1;
-        auto ahead = [&](int want, int cur) { return want <= tl ? want : (dup_cur ? cur : tl); };  // (scalar: wave-uniform)
         load_rows(bufA, t0);
         load_rows(bufB, min(t0 + 1, tl));
         for (int t = t0; t < t1; t += 3) {
-            load_rows(bufC, ahead(t + 2, t));
+            load_rows(bufC, min(t + 2, tl));
             __builtin_amdgcn_sched_barrier(0);
             process(put_tag, bufA, t);
             if (t + 1 < t1) {
-                load_rows(bufA, ahead(t + 3, t + 1));
+                load_rows(bufA, min(t + 3, tl));
                 __builtin_amdgcn_sched_barrier(0);
                 process(put_tag, bufB, t + 1);
             }
             if (t + 2 < t1) {
-                load_rows(bufB, ahead(t + 4, t + 2));
+                load_rows(bufB, min(t + 4, tl));
                 __builtin_amdgcn_sched_barrier(0);
                 process(put_tag, bufC, t + 2);
             }

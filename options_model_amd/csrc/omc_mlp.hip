@@ -1402,17 +1402,14 @@ __device__ __forceinline__ void relu_dropout_q16(v4f16 (&z)[2], uint32_t row, ui
 }
 
 template <int H, int L>
-__device__ __forceinline__ void mlp_train_q16_body(const MlpQuadArgs& a, const int tile, const int tid_in = -1)
+__device__ __forceinline__ void mlp_train_q16_body(const MlpQuadArgs& a, const int tile)
 {
     constexpr int W = H / 32, NP = mlp_params_of(H, L), CONN = H * H + H, NQ = H / 16, KS = H / 4;
     __shared__ __attribute__((aligned(16))) float sAct[L][H * 16];  // H_j, [k / 4][16 rows][k % 4]
     __shared__ __attribute__((aligned(16))) float sDz[H * 16];      // dZ_j of the layer being back-propagated, same order
     __shared__ float sX[8 * 16];                                    // inputs [in][row] (row 7 = the bias column of ones)
     __shared__ float sO[W * 16];                                    // per-wave partial outputs
-    // (tid_in: the fused-step experiment hands in an opaque copy of threadIdx.x per optimizer step, so that the per-lane
-    // addresses below are recomputed inside its step loop instead of being hoisted out of it -- and held in registers
-    // across the whole tile, which pushed that kernel into spills)
-    const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
     if (tile >= a.ntiles) return;
     float* out = a.partial + (size_t)tile * a.pstride;
     const float* Wo = a.params + H * 8 + (L - 1) * CONN;
@@ -1663,162 +1660,6 @@ template <int H, int L>
 __global__ __launch_bounds__(H * 2) void mlp_train_q16_kernel(MlpQuadArgs a)
 {
     mlp_train_q16_body<H, L>(a, blockIdx.x);
-}
-
-// ---- EXPERIMENT (round 6, OMC_MLP_FUSED = 1 | 2; off by default): the optimizer step without its Adam launch ----------------
-// The default call's step is two dependent launches: the tile kernel (16 workgroups at a minibatch of 256) and the Adam
-// kernel over all parameters.  Here the tile workgroups apply Adam THEMSELVES: after its tile a workgroup publishes its
-// partial (plain stores, every wave drains, one agent-scope release), waits until all tiles of the step have arrived (one
-// counter, relaxed polls, one agent-scope acquire), then updates ITS slice of the parameters -- 1 / workgroups of them: a
-// reduce-scatter through L2 -- summing the partials in mlp_adam_body's order, so every parameter keeps its bits.
-//   variant 1 ("a"): ONE launch per optimizer step (the launch boundary hands the new parameters to the next step);
-//   variant 2 ("b"): ONE launch per epoch: a second barrier per step (every workgroup's slice written and released, every
-//                    workgroup acquires) replaces the boundary.
-// All workgroups of a launch must be resident together (the host only takes this path for <= 64 tiles); every spin is
-// bounded (a timeout word ends all spins and fails the call).  Measured against the two-launch step in
-// profiles/r06_fused_step_experiment.txt; kept out of the default path unless it wins there.
-struct MlpFusedStep {
-    int64_t row0, nrows;
-    int ntiles;
-    uint32_t step;
-    float two_over_b, inv_b, lr_t, inv_sqrt_bc2;
-    uint32_t arrive;  // tile workgroups that have published once this step's tiles are in (cumulative over the call)
-    uint32_t pad;
-};
-static_assert(sizeof(MlpFusedStep) == 48, "mlp_fused_ws_bytes");
-constexpr int kFusedCtrWords = 64;  // [0] tiles published, [16] Adam phases finished (x workgroups), [32] timeout
-
-struct MlpFusedArgs {
-    MlpQuadArgs q;  // row0 / nrows / ntiles / two_over_b / step / drop_pos are per step (filled in the kernel)
-    float* params_w;
-    float* m;
-    float* v;
-    float* wt_w;
-    double* loss_acc;
-    float beta1, beta2, eps, wd;
-    const MlpFusedStep* steps;
-    uint32_t* ctr;
-};
-
-__device__ __forceinline__ bool fused_wait(uint32_t* word, uint32_t target, uint32_t* tmo)
-{
-    for (uint32_t spins = 0;; ++spins) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        if ((spins & 63u) == 63u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-        if (spins > (1u << 21)) {  // ~ a second: a workgroup that never arrives must not hang the device
-            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-// what this workgroup stored is visible to the other workgroups of the launch once `word` has been raised; what they
-// stored before raising it is visible here afterwards (cdna_hip_programming.md, Guideline 16: release, drained; one relaxed
-// poll; one agent-scope acquire; barrier)
-__device__ __forceinline__ void fused_barrier(uint32_t* word, uint32_t target, bool arrives, uint32_t* tmo)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (arrives) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)fused_wait(word, target, tmo);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    __builtin_amdgcn_s_dcache_inv();  // (no handed-off byte may come from the scalar cache)
-}
-
-// (the argument block lives in device memory, behind the step table: as kernel arguments its ~50 scalars stay live across
-// the tile body and push the register allocator into spills)
-template <int H, int L>
-__global__ __launch_bounds__(H * 2) void mlp_train_q16_fused_kernel(const MlpFusedArgs* __restrict__ fp, int s_begin, int s_end)
-{
-    constexpr int NP = mlp_params_of(H, L), NS = (NP + 1 + 3) & ~3;  // slots incl. the loss, in groups of four
-    const int tid = threadIdx.x, nwg = (int)gridDim.x;
-    for (int s = s_begin; s < s_end; ++s) {
-        const MlpFusedArgs& f = *fp;
-        const MlpFusedStep st = f.steps[s];
-        uint32_t* tmo = f.ctr + 32;
-        const int chunk = ((NS + nwg - 1) / nwg + 3) & ~3;
-        const int lo = (int)blockIdx.x * chunk, hi = lo + chunk < NS ? lo + chunk : NS;
-        MlpQuadArgs a = f.q;
-        a.row0 = st.row0;
-        a.nrows = st.nrows;
-        a.ntiles = st.ntiles;
-        a.two_over_b = st.two_over_b;
-        a.step = st.step;
-        a.drop_pos = f.q.drop_pos ? f.q.drop_pos + st.row0 : nullptr;
-        int tid_step = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid_step));  // opaque per step: nothing derived from it is loop-invariant
-        mlp_train_q16_body<H, L>(a, blockIdx.x, tid_step);
-        fused_barrier(f.ctr, st.arrive, (int)blockIdx.x < st.ntiles, tmo);
-        // ---- Adam on this workgroup's slots [lo, hi): g = sum over s0 = 0 .. 15 of (sum of partials s0, s0 + 16, ...) -- the
-        // order of mlp_adam_body / mlp_adam_body_flat
-        for (int base = lo + 4 * tid; base < hi; base += 4 * (H * 2)) {
-            float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (st.ntiles <= 16) {
-                float4 pv[16];
-#pragma unroll
-                for (int w = 0; w < 16; ++w)
-                    pv[w] = w < st.ntiles ? *reinterpret_cast<const float4*>(a.partial + (size_t)w * a.pstride + base)
-                                          : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-                for (int w = 0; w < 16; ++w) {
-                    if (w < st.ntiles) {  // gs = 0 + partial[w]; g += gs
-                        g[0] += 0.0f + pv[w].x;
-                        g[1] += 0.0f + pv[w].y;
-                        g[2] += 0.0f + pv[w].z;
-                        g[3] += 0.0f + pv[w].w;
-                    } else {  // an empty slice adds its 0
-                        g[0] += 0.0f; g[1] += 0.0f; g[2] += 0.0f; g[3] += 0.0f;
-                    }
-                }
-            } else {
-#pragma unroll 1
-                for (int s0 = 0; s0 < 16; ++s0) {
-                    float gs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    for (int w = s0; w < st.ntiles; w += 16) {
-                        const float4 x = *reinterpret_cast<const float4*>(a.partial + (size_t)w * a.pstride + base);
-                        gs[0] += x.x; gs[1] += x.y; gs[2] += x.z; gs[3] += x.w;
-                    }
-                    g[0] += gs[0]; g[1] += gs[1]; g[2] += gs[2]; g[3] += gs[3];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int p = base + e;
-                if (p > NP) continue;
-                float gg = g[e];
-                if (p == NP) {  // the loss slot
-                    *f.loss_acc += (double)gg * (double)st.inv_b;
-                    continue;
-                }
-                const float w0 = f.params_w[p];
-                gg = __builtin_fmaf(f.wd, w0, gg);
-                const float m = __builtin_fmaf(f.beta1, f.m[p], (1.0f - f.beta1) * gg);
-                const float v = __builtin_fmaf(f.beta2, f.v[p], (1.0f - f.beta2) * gg * gg);
-                f.m[p] = m;
-                f.v[p] = v;
-                const float denom = __builtin_amdgcn_sqrtf(v) * st.inv_sqrt_bc2 + f.eps;
-                const float w1 = w0 - st.lr_t * (m / denom);
-                f.params_w[p] = w1;
-                const int conn = H * H + H, q = p - H * 8;
-                if (q >= 0 && q < (L - 1) * conn) {
-                    const int jc = q / conn, rem = q - jc * conn;
-                    if (rem < H * H) {
-                        const int i = rem / H, k = rem - i * H;
-                        f.wt_w[(size_t)jc * H * H + (size_t)k * H + i] = w1;
-                    }
-                }
-            }
-        }
-        if (s + 1 < s_end)  // the next step of THIS launch reads every workgroup's slice
-            fused_barrier(f.ctr + 16, (uint32_t)nwg * (uint32_t)(s - s_begin + 1), true, tmo);
-    }
 }
 
 // ---- many small networks trained side by side (the curve entry points: one net per curve point) ----------------
@@ -2798,80 +2639,12 @@ static hipError_t tile_steps(hipStream_t st, const MlpTrainPlan& t)
     return hipGetLastError();
 }
 
-// EXPERIMENT (MlpTrainPlan::fused): the 16-row trainer with Adam applied by the tile workgroups themselves -- one launch
-// per step (1) or per epoch (2); the step table and the counters live in t.fused_dev (mlp_fused_ws_bytes)
-size_t mlp_fused_ws_bytes(int64_t nsteps)
-{
-    return sizeof(uint32_t) * kFusedCtrWords + (sizeof(MlpFusedArgs) + 15) / 16 * 16 + sizeof(MlpFusedStep) * (size_t)(nsteps > 0 ? nsteps : 0);
-}
-
-template <int H, int L>
-static hipError_t fused_steps(hipStream_t st, const MlpTrainPlan& t)
-{
-    if (!t.wt_current) hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
-    const int64_t nsteps = plan_steps(t);
-    constexpr size_t kArgBytes = (sizeof(MlpFusedArgs) + 15) / 16 * 16;
-    uint32_t* ctr_h = (uint32_t*)t.fused_host;
-    MlpFusedArgs* args_h = (MlpFusedArgs*)(ctr_h + kFusedCtrWords);
-    MlpFusedStep* tab_h = (MlpFusedStep*)((char*)args_h + kArgBytes);
-    memset(ctr_h, 0, sizeof(uint32_t) * kFusedCtrWords);
-    int64_t step = t.first_step;
-    uint32_t arrive = 0;
-    int tiles_max = 0;
-    for (int64_t k = 0; k < nsteps; ++k) {
-        const StepSpan sp = plan_span(t, k);
-        ++step;
-        MlpFusedStep& r = tab_h[k];
-        r.row0 = sp.row0;
-        r.nrows = sp.local;
-        r.ntiles = (int)((sp.local + 15) / 16);
-        r.step = (uint32_t)step;
-        r.two_over_b = (float)(2.0 / (double)sp.global);
-        r.inv_b = (float)(1.0 / (double)sp.global);
-        const double bc1 = 1.0 - pow(t.beta1, (double)step), bc2 = 1.0 - pow(t.beta2, (double)step);
-        r.lr_t = (float)(t.lr / bc1);
-        r.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-        arrive += (uint32_t)r.ntiles;
-        r.arrive = arrive;
-        r.pad = 0;
-        tiles_max = r.ntiles > tiles_max ? r.ntiles : tiles_max;
-    }
-    MlpFusedArgs& f = *args_h;
-    f = MlpFusedArgs{};
-    f.q.data = t.data; f.q.params = t.params; f.q.wt = t.wt; f.q.partial = t.partial;
-    f.q.row0 = 0; f.q.nrows = 0; f.q.shuf = plan_shuffle(t); f.q.ntiles = 0; f.q.pstride = tile_pstride(H, L);
-    f.q.two_over_b = 0.0f;
-    f.q.keep16 = t.dropout > 0.0 ? (uint32_t)llround((1.0 - t.dropout) * 65536.0) : 65536u;
-    f.q.inv_keep = f.q.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)f.q.keep16);
-    f.q.step = 0; f.q.k0 = (uint32_t)t.seed; f.q.k1 = (uint32_t)(t.seed >> 32);
-    f.q.drop_pos = t.drop_pos;
-    f.params_w = t.params; f.m = t.adam_m; f.v = t.adam_v; f.wt_w = t.wt; f.loss_acc = t.loss_acc;
-    f.beta1 = (float)t.beta1; f.beta2 = (float)t.beta2; f.eps = (float)t.eps; f.wd = (float)t.weight_decay;
-    f.ctr = (uint32_t*)t.fused_dev;
-    const MlpFusedArgs* args_d = (const MlpFusedArgs*)(f.ctr + kFusedCtrWords);
-    f.steps = (const MlpFusedStep*)((const char*)args_d + kArgBytes);
-    hipError_t e = hipMemcpyAsync(t.fused_dev, t.fused_host, mlp_fused_ws_bytes(nsteps), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return e;
-    if (t.fused == 2) {
-        hipLaunchKernelGGL((mlp_train_q16_fused_kernel<H, L>), dim3(tiles_max), dim3(H * 2), 0, st, args_d, 0, (int)nsteps);
-    } else {
-        for (int64_t k = 0; k < nsteps; ++k)
-            hipLaunchKernelGGL((mlp_train_q16_fused_kernel<H, L>), dim3(tab_h[k].ntiles), dim3(H * 2), 0, st, args_d, (int)k, (int)k + 1);
-    }
-    return hipGetLastError();
-}
-
 // minibatches of at most kMlpMaxGroups tiles: one workgroup per tile (mlp_train_quad_kernel: 32-row tiles;
 // mlp_train_q16_kernel: 16-row tiles)
 template <int H, int L, bool Q16 = false>
 static hipError_t quad_steps(hipStream_t st, const MlpTrainPlan& t)
 {
     constexpr int kTileRows = Q16 ? 16 : 32;
-    if constexpr (Q16) {
-        if (t.fused && t.fused_dev && t.fused_host && !t.step_off &&
-            ((t.batch < t.nrows ? t.batch : t.nrows) + 15) / 16 <= kMlpFusedMaxTiles)
-            return fused_steps<H, L>(st, t);
-    }
     if (!t.wt_current) hipLaunchKernelGGL(mlp_transpose_kernel, dim3(64), dim3(256), 0, st, t.params, t.wt, H, L);
     const Shuffle sh = plan_shuffle(t);
     int64_t step = t.first_step;

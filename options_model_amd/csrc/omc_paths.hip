@@ -278,18 +278,32 @@ __global__ __launch_bounds__(kBlock) void heston_terminal_surface_kernel(float* 
     row[p + g.P] = sa;
 }
 
-// {sum, sumsq} of one strike's payoffs over one row of terminal spots: thread j adds spots j, j + 256, ... in order, then
-// the workgroup tree -- the summation order of a quote is fixed by (M, block size) alone
-__device__ __forceinline__ void payoff_means_body(const float* __restrict__ ST, int64_t M, double k, int is_put,
+// {sum, sumsq} of one strike's payoffs over one row of terminal spots, in two levels (round 6: one workgroup per strike
+// walking all 100,000 spots was 105 us of dependent loads and float64 adds on ten CUs -- four fifths of a calibrator
+// evaluation): workgroup (chunk, quote) sums kPayChunk spots -- thread j adds spots j, j + 256, ... of the chunk in order,
+// then the workgroup tree --, then one thread per quote adds the chunks' sums in chunk order.  The summation order of a
+// quote is fixed by (M, kPayChunk, block size) alone: the single-expiry call and the surface call share it bit for bit.
+constexpr int kPayChunk = 4096;
+
+__device__ __forceinline__ void payoff_chunk_body(const float* __restrict__ ST, int64_t M, double k, int is_put,
                                                   double* __restrict__ out2)
 {
     __shared__ double red[kNQ * kRedStride];
     double acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-    for (int64_t j = threadIdx.x; j < M; j += kBlock) {
-        double p = payoff_d(ST[j], k, is_put);
-        p = p > 0.0 ? p : 0.0;
+    const int64_t lo = (int64_t)blockIdx.x * kPayChunk, hi = lo + kPayChunk < M ? lo + kPayChunk : M;
+    float sv[kPayChunk / kBlock];
+#pragma unroll
+    for (int i = 0; i < kPayChunk / kBlock; ++i) {  // every load of the chunk in flight before the first use
+        const int64_t j = lo + threadIdx.x + (int64_t)i * kBlock;
+        sv[i] = j < hi ? ST[j] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < kPayChunk / kBlock; ++i) {
+        const int64_t j = lo + threadIdx.x + (int64_t)i * kBlock;
+        double p = payoff_d(sv[i], k, is_put);
+        p = (j < hi && p > 0.0) ? p : 0.0;
         acc[0] += p;
         acc[1] += p * p;
     }
@@ -297,19 +311,33 @@ __device__ __forceinline__ void payoff_means_body(const float* __restrict__ ST, 
     if (threadIdx.x < 64 && (threadIdx.x & 7) == 0 && (threadIdx.x >> 3) < 2) out2[threadIdx.x >> 3] = s;
 }
 
-__global__ __launch_bounds__(kBlock) void payoff_means_kernel(const float* __restrict__ ST, int64_t M,
-                                                              const double* __restrict__ K, int is_put,
-                                                              double* __restrict__ out)
+// part[quote][chunk][2]
+__global__ __launch_bounds__(kBlock) void payoff_partial_kernel(const float* __restrict__ ST, int64_t M,
+                                                                const double* __restrict__ K, int is_put,
+                                                                double* __restrict__ part)
 {
-    payoff_means_body(ST, M, K[blockIdx.x], is_put, out + 2 * (size_t)blockIdx.x);
+    payoff_chunk_body(ST, M, K[blockIdx.y], is_put, part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
 
-__global__ __launch_bounds__(kBlock) void payoff_means_surface_kernel(const float* __restrict__ ST, int64_t ldst, int64_t M,
-                                                                      const double* __restrict__ K,
-                                                                      const int32_t* __restrict__ expiry_of, int is_put,
-                                                                      double* __restrict__ out)
+__global__ __launch_bounds__(kBlock) void payoff_partial_surface_kernel(const float* __restrict__ ST, int64_t ldst, int64_t M,
+                                                                        const double* __restrict__ K,
+                                                                        const int32_t* __restrict__ expiry_of, int is_put,
+                                                                        double* __restrict__ part)
 {
-    payoff_means_body(ST + (int64_t)expiry_of[blockIdx.x] * ldst, M, K[blockIdx.x], is_put, out + 2 * (size_t)blockIdx.x);
+    payoff_chunk_body(ST + (int64_t)expiry_of[blockIdx.y] * ldst, M, K[blockIdx.y], is_put,
+                      part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+}
+
+// out[quote][2] = the chunks' sums added in chunk order
+__global__ __launch_bounds__(kBlock) void payoff_final_kernel(const double* __restrict__ part, int nchunks, int n_quotes,
+                                                              double* __restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;  // (quote, component)
+    if (i >= 2 * n_quotes) return;
+    const double* p = part + (size_t)(i >> 1) * nchunks * 2 + (i & 1);
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += p[2 * c];
+    out[i] = s;
 }
 
 hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_paths, int n_steps,
@@ -356,21 +384,32 @@ hipError_t launch_heston_terminal_surface(hipStream_t st, float* ST, int64_t lds
     return hipGetLastError();
 }
 
+size_t payoff_partial_bytes(int64_t n_paths, int n_quotes)
+{
+    const int64_t nchunks = (n_paths + kPayChunk - 1) / kPayChunk;
+    return sizeof(double) * 2 * (size_t)(nchunks > 0 ? nchunks : 1) * (size_t)(n_quotes > 0 ? n_quotes : 0);
+}
+
 hipError_t launch_payoff_means_surface(hipStream_t st, const float* ST, int64_t ldst, int64_t n_paths, const double* K_dev,
-                                       const int32_t* expiry_of_dev, int n_quotes, int is_put, double* out_dev)
+                                       const int32_t* expiry_of_dev, int n_quotes, int is_put, double* part_dev, double* out_dev)
 {
     if (n_quotes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(payoff_means_surface_kernel, dim3(n_quotes), dim3(kBlock), 0, st, ST, ldst, n_paths, K_dev, expiry_of_dev,
-                       is_put, out_dev);
+    const int nchunks = (int)((n_paths + kPayChunk - 1) / kPayChunk);
+    hipLaunchKernelGGL(payoff_partial_surface_kernel, dim3(nchunks, n_quotes), dim3(kBlock), 0, st, ST, ldst, n_paths, K_dev,
+                       expiry_of_dev, is_put, part_dev);
+    hipLaunchKernelGGL(payoff_final_kernel, dim3((2 * n_quotes + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                       (const double*)part_dev, nchunks, n_quotes, out_dev);
     return hipGetLastError();
 }
 
 hipError_t launch_payoff_means(hipStream_t st, const float* ST, int64_t n_paths, const double* K_dev,
-                               int n_strikes, int is_put, double* out_dev)
+                               int n_strikes, int is_put, double* part_dev, double* out_dev)
 {
     if (n_strikes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(payoff_means_kernel, dim3(n_strikes), dim3(kBlock), 0, st, ST, n_paths, K_dev,
-                       is_put, out_dev);
+    const int nchunks = (int)((n_paths + kPayChunk - 1) / kPayChunk);
+    hipLaunchKernelGGL(payoff_partial_kernel, dim3(nchunks, n_strikes), dim3(kBlock), 0, st, ST, n_paths, K_dev, is_put, part_dev);
+    hipLaunchKernelGGL(payoff_final_kernel, dim3((2 * n_strikes + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                       (const double*)part_dev, nchunks, n_strikes, out_dev);
     return hipGetLastError();
 }
 

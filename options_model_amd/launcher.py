@@ -114,7 +114,13 @@ def launch_ranks(n: int, deadline_s: float, argv, who: str = "options_model_amd.
     return rc
 
 
-VALUE_ERROR_GRACE_S = 5.0  # how long the other ranks may take to raise the same ValueError (see _roundtrip)
+# How long the other ranks may take to raise the same ValueError once the first rank has (see _roundtrip): at least
+# VALUE_ERROR_GRACE_S, and VALUE_ERROR_GRACE_FRACTION of the call's own timeout -- a ValueError that every rank raises
+# legitimately can arrive with seconds of skew on a first call (one rank still building or loading the library, creating
+# its context, or generating a longer shard before a library check turns a negative return code into the exception), and
+# five seconds flat would have declared those ranks out of step and cost the pool.
+VALUE_ERROR_GRACE_S = 5.0
+VALUE_ERROR_GRACE_FRACTION = 0.05  # 30 s at the default 600 s timeout
 
 
 class RankError(RuntimeError):
@@ -189,7 +195,8 @@ class RankPool:
                 if left <= 0:
                     missing = [r for r, a in enumerate(answers) if a is None]
                     raise RankError(f"rank(s) {missing} did not answer {req['fn']} within {timeout_s:.0f} s")
-                if refused_at is not None and time.monotonic() - refused_at > VALUE_ERROR_GRACE_S:
+                if refused_at is not None and time.monotonic() - refused_at > max(VALUE_ERROR_GRACE_S,
+                                                                                      VALUE_ERROR_GRACE_FRACTION * timeout_s):
                     # An argument error is raised before anything collective -- on EVERY rank, within moments.  A rank
                     # that has not refused by now took the call: the ValueError was rank-local (a library check that only
                     # fails for one shard), and that rank's peers sit in a collective it will never enter.

@@ -191,7 +191,7 @@ def test_config1_nn_prices_follow_the_references_distribution(torch_cuda, golden
     drawn from five reference runs (rounds 3-4) says little about a sixth.  Round 5: the reference itself was run for
     master seeds 42 and 1 .. 20 (tools/capture_reference_band.py, ~150 s of CPU each; tests/golden/scalars.json), and
     OUR pricer is run for the same 21 seeds.  The two SAMPLES must agree:
-      * means: Welch's t below 3.5;
+      * means: Welch's t below 3.0 (measured: -1.4 over the 21 seeds; 0.4 for the 3 x 64 net);
       * distributions: two-sample Kolmogorov-Smirnov statistic below its 0.1 % critical value 1.95 sqrt((n + m) / (n m));
       * spread: standard deviations within a factor 2 of each other;
       * every single price inside the reference's own range widened by its standard deviation -- the band a further
@@ -212,7 +212,7 @@ def test_config1_nn_prices_follow_the_references_distribution(torch_cuda, golden
 
 
 def _same_distribution(prices, refs, what):
-    """Two samples of prices over the same master seeds (ours / the reference's own runs): Welch's t below 3.5, the
+    """Two samples of prices over the same master seeds (ours / the reference's own runs): Welch's t below 3.0, the
     two-sample Kolmogorov-Smirnov statistic below its 0.1 % critical value, standard deviations within a factor 2, and
     every single price of ours inside the reference's range widened by its own standard deviation."""
     from scipy import stats
@@ -221,11 +221,38 @@ def _same_distribution(prices, refs, what):
     ks = stats.ks_2samp(prices, refs).statistic
     print(f"{what}, {n} seeds: ours mean {prices.mean():.4f} sd {prices.std(ddof=1):.4f} [{prices.min():.3f}, {prices.max():.3f}]; "
           f"reference mean {refs.mean():.4f} sd {refs.std(ddof=1):.4f} [{refs.min():.3f}, {refs.max():.3f}]; Welch t {t:.2f}, KS {ks:.3f}")
-    assert abs(t) < 3.5, (t, prices, refs)
+    assert abs(t) < 3.0, (t, prices, refs)
     assert ks < 1.95 * np.sqrt((n + m) / (n * m)), (ks, prices, refs)
     assert 0.5 < prices.std(ddof=1) / refs.std(ddof=1) < 2.0
     sd = refs.std(ddof=1)
     assert np.all((prices > refs.min() - sd) & (prices < refs.max() + sd)), (prices, refs)
+
+
+def test_config1_nn_kernels_against_autograd_paired_over_seeds(torch_cuda):
+    """the two-sample test above compares our prices with the reference's over 21 seeds at a price sd of 0.2 -- a
+    bias of 2 % in the 16-row trainer could hide in it.  The PAIRED form removes the path noise: for each of 16 seeds the
+    same paths, the same rows and the same initial weights (torch.manual_seed before the net is built), trained once by the
+    library's kernels and once by PyTorch autograd + torch.optim.Adam (the reference's own training loop).  Minibatch
+    order and dropout draws differ between the two (their generators cannot be matched), so single prices differ by the
+    +-0.3 of profiles/r05_nn_seed_study.jsonl; what must hold:
+      * every seed ends at the same loss: best epoch-mean loss within 1 %;
+      * no systematic offset: |mean of the price differences| below 3 standard errors of that mean (paired t)."""
+    from options_model_amd import nn_regressor as nnr
+    d, rel_loss = [], []
+    for seed in range(101, 117):
+        kw = dict(seed=seed, torch_seed=seed + 1000, nn_hidden=128, nn_layers=3, nn_epochs=25)
+        a = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 10_000, 50, nn_trainer="hip", **kw)
+        b = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 10_000, 50, nn_trainer="torch", **kw)
+        assert a.info["trainer"] == "hip" and a.info["trainer_kernel"] == "mlp_train_q16_kernel" and b.info["trainer"] == "torch"
+        assert a.sum_nitm == b.sum_nitm and a.info["batch"] == b.info["batch"] == 256  # the same rows
+        d.append(a.price - b.price)
+        rel_loss.append(a.info["best_loss"] / b.info["best_loss"] - 1.0)
+    d, rel_loss = np.array(d), np.array(rel_loss)
+    t = d.mean() / (d.std(ddof=1) / np.sqrt(len(d)))
+    print(f"paired over {len(d)} seeds: kernels - autograd: mean {d.mean():+.4f}, sd {d.std(ddof=1):.4f}, paired t {t:+.2f}; "
+          f"best loss kernels / autograd - 1: mean {rel_loss.mean():+.2e}, max |.| {np.abs(rel_loss).max():.2e}")
+    assert np.abs(rel_loss).max() < 1e-2, rel_loss
+    assert abs(t) < 3.0, (t, d)
 
 
 def test_config1_nn_hidden64_all_hip_follows_the_references_distribution(torch_cuda, golden):

@@ -67,8 +67,14 @@ def test_a_rank_local_value_error_does_not_leave_the_peers_waiting(monkeypatch):
     t0 = time.monotonic()
     with pytest.raises(launcher.RankError, match=r"rank\(s\) \[1\] refused bad_on_one \(selected another number of rows\) "
                                                  r"while rank\(s\) \[0, 2\] went ahead"):
-        p.call("bad_on_one", dict(rank=1), timeout_s=600)
-    assert time.monotonic() - t0 < 30 and p._closed and all(q.poll() is not None for q in p.procs)
+        p.call("bad_on_one", dict(rank=1), timeout_s=20)  # grace = max(1 s, 5 % of the call's timeout) = 1 s
+    assert time.monotonic() - t0 < 15 and p._closed and all(q.poll() is not None for q in p.procs)
+    # the grace grows with the call's own timeout (a first call's ranks can be seconds apart): 5 % of 100 s = 5 s here
+    p = _pool(3)
+    t0 = time.monotonic()
+    with pytest.raises(launcher.RankError, match="went ahead"):
+        p.call("bad_on_one", dict(rank=1), timeout_s=100)
+    assert 4.5 < time.monotonic() - t0 < 40 and p._closed
 
 
 def test_deadline_ends_a_stuck_rank():

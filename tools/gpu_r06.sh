@@ -118,6 +118,23 @@ fused)  # EXPERIMENT: the default call's optimizer step without its Adam launch 
   done
   true
   ;;
+fusedprof)  # rocprofv3 kernel stats of the three step forms (the experiment's child process, 2 epochs of the default call's shape)
+  for F in 0 1 2; do
+    export OMC_MLP_FUSED=$F
+    prof fused_step_$F "$R/tools/exp_fused_step.py" --child 225057 256 2 128 3 0.1 || exit 1
+    cat gpurun_out/${TAG}_fused_step_${F}_under_rocprof.json | cut -c1-300
+  done
+  unset OMC_MLP_FUSED
+  true
+  ;;
+c5)  # config 5 and the default call after the rows rework: lines + kernel stats
+  timeout -k 10 400 python bench.py --config c5 --steps 3 --warmup 1 > gpurun_out/bench_${TAG}_c5.json 2> gpurun_out/bench_${TAG}_c5.err; rc=$?
+  echo "bench c5 exit=$rc"; ok $rc || exit 1
+  python3 -c "
+import json; d=json.load(open('gpurun_out/bench_${TAG}_c5.json')); print('c5 ms_per_step', d['ms_per_step'], 'timings', d['timings_ms'], 'price', d['price'], 'rows', d['rows'])"
+  prof c5 "$R/bench.py" --config c5 --steps 2 --warmup 1 || exit 1
+  grep "rows_\|Name" gpurun_out/${TAG}_c5_kernel_stats.csv | cut -c1-200
+  ;;
 tests)
   timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
   tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
