@@ -278,7 +278,7 @@ int omc_heston_price_surface(omc_ctx* ctx, int64_t n_paths, int n_steps, double 
 /* ---- NN continuation-value regressor: fused training of the network ------------------------ */
 /* replaces the minibatch loop of price_american_enhanced_lsm (options_model_3.py:565-600:
  * SingleLSMNet(7, hidden, layers) :85-103, nn.MSELoss, optim.Adam(lr, weight_decay), shuffled
- * minibatches) for hidden = 64 or 128 with layers = 2 (BASELINE config 5 names 7 -> 64 -> 64 -> 1)
+ * minibatches) for hidden = 32, 64 or 128 with layers = 2 (BASELINE config 5 names 7 -> 64 -> 64 -> 1)
  * or 3 (the depth SingleLSMNet always has in the reference; 3 x 128 is its default) -- see
  * omc_mlp_train_supported for the batch sizes; anything else returns -9.
  * One call = one epoch over `n_rows` rows of
@@ -369,9 +369,10 @@ int omc_price_american_ols7(omc_ctx* ctx, const omc_params* p, omc_result* res, 
  * their population variances (two passes: mean first, then squared deviations).  out16: host. */
 int omc_nn_feature_stats(omc_ctx* ctx, const double* x, const int32_t* t, const double* y,
                          int64_t n_rows, double T, double dt, double* out16);
-/* 1 if omc_mlp_train_epoch covers this network shape at this minibatch size: hidden 64 or 128 (the
- * reference's default width) with 2 or 3 hidden layers, any batch; also 32 units x 2 layers (the width
- * the per-step ContNet flow trains at, omc_lsm_contnet). */
+/* 1 if omc_mlp_train_epoch covers this network shape at this minibatch size: hidden 32, 64 or 128 (the
+ * reference's default width) with 2 or 3 hidden layers, any batch (32 is also the width the per-step ContNet flow
+ * trains at, omc_lsm_contnet).  Wider networks (256 units: a connection's operands no longer fit the registers /
+ * LDS the kernels keep them in) train and sweep through PyTorch-ROCm, with a RuntimeWarning from nn_regressor. */
 int omc_mlp_train_supported(int hidden, int layers, int64_t batch);
 int omc_mlp_train_epoch(omc_ctx* ctx, const float* data, int64_t n_rows, int64_t batch, int hidden,
                         int layers, float* params, float* adam_m, float* adam_v, int64_t* step,
@@ -453,7 +454,7 @@ int omc_localvol_paths_f32(omc_ctx* ctx, float* S, int64_t ld, int64_t n_paths, 
  * learning rate, dropout / shuffle keys and step counter.  Every network ends the epoch with exactly the parameters,
  * Adam moments and mean loss that its own omc_mlp_train_epoch call produces (same kernel body, same reductions).
  * jobs[i].step is advanced by the epoch's steps, jobs[i].mean_loss receives the epoch-mean batch loss.  Pointers are
- * device pointers as in omc_mlp_train_epoch.  Shapes: 64 | 128 units x 2 | 3 hidden layers (and 32 x 2) at
+ * device pointers as in omc_mlp_train_epoch.  Shapes: 32 | 64 | 128 units x 2 | 3 hidden layers at
  * minibatches of at most 8192 rows. */
 typedef struct {
     const float* data;     /* [n_rows][8] float32: 7 normalised features + normalised target        */

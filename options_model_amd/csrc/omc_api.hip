@@ -2105,7 +2105,7 @@ int omc_lsm_apply_mlp_shard(omc_ctx* c, const float* S, int64_t ld, int64_t n_pa
     if ((rc = check_sizes(n_paths, n_steps))) return rc;
     if ((rc = check_matrix(S, ld, n_paths))) return rc;
     if (omc_mlp_param_count(hidden, layers) < 0)
-        return fail(-9, "pass 2 supports hidden = 64 or 128 with 2 or 3 hidden layers.");
+        return fail(-9, "pass 2 supports hidden = 32, 64 or 128 with 2 or 3 hidden layers.");
     if (!params || !feat_mean || !feat_std || !res) return fail(-7, "null pointer.");
     if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
     for (int i = 0; i < 7; ++i)
@@ -2518,7 +2518,7 @@ int omc_mlp_dropout_masks(omc_ctx* c, int variant, int hidden, int layers, int64
     int rc = bind_in(c);
     if (rc) return rc;
     if (variant < 0 || variant > 4) return fail(-4, "variant must be 0 (pass 2) or 1 .. 4 (omc_mlp_train_variant).");
-    const bool shape_ok = variant == 3 ? (hidden == 32 || hidden == 64 || hidden == 128)
+    const bool shape_ok = (variant == 3 || variant == 0) ? (hidden == 32 || hidden == 64 || hidden == 128)
                         : variant == 1 ? hidden == 64 : (hidden == 64 || hidden == 128);
     if (!shape_ok || layers < 1 || layers > 3) return fail(-9, "this kernel does not exist for that network shape.");
     if (n_rows <= 0 || !out) return fail(-3, "n_rows must be positive, out non-null.");
@@ -2552,7 +2552,7 @@ int omc_mlp_train_epoch(omc_ctx* c, const float* data, int64_t n_rows, int64_t b
     int rc = bind_in(c);
     if (rc) return rc;
     if (omc::mlp_train_kernel_choice(hidden, layers, batch) == 0)
-        return fail(-9, "the fused trainer supports hidden = 64 or 128 with 2 or 3 hidden layers (and 32 x 2).");
+        return fail(-9, "the fused trainer supports hidden = 32, 64 or 128 with 2 or 3 hidden layers.");
     if (!data || !params || !adam_m || !adam_v || !step || !mean_loss) return fail(-7, "null pointer.");
     if (n_rows <= 0 || batch <= 0 || *step < 0) return fail(-3, "n_rows, batch must be positive.");
     if (!(dropout >= 0.0 && dropout < 1.0)) return fail(-4, "dropout must be in [0, 1).");
@@ -2681,7 +2681,7 @@ int omc_mlp_train_epoch_sharded(omc_ctx* c, const float* data_epoch, int64_t n_r
     t.allreduce = allreduce_cb; t.allreduce_user = c;  // no communicator / hook: the sum of one rank
     const int64_t kb = omc::mlp_plan_kernel_batch(t);
     if (omc::mlp_train_kernel_choice(hidden, layers, kb) == 0)
-        return fail(-9, "the fused trainer supports hidden = 64 or 128 with 2 or 3 hidden layers (and 32 x 2).");
+        return fail(-9, "the fused trainer supports hidden = 32, 64 or 128 with 2 or 3 hidden layers.");
     const int np = omc::mlp_train_param_count(hidden, layers);
     if ((rc = c->mlp_part.ensure(omc::mlp_partial_bytes(hidden, layers, kb)))) return rc;
     if ((rc = c->mlp_wt.ensure(omc::mlp_wt_bytes(hidden, layers)))) return rc;
@@ -2722,7 +2722,7 @@ int omc_mlp_train_epoch_batch(omc_ctx* c, omc_mlp_job* jobs, int n, int hidden, 
         if (!(j.lr > 0.0)) return fail(-4, "learning rate must be positive.");
         if (!omc::mlp_batch_supported(hidden, layers, j.batch))
             return fail(-9, "the batched trainer covers the one-tile-per-workgroup shapes (64 | 128 units x 2 | 3 layers at "
-                            "minibatches of at most 8192 rows, 32 x 2).");
+                            "minibatches of at most 8192 rows, 32 units x 2 | 3 layers).");
         const int64_t nb = (j.n_rows + j.batch - 1) / j.batch;
         if (nb > max_steps) max_steps = nb;
         // every network runs the kernel its own omc_mlp_train_epoch call runs (16-row tiles up to q16_rows rows)

@@ -735,12 +735,18 @@ __host__ __device__ constexpr int apply_lds_floats(int H, int L)
 
 // ReLU + inverted dropout over NT 32-unit tiles; one Philox block seeds the two streams of a
 // tile pair.
+__device__ __forceinline__ void relu_dropout_1(v16f& z, uint32_t row, uint32_t step, uint32_t tag, uint32_t keep16,
+                                               float inv_keep, uint32_t k0, uint32_t k1);
 template <int NT>
 __device__ __forceinline__ void relu_dropout_n(v16f (&z)[NT], uint32_t row, uint32_t step, uint32_t tag,
                                                uint32_t keep16, float inv_keep, uint32_t k0, uint32_t k1)
 {
+    if constexpr (NT == 1) {  // 32 hidden units: one tile, no partner -- the single-stream generator (relu_dropout_1)
+        relu_dropout_1(z[0], row, step, tag, keep16, inv_keep, k0, k1);
+        return;
+    }
 #pragma unroll
-    for (int p = 0; p < NT; p += 2) {
+    for (int p = 0; p + 1 < NT; p += 2) {
         v16f pair[2] = {z[p], z[p + 1]};
         relu_dropout<true>(pair, row, step, tag + 0x1000u * (uint32_t)p, keep16, inv_keep, k0, k1);
         z[p] = pair[0];
@@ -2290,7 +2296,7 @@ static int mlp_train_kernel_choice32(int hidden, int layers, int64_t batch)
     static const int quad = getenv("OMC_MLP_QUAD") ? atoi(getenv("OMC_MLP_QUAD")) : 1;
     if (hidden == 64) return tiles <= 32 ? (quad ? 3 : 2) : 1;
     if (hidden == 128) return (quad && tiles <= kMlpMaxGroups) ? 3 : 2;
-    if (hidden == 32 && layers == 2) return 3;  // the per-step ContNet of omc_contnet.hip: any number of tiles
+    if (hidden == 32) return 3;  // 32 units (the per-step ContNet of omc_contnet.hip; SingleLSMNet(7, 32, 2 | 3)): any number of tiles
     return 0;
 }
 
@@ -2313,8 +2319,7 @@ int mlp_train_kernel_choice(int hidden, int layers, int64_t batch)
 
 int mlp_train_param_count(int hidden, int layers)
 {
-    if (hidden == 32 && layers == 2) return mlp_params_of(32, 2);
-    if ((hidden != 64 && hidden != 128) || (layers != 2 && layers != 3)) return -1;
+    if ((hidden != 32 && hidden != 64 && hidden != 128) || (layers != 2 && layers != 3)) return -1;
     return mlp_params_of(hidden, layers);
 }
 
@@ -2381,6 +2386,14 @@ __global__ __launch_bounds__(64) void mlp_mask_probe_kernel(int variant, int lay
                 for (int r = 0; r < 16; ++r) o[32 * w + rho(r)] = z[w][r] != 0.0f;
             }
             continue;
+        }
+        if constexpr (NT == 1) {
+            if (variant == 0) {  // pass 2 with one 32-unit tile
+                const uint32_t tag = (j == 0 ? 0x300u : 0x400u + 0x100u * (uint32_t)(j - 1)) + (uint32_t)h;
+                relu_dropout_n<1>(z, key, step, tag, keep16, inv_keep, k0, k1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[unit_of(0, r, h)] = z[0][r] != 0.0f;
+            }
         }
         if constexpr (NT >= 2) {
             if (variant == 2) {
@@ -2715,7 +2728,7 @@ hipError_t mlp_train_steps(hipStream_t st, const MlpTrainPlan& t)
         return t.layers == 2 ? tile_steps<128, 2>(st, t) : tile_steps<128, 3>(st, t);
     }
     if (choice == 3) {
-        if (t.hidden == 32) return quad_steps<32, 2>(st, t);
+        if (t.hidden == 32) return t.layers == 2 ? quad_steps<32, 2>(st, t) : quad_steps<32, 3>(st, t);
         if (t.hidden == 64) return t.layers == 2 ? quad_steps<64, 2>(st, t) : quad_steps<64, 3>(st, t);
         return t.layers == 2 ? quad_steps<128, 2>(st, t) : quad_steps<128, 3>(st, t);
     }
@@ -2751,7 +2764,7 @@ void mlp_batch_table_image(const MlpBatchJob* jobs, int n, int hidden, int layer
         p.inv_keep = p.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)p.keep16);
         p.k0 = (uint32_t)j.seed;
         p.k1 = (uint32_t)(j.seed >> 32);
-        p.pstride = hidden == 32 ? tile_pstride(32, 2) : (hidden == 64 ? tile_pstride(64, layers) : tile_pstride(128, layers));
+        p.pstride = tile_pstride(hidden, layers);
         p.q16_rows = j.allow_q16 ? (int)mlp_q16_rows(hidden) : 0;
         p.nrows_dev = j.nrows_dev;
     }
@@ -2819,7 +2832,8 @@ hipError_t mlp_train_epoch_batch(hipStream_t st, const void* table_dev, int n, i
 {
     const MlpBatchProb* tab = (const MlpBatchProb*)table_dev;
     const int t32 = max_tiles32, t16 = max_tiles16;
-    if (hidden == 32 && layers == 2) return batch_epoch<32, 2>(st, tab, n, max_steps, t32, 0, bc1_dev, bc2_dev);
+    if (hidden == 32) return layers == 2 ? batch_epoch<32, 2>(st, tab, n, max_steps, t32, 0, bc1_dev, bc2_dev)
+                                         : batch_epoch<32, 3>(st, tab, n, max_steps, t32, 0, bc1_dev, bc2_dev);
     if (hidden == 64) return layers == 2 ? batch_epoch<64, 2>(st, tab, n, max_steps, t32, t16, bc1_dev, bc2_dev)
                                          : batch_epoch<64, 3>(st, tab, n, max_steps, t32, t16, bc1_dev, bc2_dev);
     if (hidden == 128) return layers == 2 ? batch_epoch<128, 2>(st, tab, n, max_steps, t32, t16, bc1_dev, bc2_dev)
@@ -2829,7 +2843,7 @@ hipError_t mlp_train_epoch_batch(hipStream_t st, const void* table_dev, int n, i
 
 int mlp_apply_param_count(int hidden, int layers)
 {
-    if ((hidden != 64 && hidden != 128) || (layers != 2 && layers != 3)) return -1;
+    if ((hidden != 32 && hidden != 64 && hidden != 128) || (layers != 2 && layers != 3)) return -1;
     return mlp_params_of(hidden, layers);
 }
 
@@ -2865,6 +2879,8 @@ hipError_t mlp_apply_pass2(hipStream_t st, const LsmProblem& p, int hidden, int 
     a.inv_keep = a.keep16 >= 65536u ? 1.0f : (float)(65536.0 / (double)a.keep16);
     a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
     a.ntiles = (int)((p.M + 31) / 32);
+    if (hidden == 32 && layers == 2) return launch_apply<32, 2>(st, a);
+    if (hidden == 32 && layers == 3) return launch_apply<32, 3>(st, a);
     if (hidden == 64 && layers == 2) return launch_apply<64, 2>(st, a);
     if (hidden == 64 && layers == 3) return launch_apply<64, 3>(st, a);
     if (hidden == 128 && layers == 2) return launch_apply<128, 2>(st, a);

@@ -97,7 +97,7 @@ def price_american_option_nn_sharded(sp, S0, K, r, sigma, T, n_paths, n_steps, m
         torch.manual_seed(int(seed + 1 if torch_seed is None else torch_seed))  # :455 -- the same on every rank
         net = nr.make_net(7, nn_hidden, nn_layers, nn_dropout).to(dev)
         if not nr.fused_apply_supports(net):
-            raise ValueError("the sharded NN regressor covers SingleLSMNet(7, 64 | 128, 2 | 3)")
+            raise ValueError("the sharded NN regressor covers SingleLSMNet(7, 32 | 64 | 128, 2 | 3)")
         H, L = nr._linear_shape(net)
         # pass 1: own rows, the job's normalisers
         R_local = ctx.nn_build_rows(S.data_ptr(), S.stride(0), n_local, N, K, r, T, is_put)

@@ -231,8 +231,8 @@ def _linear_shape(net):
 def fused_trainer_supports(net, batch=256):
     """The hand-written trainers (omc_mlp_train_epoch) cover 64 hidden units x 2 or 3 hidden layers at
     any minibatch size (workgroup kernel with the weights in LDS, tile-per-wave kernel for small
-    minibatches; BASELINE config 5 names 2 x 64) and 128 units -- the reference's default width --
-    (tile-per-wave kernel)."""
+    minibatches; BASELINE config 5 names 2 x 64), 128 units -- the reference's default width --
+    (tile-per-wave kernel) and 32 units (one 32-row tile per workgroup at any minibatch size)."""
     shape = _linear_shape(net)
     if shape is None:
         return False
@@ -241,9 +241,9 @@ def fused_trainer_supports(net, batch=256):
 
 
 def fused_apply_supports(net):
-    """The pass-2 kernel (omc_lsm_apply_mlp) covers 64 or 128 hidden units x 2 or 3 hidden layers,
+    """The pass-2 kernel (omc_lsm_apply_mlp) covers 32, 64 or 128 hidden units x 2 or 3 hidden layers,
     i.e. also the reference's own SingleLSMNet defaults (3 x 128, options_model_3.py:87)."""
-    return _linear_shape(net) in ((64, 2), (64, 3), (128, 2), (128, 3))
+    return _linear_shape(net) in ((32, 2), (32, 3), (64, 2), (64, 3), (128, 2), (128, 3))
 
 
 def flatten_params(net):
@@ -411,7 +411,7 @@ def train(net, x, t, y, fm, fs, ym, ysd, T, dt, epochs, lr, nn_batch=None, verbo
 def train_on_matrix(net, data, epochs, lr, nn_batch=None, verbose=False, use_graph=True, trainer="auto"):
     """:565-613: Adam(lr, wd 1e-5), MSE, shuffled minibatches, ReduceLROnPlateau on the epoch-mean
     loss, early stop after 8 non-improving epochs, best-weights restore.
-    trainer: "hip" = the library's fused MFMA kernels (64 or 128 units x 2 or 3 hidden layers), "torch" = PyTorch-ROCm
+    trainer: "hip" = the library's fused MFMA kernels (32, 64 or 128 units x 2 or 3 hidden layers), "torch" = PyTorch-ROCm
     autograd (any SingleLSMNet shape), "auto" = hip where it applies."""
     torch = _torch()
     R = data.shape[0]
@@ -420,12 +420,12 @@ def train_on_matrix(net, data, epochs, lr, nn_batch=None, verbose=False, use_gra
     if trainer not in ("auto", "hip", "torch"):
         raise ValueError("trainer must be 'auto', 'hip' or 'torch'")
     if trainer == "hip" and not fused_trainer_supports(net, bs):
-        raise ValueError("trainer='hip' covers SingleLSMNet(7, 64 | 128, 2 | 3)")
+        raise ValueError("trainer='hip' covers SingleLSMNet(7, 32 | 64 | 128, 2 | 3)")
     if trainer != "torch" and fused_trainer_supports(net, bs):
         return _train_fused(net, data, epochs, lr, bs, verbose)
     if trainer == "auto":
         _warn_once("trainer", f"options_model_amd: SingleLSMNet shape {_linear_shape(net)} (hidden units, hidden layers) is not "
-                              "covered by the HIP trainer kernels (64 | 128 units x 2 | 3 layers): training through PyTorch-ROCm "
+                              "covered by the HIP trainer kernels (32 | 64 | 128 units x 2 | 3 layers): training through PyTorch-ROCm "
                               "autograd instead (same arithmetic, several times slower); info['trainer'] == 'torch'")
     # state snapshots for the warm-up steps of the graph capture must not leak into training
     init_state = copy.deepcopy(net.state_dict())
@@ -576,7 +576,7 @@ def price_with_paths(S, K, r, T, is_put, torch_seed, nn_hidden=128, nn_layers=3,
     else:
         if trainer != "torch":
             _warn_once("pass2", f"options_model_amd: SingleLSMNet shape {_linear_shape(net)} is not covered by the HIP pass-2 "
-                                "kernel (64 | 128 units x 2 | 3 layers): the backward sweep evaluates the network through "
+                                "kernel (32 | 64 | 128 units x 2 | 3 layers): the backward sweep evaluates the network through "
                                 "PyTorch-ROCm; info['pass2'] == 'torch'")
         cf, ex = pass2(S, K, r, T, is_put, net, fm, fs, ym, ysd, dropout_on=inference_dropout)
         price = float(cf.mean())

@@ -197,7 +197,14 @@ def apply_bits(hidden, layers, cols, t, seed):
     out = np.empty((layers, cols.shape[0], hidden), np.uint32)
     for j in range(layers):
         base = 0x300 if j == 0 else 0x400 + 0x100 * (j - 1)
-        b = _layer_bits_pairs(key, int(t), base, seed, hidden)
+        if hidden == 32:  # one 32-unit tile has no partner: the SINGLE generator (relu_dropout_n<1> = relu_dropout_1), tag base + h
+            b = np.empty((cols.shape[0], 1, 32), np.uint32)
+            for h in (0, 1):
+                bits = _single_bits(key, int(t), base + h, seed)
+                for r in range(16):
+                    b[:, 0, _slot(r, h)] = bits[:, r]
+        else:
+            b = _layer_bits_pairs(key, int(t), base, seed, hidden)
         out[j] = _tiles_to_units(b, hidden, lambda tile, s: 32 * tile + s)
     return out
 

@@ -41,7 +41,7 @@ def env(ctx):
                                             (dr.QUAD, 128), (dr.Q16, 64), (dr.Q16, 128)])
 @pytest.mark.parametrize("p_drop", [0.1, 0.5])
 def test_trainer_masks_on_the_device_equal_the_oracle(ctx, variant, hidden, p_drop):
-    layers = 2 if hidden == 32 else 3
+    layers = 3
     for n_rows, step, seed in ((1, 1, 5), (33, 2, 2 ** 62 - 7), (1000, 22_050, 0x1234_5678_9ABC_DEF0)):
         got = ctx.mlp_dropout_masks(variant, hidden, layers, n_rows, step, seed, p_drop)
         want = dr.train_masks(variant, hidden, layers, np.arange(n_rows), step, seed, p_drop)
@@ -56,7 +56,7 @@ def test_trainer_masks_on_the_device_equal_the_oracle(ctx, variant, hidden, p_dr
     assert abs(got.mean() - q) < 5 * np.sqrt(q * (1 - q) / got.size)
 
 
-@pytest.mark.parametrize("hidden,layers", [(64, 2), (64, 3), (128, 2), (128, 3)])
+@pytest.mark.parametrize("hidden,layers", [(32, 2), (32, 3), (64, 2), (64, 3), (128, 2), (128, 3)])
 def test_pass2_masks_on_the_device_equal_the_oracle(ctx, hidden, layers):
     cols = np.concatenate([np.arange(0, 300), np.arange(500_000, 500_300), [2 ** 32 - 1]]).astype(np.int64)
     for t, seed, p_drop in ((1, 11, 0.1), (251, 2 ** 61 + 3, 0.1), (17, 99, 0.5)):
@@ -171,6 +171,7 @@ def _check_one_step(env, ctx, hidden, layers, rows, p_drop, variant, first_step=
 
 @pytest.mark.parametrize("p_drop", [0.1, 0.5])
 @pytest.mark.parametrize("hidden,layers,rows,variant", [
+    (32, 2, 1, dr.QUAD), (32, 3, 100, dr.QUAD), (32, 2, 256, dr.QUAD), (32, 3, 4097, dr.QUAD), (32, 2, 1 << 17, dr.QUAD),
     (64, 2, 16, dr.Q16), (64, 2, 100, dr.Q16), (64, 3, 1000, dr.Q16), (64, 3, 1024, dr.Q16),
     (128, 3, 1, dr.Q16), (128, 3, 17, dr.Q16), (128, 3, 256, dr.Q16), (128, 2, 1000, dr.Q16), (128, 2, 1024, dr.Q16),
     (128, 3, 1025, dr.Q16), (128, 3, 4096, dr.Q16), (128, 3, 4097, dr.QUAD), (128, 2, 8192, dr.QUAD),
@@ -189,7 +190,8 @@ def test_a_later_optimizer_step_draws_its_own_masks(env, ctx, hidden, layers, ro
     _check_one_step(env, ctx, hidden, layers, rows, 0.1, variant, first_step=21_999, seed=2 ** 61 + 12345)
 
 
-@pytest.mark.parametrize("hidden,layers,bs,variant", [(128, 3, 256, dr.Q16), (128, 2, 2048, dr.Q16), (128, 2, 5000, dr.QUAD), (64, 2, 2048, dr.GROUP)])
+@pytest.mark.parametrize("hidden,layers,bs,variant", [(32, 3, 256, dr.QUAD), (128, 3, 256, dr.Q16), (128, 2, 2048, dr.Q16), (128, 2, 5000, dr.QUAD),
+                                                      (64, 2, 2048, dr.GROUP)])
 def test_several_steps_track_torch_adam_under_the_same_masks(env, ctx, hidden, layers, bs, variant):
     """Ten optimizer steps of an epoch (masks of steps 1..10, rows in storage order) against torch.optim.Adam fed the
     masked losses: the weights stay together as in the dropout-free test (test_gpu_mlp.py), i.e. masks, 1 / keep and
@@ -220,18 +222,25 @@ def test_several_steps_track_torch_adam_under_the_same_masks(env, ctx, hidden, l
     assert float(diff.max()) <= 2.5e-3 and float(diff.mean()) <= 2e-5  # the dropout-free test's bounds
 
 
-@pytest.mark.parametrize("hidden,layers,batch,variant_local", [(64, 2, 8192, dr.GROUP), (128, 3, 256, dr.Q16),
-                                                               (64, 2, 1500, dr.Q16), (128, 3, 4096, dr.Q16), (128, 3, 8000, dr.QUAD)])
-def test_sharded_step_draws_the_masks_of_the_global_minibatch(env, ctx, hidden, layers, batch, variant_local):
+@pytest.mark.parametrize("hidden,layers,batch,variant_global", [(64, 2, 8192, dr.GROUP), (128, 3, 256, dr.Q16),
+                                                                (64, 2, 1500, dr.GROUP), (128, 3, 4096, dr.Q16),
+                                                                (128, 3, 6000, dr.QUAD), (128, 3, 8000, dr.QUAD)])
+def test_sharded_step_draws_the_masks_of_the_global_minibatch(env, ctx, hidden, layers, batch, variant_global):
     """One rank's part of a global minibatch (omc_mlp_train_epoch_sharded without a communicator = the sum of one
     rank): its rows carry their positions in the GLOBAL minibatch as dropout keys, the loss is scaled by the global
-    size.  Gradient = autograd of sum_own (o - y)^2 / B_global under the masks of those positions."""
+    size.  Gradient = autograd of sum_own (o - y)^2 / B_global under the masks of those positions -- drawn by the kernel
+    the UNSHARDED run picks for the global minibatch (a rank used to pick by its own share, so a rank holding 937
+    of 1,500 rows ran the 16-row kernel while the unsharded run -- and a peer with a larger share -- ran another one, with
+    another unit map: masks that are not the unsharded run's).  Cases 3 and 5 are such shares."""
     torch, nnr, dev = env
     p_drop, seed = 0.1, 31
     rng = np.random.default_rng(8)
     pos = np.sort(rng.choice(batch, size=batch * 5 // 8, replace=False)).astype(np.uint32)  # this rank's positions
     n_loc = pos.size
-    assert ctx.lib.omc_mlp_train_variant(hidden, layers, n_loc) == variant_local
+    assert ctx.lib.omc_mlp_train_variant(hidden, layers, batch) == variant_global
+    if (hidden, layers, batch) in ((64, 2, 1500), (128, 3, 6000)):
+        assert ctx.lib.omc_mlp_train_variant(hidden, layers, n_loc) != variant_global  # the rank's own share would pick another
+    variant_local = variant_global
     torch.manual_seed(6)
     net = nnr.make_net(7, hidden, layers, p_drop).to(dev)
     data = _data(torch, dev, n_loc, 15)

@@ -218,11 +218,11 @@ def _mask_cases(n, seed):
     from oracle import dropout as dr
     rng = np.random.default_rng(seed)
     shapes = [(dr.GROUP, 64), (dr.TILE, 64), (dr.TILE, 128), (dr.QUAD, 32), (dr.QUAD, 64), (dr.QUAD, 128), (dr.Q16, 64),
-              (dr.Q16, 128), (0, 64), (0, 128)]  # 0: pass 2 (mlp_apply_kernel), keyed by path column and time step
+              (dr.Q16, 128), (0, 32), (0, 64), (0, 128)]  # 0: pass 2 (mlp_apply_kernel), keyed by path column and time step
     out = []
     for _ in range(n):
         variant, hidden = shapes[int(rng.integers(0, len(shapes)))]
-        out.append(dict(variant=variant, hidden=hidden, layers=2 if hidden == 32 else int(rng.integers(2, 4)),
+        out.append(dict(variant=variant, hidden=hidden, layers=int(rng.integers(2, 4)),
                         rows=int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 255, 257, 1000, 4097])),
                         step=int(rng.choice([1, 2, 255, 256, 65_535, 65_536, 22_050, 2 ** 31 - 1])),
                         seed=int(rng.integers(0, 2 ** 63)), p=float(rng.choice([0.0, 0.05, 0.1, 0.25, 0.5, 0.9])),
@@ -255,7 +255,7 @@ def _grad_cases(n, seed):
     out = []
     for _ in range(n):
         rows = int(rng.choice([1, 7, 16, 17, 100, 255, 256, 257, 1000, 2049, 4096, 4097, 9000, 20_000, 40_001]))
-        out.append(dict(hidden=int(rng.choice([64, 128])), layers=int(rng.integers(2, 4)), rows=rows,
+        out.append(dict(hidden=int(rng.choice([32, 64, 128])), layers=int(rng.integers(2, 4)), rows=rows,
                         p=float(rng.choice([0.05, 0.1, 0.3, 0.5])), step=int(rng.choice([0, 1, 999, 21_999, 10 ** 6])),
                         seed=int(rng.integers(0, 2 ** 62))))
     return out
@@ -287,7 +287,7 @@ def _pass2_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(n):
-        out.append(dict(hidden=int(rng.choice([64, 128])), layers=int(rng.integers(2, 4)),
+        out.append(dict(hidden=int(rng.choice([32, 64, 128])), layers=int(rng.integers(2, 4)),
                         M=int(rng.choice([2, 64, 254, 1000, 1026, 3000])), N=int(rng.choice([2, 3, 5, 12, 30])),
                         is_put=bool(rng.integers(0, 2)), model="heston" if rng.random() < 0.3 else "gbm",
                         S0=float(rng.choice([90.0, 100.0, 110.0])), r=float(rng.choice([0.0, 0.03, 0.08])),

@@ -42,7 +42,7 @@ def _flat_grads(torch, nnr, net):
     return nnr.flatten_params(g)
 
 
-@pytest.mark.parametrize("hidden,layers", [(64, 2), (64, 3), (128, 2), (128, 3)])
+@pytest.mark.parametrize("hidden,layers", [(32, 2), (32, 3), (64, 2), (64, 3), (128, 2), (128, 3)])
 @pytest.mark.parametrize("rows", [32, 100, 1000, 4096, 50_000, 100_000])
 def test_gradients_and_loss_match_autograd(env, ctx, rows, hidden, layers):
     """After ONE Adam step from zero moments, m = (1 - beta1) * (grad + wd * w): the first-moment
@@ -72,7 +72,7 @@ def test_gradients_and_loss_match_autograd(env, ctx, rows, hidden, layers):
     assert torch.allclose(p[big], expect[big], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("hidden,layers", [(64, 2), (128, 3)])
+@pytest.mark.parametrize("hidden,layers", [(32, 3), (64, 2), (128, 3)])
 @pytest.mark.parametrize("rows,bs", [(1, 1), (2, 2), (31, 31), (33, 33), (65, 64), (97, 40), (1500, 1100)])
 def test_ragged_tiny_batches(env, ctx, hidden, layers, rows, bs):
     """Edge sizes: fewer rows than a tile, one row over a tile, ragged last batches, on both kernels
@@ -96,7 +96,8 @@ def test_ragged_tiny_batches(env, ctx, hidden, layers, rows, bs):
     assert loss == pytest.approx(tot / n, rel=1e-4, abs=1e-7)
 
 
-@pytest.mark.parametrize("hidden,layers,bs", [(64, 2, 1000), (64, 3, 1000), (64, 2, 2500), (128, 3, 1000), (128, 2, 2500)])
+@pytest.mark.parametrize("hidden,layers,bs", [(32, 2, 1000), (32, 3, 2500), (64, 2, 1000), (64, 3, 1000), (64, 2, 2500), (128, 3, 1000),
+                                              (128, 2, 2500)])
 def test_many_steps_track_torch_adam(env, ctx, hidden, layers, bs):
     torch, nnr, dev = env
     torch.manual_seed(4)
@@ -291,7 +292,7 @@ def test_pass2_kernel_matches_torch_sweep(env, ctx):
     assert on["pass2"] == "hip"
 
 
-@pytest.mark.parametrize("hidden,layers", [(64, 2), (64, 3), (128, 3)])
+@pytest.mark.parametrize("hidden,layers", [(32, 2), (32, 3), (64, 2), (64, 3), (128, 3)])
 def test_flatten_unflatten_roundtrip(env, hidden, layers):
     torch, nnr, dev = env
     torch.manual_seed(1)
@@ -323,12 +324,15 @@ def test_unsupported_shapes_and_bad_arguments(env, ctx):
     lib = ctx.lib
     assert lib.omc_mlp_param_count(64, 2) == 4737
     assert lib.omc_mlp_param_count(128, 3) == 128 * 8 + 2 * (128 * 128 + 128) + 128 + 1
-    assert lib.omc_mlp_param_count(32, 2) == -1 and lib.omc_mlp_param_count(64, 4) == -1
+    assert lib.omc_mlp_param_count(32, 3) == 32 * 8 + 2 * (32 * 32 + 32) + 32 + 1  # (32 units: round 6)
+    assert lib.omc_mlp_param_count(256, 2) == -1 and lib.omc_mlp_param_count(64, 4) == -1 and lib.omc_mlp_param_count(96, 3) == -1
     d = torch.zeros(64, 8, device=dev)
     p = torch.zeros(4737, device=dev)
-    with pytest.raises(ValueError, match="hidden = 64"):
+    with pytest.raises(ValueError, match="hidden = 32, 64 or 128"):
         ctx.mlp_train_epoch(d.data_ptr(), 64, 64, p.data_ptr(), p.data_ptr(), p.data_ptr(), 0, 1e-3, 0.0, 1,
-                            hidden=32, layers=3)
+                            hidden=256, layers=3)
+    assert lib.omc_mlp_train_supported(32, 3, 256) == 1 and lib.omc_mlp_train_supported(32, 2, 1 << 17) == 1
+    assert lib.omc_mlp_train_supported(256, 3, 256) == 0
     assert lib.omc_mlp_train_supported(128, 3, 8192) == 1 and lib.omc_mlp_train_supported(128, 3, 1 << 20) == 1
     assert lib.omc_mlp_train_supported(64, 2, 1 << 20) == 1 and lib.omc_mlp_train_supported(64, 4, 256) == 0
     with pytest.raises(ValueError, match="dropout"):

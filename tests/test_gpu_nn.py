@@ -301,6 +301,27 @@ def test_a_shape_outside_the_kernels_says_so_once(torch_cuda):
     assert o.info["trainer"] == "hip" and not [x for x in w if "options_model_amd" in str(x.message)]
 
 
+def test_nn_hidden_32_runs_in_the_kernels(torch_cuda):
+    """Round 6: SingleLSMNet(7, 32, 3) -- a width the reference's constructor accepts (options_model_3.py:340-358,
+    nn_hidden) -- trains through mlp_train_quad_kernel<32, 3> and sweeps through mlp_apply_kernel<32, 3>: no PyTorch
+    autograd, no warning; same optimisation problem as the autograd trainer (same rows, same initial weights)."""
+    import warnings
+    from options_model_amd import AdvancedOptionPricer, RNGManager
+    from options_model_amd import nn_regressor as nnr
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        p = AdvancedOptionPricer(K=100, r=0.05, sigma=0.2, option_type="put", rng_manager=RNGManager(42),
+                                 use_control_variate=False, nn_hidden=32)
+        price = p.price_american_option(100.0, 1.0, 10000, 50)
+    info = p.last_result
+    assert info["trainer"] == "hip" and info["trainer_kernel"] == "mlp_train_quad_kernel" and info["pass2"] == "hip"
+    assert 6.3 < price < 7.6 and not [x for x in w if "options_model_amd" in str(x.message)]
+    kw = dict(seed=9, torch_seed=10, nn_hidden=32, nn_layers=3, nn_epochs=8, inference_dropout=False)
+    a = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, nn_trainer="hip", **kw)
+    b = nnr.price_american_option_nn(100.0, 100.0, 0.05, 0.2, 1.0, 20_000, 25, nn_trainer="torch", **kw)
+    assert a.info["best_loss"] == pytest.approx(b.info["best_loss"], rel=1e-2) and abs(a.price - b.price) < 0.8
+
+
 def test_bench_c1nn_line_is_the_references_default_call(torch_cuda):
     """`python bench.py --config c1nn`: ONE JSON line for the reference's default call (3 x 128, minibatch 256, dropout on)
     with the contract's fields, the trainer's MFMA roofline and the reference's own time as the quoted CPU baseline."""

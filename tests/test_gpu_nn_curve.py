@@ -70,6 +70,7 @@ def _curve(monkeypatch, batched, seed=11, **kw):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(nn_hidden=64, nn_epochs=6, use_control_variate=False),
+                                dict(nn_hidden=32, nn_epochs=5, use_control_variate=False),
                                 dict(nn_hidden=64, nn_layers=2, nn_epochs=4, use_heston=True,
                                      heston_params=dict(v0=0.04, kappa=2.0, theta=0.04, xi=0.3, rho=-0.7))])
 def test_nn_curve_batched_equals_point_by_point(torch_cuda, monkeypatch, kw):
