@@ -66,7 +66,7 @@ int main()
     REQUIRE(omc_comm_init(nullptr, 0, 1, small, sizeof small) != 0);
     REQUIRE(omc_mlp_param_count(64, 2) > 0 && omc_mlp_param_count(63, 2) < 0);
     REQUIRE(omc_localvol_param_count(64, 4) > 0);
-    REQUIRE(omc_mlp_train_supported(128, 3, 256) == 1 && omc_mlp_train_supported(32, 2, 256) == 1 && omc_mlp_train_supported(32, 3, 256) == 0 && omc_mlp_train_supported(48, 2, 256) == 0);
+    REQUIRE(omc_mlp_train_supported(128, 3, 256) == 1 && omc_mlp_train_supported(32, 2, 256) == 1 && omc_mlp_train_supported(32, 3, 256) == 1 && omc_mlp_train_supported(48, 2, 256) == 0 && omc_mlp_train_supported(256, 3, 256) == 0);
     // round 5's entry points: which trainer kernel a minibatch runs (host arithmetic), and the failure branches of the rest
     REQUIRE(omc_mlp_train_variant(128, 3, 256) == 4 && omc_mlp_train_variant(128, 3, 4096) == 4 && omc_mlp_train_variant(128, 3, 4097) == 3);
     REQUIRE(omc_mlp_train_variant(128, 3, 8193) == 2 && omc_mlp_train_variant(64, 2, 1024) == 4 && omc_mlp_train_variant(64, 2, 1025) == 1);

@@ -135,6 +135,42 @@ import json; d=json.load(open('gpurun_out/bench_${TAG}_c5.json')); print('c5 ms_
   prof c5 "$R/bench.py" --config c5 --steps 2 --warmup 1 || exit 1
   grep "rows_\|Name" gpurun_out/${TAG}_c5_kernel_stats.csv | cut -c1-200
   ;;
+pmc)  # HBM bytes per launch for c2 (two flows), c3, c4: separate FETCH_SIZE / WRITE_SIZE passes (MI355X_MICROARCH.md)
+  cd /tmp && export TMPDIR=/tmp
+  for CFG in c2 c3 c4; do
+    case $CFG in c2) PPG=1000000; SEMS="two_pass reference";; c3) PPG=8000000; SEMS="two_pass";; c4) PPG=4000000; SEMS="two_pass";; esac
+    for SEM in $SEMS; do
+      EXTRA=""; [ $SEM = reference ] && EXTRA="--group 16 --steps 16"
+      for CTR in FETCH_SIZE WRITE_SIZE; do
+        OUT="$R/gpurun_out/pmc_${TAG}${CFG}${SEM}_$CTR"
+        timeout -k 10 400 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$OUT" -- \
+            python3 "$R/bench.py" --config $CFG --steps 3 --warmup 1 --min-warmup-seconds 0.02 --semantics $SEM $EXTRA --only-timed > /dev/null 2> "$OUT.err"; rc=$?
+        echo "pmc $CFG $SEM $CTR exit=$rc"; ok $rc || exit 1
+      done
+      python3 "$R/tools/summarize_pmc.py" "$R/gpurun_out" "${TAG}${CFG}${SEM}" $CFG $PPG "$TAG" | tee "$R/gpurun_out/pmc_summary_${TAG}_${CFG}_${SEM}.txt"
+      rm -rf "$R/gpurun_out/pmc_${TAG}${CFG}${SEM}_FETCH_SIZE" "$R/gpurun_out/pmc_${TAG}${CFG}${SEM}_WRITE_SIZE"
+    done
+  done
+  ;;
+bench)  # the driver's command, then every config's line, then rocprofv3 kernel stats of the same commands
+  cd "$R"
+  timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_driver.json 2> gpurun_out/bench_${TAG}_driver.err; rc=$?
+  echo "bench (driver's command) exit=$rc"; ok $rc || exit 1
+  timeout -k 10 400 python bench.py --config c3 --steps 10 --warmup 5 --no-variants > gpurun_out/bench_${TAG}_c3.json 2> gpurun_out/bench_${TAG}_c3.err; rc=$?
+  echo "bench c3 exit=$rc"; ok $rc || exit 1
+  timeout -k 10 400 python bench.py --config c4 --steps 20 --warmup 5 --no-variants > gpurun_out/bench_${TAG}_c4.json 2> gpurun_out/bench_${TAG}_c4.err; rc=$?
+  echo "bench c4 exit=$rc"; ok $rc || exit 1
+  timeout -k 10 400 python bench.py --config c5 --steps 3 --warmup 1 > gpurun_out/bench_${TAG}_c5.json 2> gpurun_out/bench_${TAG}_c5.err; rc=$?
+  echo "bench c5 exit=$rc"; ok $rc || exit 1
+  timeout -k 10 400 python bench.py --config c1nn --steps 5 --warmup 2 > gpurun_out/bench_${TAG}_c1nn.json 2> gpurun_out/bench_${TAG}_c1nn.err; rc=$?
+  echo "bench c1nn exit=$rc"; ok $rc || exit 1
+  prof two_pass "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
+  prof reference "$R/bench.py" --gpus 1 --steps 32 --warmup 5 --semantics reference --group 16 --no-cpu-baseline --no-variants --no-sustained || exit 1
+  prof c3 "$R/bench.py" --config c3 --steps 10 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
+  prof c4 "$R/bench.py" --config c4 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
+  prof c5 "$R/bench.py" --config c5 --steps 2 --warmup 1 || exit 1
+  prof c1nn "$R/bench.py" --config c1nn --steps 5 --warmup 2 || exit 1
+  ;;
 tests)
   timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
   tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
