@@ -1785,7 +1785,7 @@ int omc_heston_price_strikes(omc_ctx* c, int64_t n_paths, int n_steps, double S0
     HIP_TRY(omc::launch_payoff_means(c->stream, ST, n_paths, Kd, n_strikes, is_put ? 1 : 0, part, out));
     std::vector<double> h(2 * (size_t)n_strikes);
     HIP_TRY(hipMemcpyAsync(h.data(), out, 2 * k_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = wait_stream(c))) return rc;  // (polling: the call lasts ~0.1 ms)
     const double df = std::exp(-r * T), M = (double)n_paths;
     for (int k = 0; k < n_strikes; ++k) {
         const double mean = h[2 * (size_t)k] / M;
@@ -1820,29 +1820,34 @@ int omc_heston_price_surface(omc_ctx* c, int64_t n_paths, int n_steps, double S0
     for (int q = 0; q < n_quotes; ++q)
         if (expiry_of[q] < 0 || expiry_of[q] >= n_expiries) return fail(-4, "expiry_of[q] must index the expiries.");
     const int64_t ldst = (n_paths + 63) / 64 * 64;
-    const size_t st_bytes = sizeof(float) * (size_t)ldst * (size_t)n_expiries;
+    const size_t st_bytes = (sizeof(float) * (size_t)ldst * (size_t)n_expiries + 255) / 256 * 256;
+    // ONE upload per call: [expiry table | strikes | quote -> expiry] as one host image behind the terminal spots
     const size_t tab_bytes = (omc::heston_surface_table_bytes(n_expiries) + 255) / 256 * 256;
     const size_t k_bytes = sizeof(double) * (size_t)n_quotes, e_bytes = (sizeof(int32_t) * (size_t)n_quotes + 255) / 256 * 256;
-    if ((rc = c->scratch.ensure(st_bytes + 256 + tab_bytes + e_bytes + 3 * k_bytes + omc::payoff_partial_bytes(n_paths, n_quotes)))) return rc;
+    const size_t img_bytes = tab_bytes + (k_bytes + 255) / 256 * 256 + e_bytes;
+    if ((rc = c->scratch.ensure(st_bytes + img_bytes + 2 * k_bytes + 256 + omc::payoff_partial_bytes(n_paths, n_quotes)))) return rc;
     char* base = (char*)c->scratch.p;
     float* ST = (float*)base;
-    void* tab = base + (st_bytes + 255) / 256 * 256;
-    int32_t* eo = (int32_t*)((char*)tab + tab_bytes);
-    double* Kd = (double*)((char*)eo + e_bytes);
-    double* out = Kd + n_quotes;
+    char* img_d = base + st_bytes;
+    const void* tab = img_d;
+    const double* Kd = (const double*)(img_d + tab_bytes);
+    const int32_t* eo = (const int32_t*)(img_d + tab_bytes + (k_bytes + 255) / 256 * 256);
+    double* out = (double*)(img_d + img_bytes);
     double* part = out + 2 * (size_t)n_quotes;
-    // host images that must outlive the asynchronous copies (pageable memory): the context keeps them until the wait below
-    c->h_table.resize(tab_bytes + sizeof(uint32_t) * (size_t)n_expiries);
-    uint32_t* st32 = (uint32_t*)(c->h_table.data() + tab_bytes);
+    // the host image must outlive the asynchronous copy (pageable memory): the context keeps it until the wait below
+    c->h_table.resize(img_bytes + sizeof(uint32_t) * (size_t)n_expiries);
+    char* img_h = c->h_table.data();
+    uint32_t* st32 = (uint32_t*)(img_h + img_bytes);
     for (int e = 0; e < n_expiries; ++e) st32[e] = (uint32_t)streams[e];
-    HIP_TRY(hipMemcpyAsync(Kd, strikes, k_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(eo, expiry_of, sizeof(int32_t) * (size_t)n_quotes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(omc::launch_heston_terminal_surface(c->stream, ST, ldst, n_paths, n_steps, S0, r, expiries, st32, n_expiries, v0,
-                                                kappa, theta, xi, rho, seed, 0, scheme, c->h_table.data(), tab));
+    omc::heston_surface_fill_table(img_h, n_steps, r, expiries, st32, n_expiries, kappa, theta, xi, rho);
+    memcpy(img_h + tab_bytes, strikes, k_bytes);
+    memcpy(img_h + tab_bytes + (k_bytes + 255) / 256 * 256, expiry_of, sizeof(int32_t) * (size_t)n_quotes);
+    HIP_TRY(hipMemcpyAsync(img_d, img_h, img_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(omc::launch_heston_terminal_surface(c->stream, ST, ldst, n_paths, n_steps, S0, n_expiries, v0, seed, 0, scheme, tab));
     HIP_TRY(omc::launch_payoff_means_surface(c->stream, ST, ldst, n_paths, Kd, eo, n_quotes, is_put ? 1 : 0, part, out));
     std::vector<double> h(2 * (size_t)n_quotes);
     HIP_TRY(hipMemcpyAsync(h.data(), out, 2 * k_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = wait_stream(c))) return rc;  // (polling: the call lasts ~0.1 ms)
     const double M = (double)n_paths;
     for (int q = 0; q < n_quotes; ++q) {
         const double df = std::exp(-r * expiries[expiry_of[q]]);

@@ -47,13 +47,14 @@ hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_pat
 size_t payoff_partial_bytes(int64_t n_paths, int n_quotes);
 hipError_t launch_payoff_means(hipStream_t st, const float* ST, int64_t n_paths, const double* K_dev,
                                int n_strikes, int is_put, double* part_dev, double* out_dev);
-// a whole quote surface: the expiry on grid.y (its constants and Philox sub-stream from a 64-byte-per-expiry table that
-// the launcher fills in `tab_host` and copies to `tab_dev`), ST device [n_expiries][ldst]; then one workgroup per quote
+// a whole quote surface: the expiry on grid.y (its constants and Philox sub-stream from a 64-byte-per-expiry table:
+// heston_surface_fill_table makes the host image, the caller copies it), ST device [n_expiries][ldst]; then the quotes
 size_t heston_surface_table_bytes(int n_expiries);
+void heston_surface_fill_table(void* tab_host, int n_steps, double r, const double* T_host, const uint32_t* stream_host,
+                               int n_expiries, double kappa, double theta, double xi, double rho);
 hipError_t launch_heston_terminal_surface(hipStream_t st, float* ST, int64_t ldst, int64_t n_paths, int n_steps, double S0,
-                                          double r, const double* T_host, const uint32_t* stream_host, int n_expiries,
-                                          double v0, double kappa, double theta, double xi, double rho, uint64_t seed,
-                                          uint64_t pair_offset, int scheme, void* tab_host, void* tab_dev);
+                                          int n_expiries, double v0, uint64_t seed, uint64_t pair_offset, int scheme,
+                                          const void* tab_dev);
 hipError_t launch_payoff_means_surface(hipStream_t st, const float* ST, int64_t ldst, int64_t n_paths, const double* K_dev,
                                        const int32_t* expiry_of_dev, int n_quotes, int is_put, double* part_dev, double* out_dev);
 hipError_t launch_philox_kat(hipStream_t st, const uint32_t* in, uint32_t* out, int n);

@@ -359,23 +359,27 @@ hipError_t launch_heston_terminal_store(hipStream_t st, float* ST, int64_t n_pat
 
 size_t heston_surface_table_bytes(int n_expiries) { return sizeof(SurfaceExpiry) * (size_t)(n_expiries > 0 ? n_expiries : 0); }
 
-hipError_t launch_heston_terminal_surface(hipStream_t st, float* ST, int64_t ldst, int64_t n_paths, int n_steps, double S0,
-                                          double r, const double* T_host, const uint32_t* stream_host, int n_expiries,
-                                          double v0, double kappa, double theta, double xi, double rho, uint64_t seed,
-                                          uint64_t pair_offset, int scheme, void* tab_host, void* tab_dev)
+// the per-expiry table image (host): constants of each expiry's time step and its Philox sub-stream
+void heston_surface_fill_table(void* tab_host, int n_steps, double r, const double* T_host, const uint32_t* stream_host,
+                               int n_expiries, double kappa, double theta, double xi, double rho)
 {
-    PathArgs g{};
-    g.P = n_paths / 2; g.n_steps = n_steps; g.s_init = (float)S0; g.v_init = (float)v0;
-    g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.pair_offset = pair_offset;
-    if (g.P <= 0 || n_expiries <= 0) return hipSuccess;
     SurfaceExpiry* h = (SurfaceExpiry*)tab_host;
     for (int e = 0; e < n_expiries; ++e) {
         h[e] = SurfaceExpiry{};
         h[e].hc = make_heston(r, T_host[e], n_steps, kappa, theta, xi, rho);
         h[e].stream = stream_host[e];
     }
-    hipError_t err = hipMemcpyAsync(tab_dev, tab_host, heston_surface_table_bytes(n_expiries), hipMemcpyHostToDevice, st);
-    if (err != hipSuccess) return err;
+}
+
+// (tab_dev: the table image of heston_surface_fill_table, already on the device or queued ahead on `st`)
+hipError_t launch_heston_terminal_surface(hipStream_t st, float* ST, int64_t ldst, int64_t n_paths, int n_steps, double S0,
+                                          int n_expiries, double v0, uint64_t seed, uint64_t pair_offset, int scheme,
+                                          const void* tab_dev)
+{
+    PathArgs g{};
+    g.P = n_paths / 2; g.n_steps = n_steps; g.s_init = (float)S0; g.v_init = (float)v0;
+    g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32); g.pair_offset = pair_offset;
+    if (g.P <= 0 || n_expiries <= 0) return hipSuccess;
     const dim3 grid(grid_for(g.P), (unsigned)n_expiries), block(kBlock);
     const SurfaceExpiry* tab = (const SurfaceExpiry*)tab_dev;
     if (scheme == 0) hipLaunchKernelGGL((heston_terminal_surface_kernel<0>), grid, block, 0, st, ST, ldst, g, tab);

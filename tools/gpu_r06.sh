@@ -164,12 +164,32 @@ bench)  # the driver's command, then every config's line, then rocprofv3 kernel 
   echo "bench c5 exit=$rc"; ok $rc || exit 1
   timeout -k 10 400 python bench.py --config c1nn --steps 5 --warmup 2 > gpurun_out/bench_${TAG}_c1nn.json 2> gpurun_out/bench_${TAG}_c1nn.err; rc=$?
   echo "bench c1nn exit=$rc"; ok $rc || exit 1
-  prof two_pass "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
+  # (the driver's command also runs the config3 block: the SAME kernels on 64M paths.  --stats averages by kernel name, so
+  #  the c2 averages the roofline is recomputed from are taken with --no-config3; the full command's stats beside them)
+  prof two_pass "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained --no-config3 || exit 1
+  prof driver_full "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
   prof reference "$R/bench.py" --gpus 1 --steps 32 --warmup 5 --semantics reference --group 16 --no-cpu-baseline --no-variants --no-sustained || exit 1
   prof c3 "$R/bench.py" --config c3 --steps 10 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
   prof c4 "$R/bench.py" --config c4 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
   prof c5 "$R/bench.py" --config c5 --steps 2 --warmup 1 || exit 1
   prof c1nn "$R/bench.py" --config c1nn --steps 5 --warmup 2 || exit 1
+  ;;
+rows)  # NN pass 1 alone at config 5's size: timing, kernel stats, SQ counters of the two sweeps
+  timeout -k 10 300 python tools/time_rows.py > gpurun_out/${TAG}_rows.json 2> gpurun_out/${TAG}_rows.err; rc=$?
+  cat gpurun_out/${TAG}_rows.json | cut -c1-400; ok $rc || exit 1
+  timeout -k 10 300 python tools/time_rows.py 10000 50 12 > gpurun_out/${TAG}_rows_c1.json 2>> gpurun_out/${TAG}_rows.err; rc=$?
+  cat gpurun_out/${TAG}_rows_c1.json | cut -c1-300; ok $rc || exit 1
+  prof rows "$R/tools/time_rows.py" || exit 1
+  pmc "rows_a" "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "$R/tools/time_rows.py" 1000000 252 2 || exit 1
+  pmc "rows_b" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS" "$R/tools/time_rows.py" 1000000 252 2 || exit 1
+  pmc "rows_c" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "$R/tools/time_rows.py" 1000000 252 2 || exit 1
+  python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_rows_" | grep -A40 "^rows_" | tee "$R/gpurun_out/${TAG}_pmc_rows.txt" | head -90
+  for d in "$R"/gpurun_out/pmc_${TAG}_rows_*; do [ -d "$d" ] && rm -rf "$d"; done
+  true
+  ;;
+prof2)  # the c2 kernel averages without the config3 block mixed in, and the driver's full command beside them
+  prof two_pass "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained --no-config3 || exit 1
+  prof driver_full "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
   ;;
 tests)
   timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
