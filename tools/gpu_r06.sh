@@ -191,6 +191,11 @@ prof2)  # the c2 kernel averages without the config3 block mixed in, and the dri
   prof two_pass "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained --no-config3 || exit 1
   prof driver_full "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-sustained || exit 1
   ;;
+rowstest)  # the NN pass-1 kernels against the oracle (quirks, ragged sizes, config 5's size, fuzz), then their timing
+  timeout -k 10 900 python -m pytest tests/test_gpu_nn.py tests/test_gpu_nn_full.py tests/test_gpu_quirks.py tests/test_gpu_fuzz.py tests/test_gpu_nn_dist.py tests/test_gpu_ols7.py -x -q -m gpu -k "rows or normalis or quirk or pass1 or config5 or full or sharded or collective" --durations=5 > gpurun_out/${TAG}_rows_tests.log 2>&1; rc=$?
+  tail -12 gpurun_out/${TAG}_rows_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
+  [ $rc -eq 0 ] || exit 1
+  ;;
 tests)
   timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
   tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
