@@ -18,6 +18,12 @@ BEFORE this process makes any GPU call; under `python -m torch.distributed.run` 
 launcher's.  Either way: world size must equal --gpus, the node must have that many devices, and
 the JSON carries the communicator's own rank count (`rccl_ranks`).
 
+Every default line (`--config c2`, two-pass flow; N = 1 included) also carries a `config3` block: BASELINE configs[2] ITSELF
+-- 64M paths x 252 steps in total, sharded over the job's N ranks (8M per GPU at N = 8), strong scaling -- timed through the
+job's communicator, with every rank's communicator-free time on its own shard and rank 0's time for the whole problem on
+one card beside it: `scaling_efficiency`, `speedup_vs_one_gpu`, and the sharded price checked against the one-GPU price
+(config3_block below; `--no-config3` / `--config3-paths` / `--config3-steps`).  The headline stays configs[1] per GPU.
+
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline          the dominant kernel (largest time share): algorithmic bytes per launch / mean
                     HIP-event duration of that launch inside the timed region, vs 8 TB/s HBM peak
@@ -27,6 +33,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
   price_check       GPU vs CPU oracle on the SAME Philox (seed, stream), bounded slice
   sustained         >= 3 s of back-to-back pricings (steady clocks), same kernels
   cpu_baseline      the C oracle (oracle/, a port: the reference is Python) on this host
+  config3           BASELINE configs[2] on this job's ranks (see above)
 """
 import argparse
 import json

@@ -336,7 +336,7 @@ int omc_lsm_apply_mlp_shard(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_
  * around centres shared by a workgroup (its first spot over the strike; sqrt(tau) of its first step), added over its lanes
  * in a fixed order, turned into (n, mean, M2) triples per workgroup and merged by Chan's formula in a fixed two-level
  * tree: the two-pass values of :550-563 to ~1e-14, a constant column's variance exactly 0 -- and one sweep writes the
- * rows.  The count call (data == NULL) makes the first sweep and leaves its results in the context; the call with `data`
+ * rows (records staged through LDS, contiguous 16-byte stores).  The count call (data == NULL) makes the first sweep and leaves its results in the context; the call with `data`
  * starts from them when it is the NEXT call on this context with the same arguments and S has not been written in
  * between (any other call on the context drops them, and the call with `data` then sweeps again itself). */
 int omc_nn_build_rows(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_paths, int n_steps, double K,

@@ -12,7 +12,8 @@
   8. the rows of NN pass 1 (count, order, normalisers, float32 matrix) against the numpy restatement;
   9. curve batches (American and European) == single calls;
  10. the calibrator's inner Monte-Carlo (one expiry, many strikes) against the C oracle's terminal spots;
- 11. the local-vol simulator with random IV networks against the per-step PyTorch evaluation.
+ 11. the local-vol simulator with random IV networks against the per-step PyTorch evaluation;
+ 12. a whole quote surface in one launch set == its per-expiry calls, bit for bit (round 6).
 
 OMC_FUZZ_SCALE multiplies every sweep's case count and OMC_FUZZ_SEED shifts its seed: soak runs (profiles/r05_fuzz_soak.txt:
 what they found -- exact ties, ill-conditioned fits, units on their ReLU kink, an ill-conditioned recurrence -- and how
@@ -498,6 +499,44 @@ def test_calibrator_inner_monte_carlo_matches_the_oracle(ctx, case):
     tol = 1e-4 * np.abs(ref) + 1e-4 * c["S0"] * 0.5 + (0.25 * errs if touches_zero else 0.0)
     assert np.all(np.abs(prices - ref) <= tol), float(np.abs(prices - ref).max())
     assert np.all(np.isfinite(errs)) and np.all(errs >= 0)
+
+
+def _surface_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append(dict(M=int(rng.choice([2, 64, 1026, 4096, 4098, 20_000, 100_000])), N=int(rng.choice([1, 2, 7, 33, 100])),
+                        S0=float(rng.uniform(50, 150)), r=float(rng.choice([0.0, 0.03, 0.08])), n_exp=int(rng.integers(1, 9)),
+                        v0=float(rng.choice([0.0, 0.01, 0.04, 0.25])), kappa=float(rng.uniform(0.1, 5.0)),
+                        theta=float(rng.choice([0.01, 0.04, 0.2])), xi=float(rng.choice([0.0, 0.1, 0.6, 1.5])),
+                        rho=float(rng.choice([-0.99, -0.7, 0.0, 0.5, 0.99])), scheme=int(rng.integers(0, 3)), is_put=bool(rng.integers(0, 2)),
+                        max_k=int(rng.integers(1, 25)), seed=int(rng.integers(1, 2 ** 31)), stream0=int(rng.integers(0, 1000))))
+    return out
+
+
+@pytest.mark.parametrize("case", _surface_cases(12 * _SCALE, 2626 + _SHIFT), ids=lambda c: f"s{c['scheme']}-{c['M']}x{c['N']}-e{c['n_exp']}")
+def test_quote_surface_equals_its_per_expiry_calls(ctx, case):
+    """Round 6 (SURVEY f-3, heston_calibration.py:283-312): omc_heston_price_surface -- every expiry simulated by one launch,
+    every quote reduced by one more -- against one omc_heston_price_strikes call per expiry on the same Philox sub-streams:
+    prices AND standard errors bit for bit, over random parameters, schemes, path counts around the reduction's chunk size
+    (4,096), 1 .. 8 expiries with ragged strike counts, quotes in random order."""
+    c = case
+    rng = np.random.default_rng(c["seed"])
+    T = np.sort(rng.uniform(0.02, 2.0, c["n_exp"]))
+    quotes = [(e, k) for e in range(c["n_exp"]) for k in rng.uniform(0.5 * c["S0"], 1.5 * c["S0"], rng.integers(1, c["max_k"] + 1))]
+    order = rng.permutation(len(quotes))
+    eo = np.array([quotes[i][0] for i in order], np.int32)
+    K = np.array([quotes[i][1] for i in order])
+    M = c["M"] // 2 * 2
+    streams = c["stream0"] + np.arange(c["n_exp"])
+    a = (c["v0"], c["kappa"], c["theta"], c["xi"], c["rho"])
+    got, err = ctx.heston_price_surface(M, c["N"], c["S0"], c["r"], *a, T, streams, K, eo, is_put=c["is_put"], seed=c["seed"],
+                                        scheme=c["scheme"])
+    for e in range(c["n_exp"]):
+        m = eo == e
+        one, one_err = ctx.heston_price_strikes(M, c["N"], c["S0"], c["r"], float(T[e]), *a, K[m], is_put=c["is_put"], seed=c["seed"],
+                                                stream=int(streams[e]), scheme=c["scheme"])
+        assert np.array_equal(got[m], one) and np.array_equal(err[m], one_err), e
 
 
 def _localvol_cases(n, seed):

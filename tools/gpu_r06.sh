@@ -196,6 +196,10 @@ rowstest)  # the NN pass-1 kernels against the oracle (quirks, ragged sizes, con
   tail -12 gpurun_out/${TAG}_rows_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
   [ $rc -eq 0 ] || exit 1
   ;;
+soak)  # the seeded fuzz sweeps against the C oracle, 30 (or $4) times as many cases from seeds shifted by $3 (one process, no -x: count every failure)
+  OMC_FUZZ_SCALE=${4:-30} OMC_FUZZ_SEED=${3:-1000} timeout -k 10 1100 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -p no:cacheprovider > gpurun_out/${TAG}_fuzz_soak.log 2>&1; rc=$?
+  grep -v "^[.s]*\( *\[ *[0-9]*%\]\)\?$" gpurun_out/${TAG}_fuzz_soak.log | tail -40; echo "pytest exit=$rc"
+  ;;
 tests)
   timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
   tail -25 gpurun_out/${TAG}_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
