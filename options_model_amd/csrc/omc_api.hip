@@ -1772,6 +1772,7 @@ int omc_heston_price_strikes(omc_ctx* c, int64_t n_paths, int n_steps, double S0
     if (scheme < 0 || scheme > 2) return fail(-4, "unknown Heston scheme.");
     if (!(rho >= -1.0 && rho <= 1.0) || !(v0 >= 0)) return fail(-5, "invalid Heston parameters.");
     if (!strikes || !prices || n_strikes <= 0) return fail(-7, "bad strike arguments.");
+    if (n_paths > (int64_t)65535 * 4096) return fail(-3, "at most 268,431,360 paths per expiry.");
     const size_t st_bytes = sizeof(float) * (size_t)n_paths;
     const size_t k_bytes = sizeof(double) * (size_t)n_strikes;
     if ((rc = c->scratch.ensure(st_bytes + 256 + 3 * k_bytes + omc::payoff_partial_bytes(n_paths, n_strikes)))) return rc;
@@ -1815,6 +1816,7 @@ int omc_heston_price_surface(omc_ctx* c, int64_t n_paths, int n_steps, double S0
     if (!(rho >= -1.0 && rho <= 1.0) || !(v0 >= 0)) return fail(-5, "invalid Heston parameters.");
     if (!expiries || !streams || n_expiries <= 0 || n_expiries > 65535) return fail(-7, "bad expiry arguments (1 .. 65535 expiries).");
     if (!strikes || !expiry_of || !prices || n_quotes <= 0) return fail(-7, "bad strike arguments.");
+    if (n_paths > (int64_t)65535 * 4096) return fail(-3, "at most 268,431,360 paths per expiry.");
     for (int e = 0; e < n_expiries; ++e)
         if (!(expiries[e] > 0)) return fail(-1, "S0, K, T must be positive.");
     for (int q = 0; q < n_quotes; ++q)

@@ -286,13 +286,13 @@ __global__ __launch_bounds__(kBlock) void heston_terminal_surface_kernel(float* 
 constexpr int kPayChunk = 4096;
 
 __device__ __forceinline__ void payoff_chunk_body(const float* __restrict__ ST, int64_t M, double k, int is_put,
-                                                  double* __restrict__ out2)
+                                                  const int chunk, double* __restrict__ out2)
 {
     __shared__ double red[kNQ * kRedStride];
     double acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-    const int64_t lo = (int64_t)blockIdx.x * kPayChunk, hi = lo + kPayChunk < M ? lo + kPayChunk : M;
+    const int64_t lo = (int64_t)chunk * kPayChunk, hi = lo + kPayChunk < M ? lo + kPayChunk : M;
     float sv[kPayChunk / kBlock];
 #pragma unroll
     for (int i = 0; i < kPayChunk / kBlock; ++i) {  // every load of the chunk in flight before the first use
@@ -311,12 +311,12 @@ __device__ __forceinline__ void payoff_chunk_body(const float* __restrict__ ST, 
     if (threadIdx.x < 64 && (threadIdx.x & 7) == 0 && (threadIdx.x >> 3) < 2) out2[threadIdx.x >> 3] = s;
 }
 
-// part[quote][chunk][2]
+// part[quote][chunk][2]; grid (quotes, chunks): the quote on x (any number of them), the chunk on y (<= 65,535: 2.7e8 paths)
 __global__ __launch_bounds__(kBlock) void payoff_partial_kernel(const float* __restrict__ ST, int64_t M,
                                                                 const double* __restrict__ K, int is_put,
                                                                 double* __restrict__ part)
 {
-    payoff_chunk_body(ST, M, K[blockIdx.y], is_put, part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+    payoff_chunk_body(ST, M, K[blockIdx.x], is_put, (int)blockIdx.y, part + 2 * ((size_t)blockIdx.x * gridDim.y + blockIdx.y));
 }
 
 __global__ __launch_bounds__(kBlock) void payoff_partial_surface_kernel(const float* __restrict__ ST, int64_t ldst, int64_t M,
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(kBlock) void payoff_partial_surface_kernel(const fl
                                                                         const int32_t* __restrict__ expiry_of, int is_put,
                                                                         double* __restrict__ part)
 {
-    payoff_chunk_body(ST + (int64_t)expiry_of[blockIdx.y] * ldst, M, K[blockIdx.y], is_put,
-                      part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+    payoff_chunk_body(ST + (int64_t)expiry_of[blockIdx.x] * ldst, M, K[blockIdx.x], is_put, (int)blockIdx.y,
+                      part + 2 * ((size_t)blockIdx.x * gridDim.y + blockIdx.y));
 }
 
 // out[quote][2] = the chunks' sums added in chunk order
@@ -399,7 +399,7 @@ hipError_t launch_payoff_means_surface(hipStream_t st, const float* ST, int64_t 
 {
     if (n_quotes <= 0) return hipSuccess;
     const int nchunks = (int)((n_paths + kPayChunk - 1) / kPayChunk);
-    hipLaunchKernelGGL(payoff_partial_surface_kernel, dim3(nchunks, n_quotes), dim3(kBlock), 0, st, ST, ldst, n_paths, K_dev,
+    hipLaunchKernelGGL(payoff_partial_surface_kernel, dim3(n_quotes, nchunks), dim3(kBlock), 0, st, ST, ldst, n_paths, K_dev,
                        expiry_of_dev, is_put, part_dev);
     hipLaunchKernelGGL(payoff_final_kernel, dim3((2 * n_quotes + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
                        (const double*)part_dev, nchunks, n_quotes, out_dev);
@@ -411,7 +411,7 @@ hipError_t launch_payoff_means(hipStream_t st, const float* ST, int64_t n_paths,
 {
     if (n_strikes <= 0) return hipSuccess;
     const int nchunks = (int)((n_paths + kPayChunk - 1) / kPayChunk);
-    hipLaunchKernelGGL(payoff_partial_kernel, dim3(nchunks, n_strikes), dim3(kBlock), 0, st, ST, n_paths, K_dev, is_put, part_dev);
+    hipLaunchKernelGGL(payoff_partial_kernel, dim3(n_strikes, nchunks), dim3(kBlock), 0, st, ST, n_paths, K_dev, is_put, part_dev);
     hipLaunchKernelGGL(payoff_final_kernel, dim3((2 * n_strikes + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
                        (const double*)part_dev, nchunks, n_strikes, out_dev);
     return hipGetLastError();

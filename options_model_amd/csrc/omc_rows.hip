@@ -203,13 +203,13 @@ __device__ __forceinline__ void trip_block_merge(Trip& t, double* lds)
 //   * in the money <=> a float32 compare against the threshold of the polynomial pass 1 (exactly payoff > 0 in float64),
 //     the count on the scalar unit (popcount of the compare mask);
 //   * sqrt(tau) and the discount factor of the step from a table in LDS (32 entries per workgroup);
-//   * POWER SUMS of u = x - c around a centre c that is uniform in the workgroup (the spot of its first path at its
-//     first step, over the strike) -- sum u .. u^6, and with e = s_t - s_t0 (uniform per step): sum e, e^2, u e, u^2 e,
-//     u e^2, u^2 e^2 --, raw sums of y and max(x-1, 0): 17 accumulators, 24 fused operations.  Centres shared by the
-//     workgroup let the lanes' sums be ADDED (three fixed-order block reductions) instead of merged; one thread turns
-//     the workgroup's sums into (n, mean, M2) of the seven quantities by the binomial expansions below.
-// A constant column still has variance exactly 0 where the reference's rule needs it (:562): max(x-1,0) of a put is a
-// sum of exact zeros; s on a one-step problem has e = 0 throughout; identical spots give u = 0 throughout.  Float64
+//   * POWER SUMS around the workgroup's FIRST ROW (x_c, s_c, y_c, max(x_c - 1, 0): uniform in the workgroup) -- sum u .. u^6
+//     of u = x - x_c, and with e = s_t - s_c (uniform per step): sum e, e^2, u e, u^2 e, u e^2, u^2 e^2 --, sums and squares
+//     of y - y_c and of max(x-1, 0) - its centre: 17 accumulators, 26 fused operations.  Centres shared by the workgroup
+//     let the lanes' sums be ADDED (three fixed-order block reductions) instead of merged; one thread turns the
+//     workgroup's sums into (n, mean, M2) of the seven quantities by the binomial expansions below.
+// A constant column still has variance exactly 0 where the reference's rule needs it (:562): the centre is one of the
+// rows, so rows that agree in a quantity have deviation 0 in it throughout and every sum involved is an exact 0.  Float64
 // throughout; deterministic (fixed summation trees); agrees with the two-pass statistics to ~1e-14 relative (the sums are
 // centred inside the workgroup's own data, so the expansions cancel at most a digit).
 constexpr int kNS = 17;  // n U1 U2 U3 U4 U5 U6 UE U2E UE2 U2E2 ME ME2 Y Y2 MX MX2
@@ -217,9 +217,10 @@ __global__ __launch_bounds__(kBlock) void rows_count_stats_kernel(RowsArgs a, in
 {
     __shared__ int wsum[kTChunk][kBlock / 64];
     __shared__ double red[kNQ * kRedStride];
-    __shared__ double tab[3][kTChunk];  // e_t = s_t - s_t0, g = discount, (spare)
+    __shared__ double tab[2][kTChunk];  // s_t = sqrt(tau_t), discount factor
     __shared__ double tot[24];
-    __shared__ double centre[2];        // c (x of the first path at t0), s_t0
+    __shared__ double centre[4];        // x, s, y, max(x - 1, 0) of the workgroup's FIRST row
+    __shared__ unsigned ckey;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int64_t p = (int64_t)tile * kBlock + tid;
@@ -233,33 +234,56 @@ __global__ __launch_bounds__(kBlock) void rows_count_stats_kernel(RowsArgs a, in
     const double invK = 1.0 / a.K;
     if (tid < kTChunk) {
         const int t = min(t0 + tid, a.N - 1);
-        const double s0 = sqrt(fmax(a.T - (double)t0 * a.dt, 1e-6));
-        tab[0][tid] = sqrt(fmax(a.T - (double)t * a.dt, 1e-6)) - s0;
+        tab[0][tid] = sqrt(fmax(a.T - (double)t * a.dt, 1e-6));
         tab[1][tid] = a.D[a.N - t];
-        if (tid == 0) {
-            centre[0] = (double)sv[0] * invK;
-            centre[1] = s0;
-        }
+        if (tid == 0) ckey = 0xFFFFFFFFu;
     }
-    __syncthreads();
-    const double c = centre[0];
     const float thr = live ? itm_threshold(a.K, a.is_put) : (a.is_put ? -__builtin_inff() : __builtin_inff());
     const bool is_put = a.is_put != 0;
+    // which of the lane's 32 steps are in the money; the workgroup's centre = its FIRST row (lowest thread that has one, at
+    // that thread's first step): a real row, so that rows which are constant in a quantity -- one row in all, one time step,
+    // identical spots or targets -- have deviation 0 EXACTLY and the variance comes out as a true zero (the reference's
+    // "zero std -> 1" rule, :562; a centre outside the data left rounding noise of 1e-16 there: soak r06)
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < kTChunk; ++i) bits |= (uint32_t)((is_put ? sv[i] < thr : sv[i] > thr) && t0 + i < t1) << i;
+    __syncthreads();
+    {
+        const uint64_t has = __builtin_amdgcn_ballot_w64(bits != 0u);
+        if (has != 0ull && lane == (int)__builtin_ctzll(has)) atomicMin(&ckey, ((unsigned)tid << 5) | (unsigned)__builtin_ctz(bits));
+    }
+    __syncthreads();
+    const unsigned ck = ckey;
+    if (ck != 0xFFFFFFFFu && tid == (int)(ck >> 5)) {
+        const int i0 = (int)(ck & 31u);
+        float sc32 = sv[0];
+#pragma unroll
+        for (int i = 1; i < kTChunk; ++i) sc32 = i == i0 ? sv[i] : sc32;
+        const double xc = (double)sc32 * invK;
+        centre[0] = xc;
+        centre[1] = tab[0][i0];
+        centre[2] = payN * tab[1][i0];
+        centre[3] = fmax(fma((double)sc32, invK, -1.0), 0.0);
+    } else if (ck == 0xFFFFFFFFu && tid == 0) {
+        centre[0] = centre[1] = centre[2] = centre[3] = 0.0;  // no row in this workgroup: every sum below stays 0
+    }
+    __syncthreads();
+    const double c = centre[0], sc = centre[1], yc = centre[2], cmx = centre[3];
     double acc[kNS];
 #pragma unroll
     for (int q = 0; q < kNS; ++q) acc[q] = 0.0;
 #pragma unroll 4
     for (int i = 0; i < kTChunk; ++i) {
         const float s = sv[i];
-        const bool f = (is_put ? s < thr : s > thr) && t0 + i < t1;
+        const bool f = (bits >> i) & 1u;
         const int wc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
         if (lane == 0) wsum[i][wave] = wc;
         const double m = f ? 1.0 : 0.0;          // (masking by multiplication: u m and y m are exact)
-        const double e = tab[0][i], g = tab[1][i];
+        const double e = tab[0][i] - sc, g = tab[1][i];
         const double x1 = fma((double)s, invK, -1.0);
         const double u = fma((double)s, invK, -c) * m;
-        const double mx = fmax(x1, 0.0) * m;
-        const double y = payN * g * m;
+        const double mx = (fmax(x1, 0.0) - cmx) * m;
+        const double y = fma(payN, g, -yc) * m;
         const double u2 = u * u, u3 = u2 * u, ue = u * e, me = m * e;
         acc[0] += m;
         acc[1] += u;
@@ -301,17 +325,17 @@ __global__ __launch_bounds__(kBlock) void rows_count_stats_kernel(RowsArgs a, in
     }
     const double U1 = tot[1], U2 = tot[2], U3 = tot[3], U4 = tot[4], U5 = tot[5], U6 = tot[6], UE = tot[7], U2E = tot[8],
                  UE2 = tot[9], U2E2 = tot[10], ME = tot[11], ME2 = tot[12], Y = tot[13], Y2 = tot[14], MX = tot[15], MX2 = tot[16];
-    const double sc = centre[1], inv = 1.0 / n, c2 = c * c, c3 = c2 * c, c4 = c2 * c2;
+    const double inv = 1.0 / n, c2 = c * c, c3 = c2 * c, c4 = c2 * c2;
     double sd[7], sq[7], base[7];  // sum of deviations from `base`, sum of their squares
     base[0] = c;       sd[0] = U1;                              sq[0] = U2;
     base[1] = c2;      sd[1] = 2.0 * c * U1 + U2;               sq[1] = 4.0 * c2 * U2 + 4.0 * c * U3 + U4;
     base[2] = c3;      sd[2] = 3.0 * c2 * U1 + 3.0 * c * U2 + U3;
     sq[2] = 9.0 * c4 * U2 + 18.0 * c3 * U3 + 15.0 * c2 * U4 + 6.0 * c * U5 + U6;
-    base[3] = 0.0;     sd[3] = MX;                              sq[3] = MX2;
+    base[3] = cmx;     sd[3] = MX;                              sq[3] = MX2;
     base[4] = sc;      sd[4] = ME;                              sq[4] = ME2;
     base[5] = c * sc;  sd[5] = c * ME + sc * U1 + UE;
     sq[5] = c2 * ME2 + sc * sc * U2 + U2E2 + 2.0 * c * sc * UE + 2.0 * c * UE2 + 2.0 * sc * U2E;
-    base[6] = 0.0;     sd[6] = Y;                               sq[6] = Y2;
+    base[6] = yc;      sd[6] = Y;                               sq[6] = Y2;
     o[0] = n;
 #pragma unroll
     for (int q = 0; q < 7; ++q) {

@@ -151,3 +151,19 @@ def test_heston_pricer_batch_is_the_surface_call_with_the_loops_bits(ctx):
     # a failure is the reference's behaviour: a warning on stdout and nan, never an exception (:308-310)
     bad = a.price_options_batch(SimpleNamespace(kappa=2.0), 100.0, K[:3], T[:3], 0.03)
     assert np.isnan(bad).all() and a.price_options_batch(prm, 100.0, [], [], 0.03).shape == (0,)
+
+
+def test_surface_with_more_quotes_than_a_grid_dimension(ctx):
+    """70,000 quotes over two expiries (the quote sits on grid.x of the reduction: any number; the chunk on grid.y): a
+    sample of them against their single-expiry calls, bit for bit."""
+    rng = np.random.default_rng(2)
+    T = np.array([0.3, 1.1])
+    eo = rng.integers(0, 2, 70_000).astype(np.int32)
+    K = rng.uniform(70.0, 140.0, 70_000)
+    a = (100.0, 0.02, 0.04, 1.5, 0.05, 0.4, -0.5)
+    got, err = ctx.heston_price_surface(6000, 20, *a, T, [7, 8], K, eo, seed=5, scheme=2)
+    assert got.shape == (70_000,) and np.all(np.isfinite(got)) and np.all(err >= 0)
+    for e in (0, 1):
+        idx = np.flatnonzero(eo == e)[::997]
+        one, one_err = ctx.heston_price_strikes(6000, 20, a[0], a[1], float(T[e]), *a[2:], K[idx], seed=5, stream=7 + e, scheme=2)
+        assert np.array_equal(got[idx], one) and np.array_equal(err[idx], one_err)
