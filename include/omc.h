@@ -333,7 +333,7 @@ int omc_lsm_apply_mlp_shard(omc_ctx* ctx, const float* S, int64_t ld, int64_t n_
  * rank's own, 3102 on its peers -- instead of leaving them inside a collective; a job without any in-the-money row
  * returns the default statistics (means 0, stds 1) on every rank.
  * S is read twice IN ALL: one sweep counts the rows of every (step, 256-path tile) and forms the statistics -- power sums
- * around centres shared by a workgroup (its first spot over the strike; sqrt(tau) of its first step), added over its lanes
+ * around a workgroup's first row (a real row: a column that is constant has deviation 0 exactly), added over its lanes
  * in a fixed order, turned into (n, mean, M2) triples per workgroup and merged by Chan's formula in a fixed two-level
  * tree: the two-pass values of :550-563 to ~1e-14, a constant column's variance exactly 0 -- and one sweep writes the
  * rows (records staged through LDS, contiguous 16-byte stores).  The count call (data == NULL) makes the first sweep and leaves its results in the context; the call with `data`

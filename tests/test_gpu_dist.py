@@ -218,6 +218,10 @@ def test_bench_gpus_2_starts_its_own_ranks(ctx):
     ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=200000, n_steps=50, seed=42, stream=1))
     assert d["price"] == pytest.approx(ref["price"], rel=1e-10)
     assert d["price_check"]["rel_err"] < 1e-3 and d["price_check"]["same_stream"]
+    # the config3 block through the torch.distributed hook transport too: 64 x the headline's paths, sharded two ways
+    c3 = d["config3"]
+    assert (c3["total_paths"], c3["paths_per_gpu"], c3["n_gpus"]) == (6_400_000, 3_200_000, 2) and c3["comm"].startswith("torch.distributed gloo")
+    assert c3["price_equals_one_gpu"] is True and len(c3["shard_alone_ms"]) == 2 and c3["speedup_vs_one_gpu"] > 0
     # the per-step flow went through the 2-rank exchange too
     ps = d["roofline_per_step"]  # (several pricings per launch: K moment vectors per collective)
     ref2 = ctx.price_american(_ffi.make_params(semantics="reference", n_paths=200000, n_steps=50, seed=42,
