@@ -240,7 +240,9 @@ def bench_c1nn(a) -> int:
                                    "(the reference does not travel to the GPU box)"},
         "price": price, "prices": prices, "stderr": o.get("stderr"), "rows": o.get("R"),
         "info": {k: o.get(k) for k in ("trainer", "trainer_kernel", "pass2", "rows", "batch", "epochs_run", "optimizer_steps", "best_loss")},
-        "timings_ms": {k[len("seconds_"):]: round(1e3 * v, 3) for k, v in o.items() if k.startswith("seconds_")},
+        # (median over the timed pricings: the first one after a change of row count pays the row tensor's allocation)
+        "timings_ms": {k[len("seconds_"):]: round(1e3 * sorted(x.get(k, 0.0) for _, x in outs)[len(outs) // 2], 3)
+                       for k in o if k.startswith("seconds_")},
         "price_check": "tests/test_gpu_nn.py::test_config1_nn_end_to_end_band (the reference's own seed band: 6.81 - 7.29), "
                        "tests/test_gpu_dropout.py (trainer and pass 2 under the oracle's masks)",
     }
@@ -277,7 +279,7 @@ def config3_block(a, _ffi, ctx, pricer, rank, world, local_rank, N, kw, barrier,
     out = {"workload": f"GBM American put, S0=K=100 r=0.05 sigma=0.2 T=1, {total} paths x {N} steps in TOTAL, path-sharded over "
                        f"{world} rank(s) ({M3} per GPU), polynomial LSM (two_pass flow): BASELINE configs[2]",
            "baseline_config": "c3 (configs[2])", "total_paths": total, "paths_per_gpu": M3, "n_steps": N, "n_gpus": world,
-           "steps": K3, "warmup": W3, "scaling": "strong", "unit": "path-steps/s"}
+           "steps": K3, "warmup": W3, "scaling": "strong", "unit": "path-steps/s", "storage": a.storage}
     if pricer is None:  # one rank: the one-GPU leg IS the job
         def run1(s):
             return ctx.price_american_seq([_ffi.make_params(n_paths=total, pair_offset=0, stream=i, **kw3) for i in s])
@@ -298,6 +300,7 @@ def config3_block(a, _ffi, ctx, pricer, rank, world, local_rank, N, kw, barrier,
     from options_model_amd import dist as omc_dist
     n_local, off = omc_dist.shard(total, world, rank)
     alone = _ffi.Context(local_rank)
+    alone.set_option("fold_antithetic", 1 if a.storage == "folded" else 0)
     try:
         def run_alone(s):
             return alone.price_american_seq([_ffi.make_params(n_paths=n_local, pair_offset=off, stream=i, **kw3) for i in s])
@@ -323,6 +326,7 @@ def config3_block(a, _ffi, ctx, pricer, rank, world, local_rank, N, kw, barrier,
     if rank == 0:
         try:
             solo = _ffi.Context(local_rank)
+            solo.set_option("fold_antithetic", 1 if a.storage == "folded" else 0)
             try:
                 def run_solo(s):
                     return solo.price_american_seq([_ffi.make_params(n_paths=total, pair_offset=0, stream=i, **kw3) for i in s])
@@ -364,6 +368,12 @@ def main():
     ap.add_argument("--n-steps", type=int, default=252)
     ap.add_argument("--semantics", default="two_pass", choices=["two_pass", "reference", "textbook"])
     ap.add_argument("--model", default=None, choices=["gbm", "heston"], help="override the config's model")
+    ap.add_argument("--storage", default="folded", choices=["folded", "full"],
+                    help="how the fused pricing keeps antithetic GBM paths in the two-pass flow: 'folded' (library default: "
+                         "only the first partner of every pair is stored, the partner is priced from the same spot through "
+                         "S_t S'_t = S0^2 exp(2 drift t)) or 'full' (both partners stored, the layout of rounds 1-5)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="omc_set_option on the pricing context before anything runs (experiments; repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-sustained", action="store_true")
@@ -495,6 +505,10 @@ def main():
         ctx = _ffi.Context(local_rank)
         barrier = lambda: None  # noqa: E731
         rccl_ranks = 0
+
+    ctx.set_option("fold_antithetic", 1 if a.storage == "folded" else 0)
+    for kv in a.option:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     def params(sem, stream, n_paths=M, pair_offset=0):
         return _ffi.make_params(model=model, is_put=is_put, semantics=sem, n_steps=N, seed=42, stream=stream,
@@ -632,8 +646,11 @@ def main():
         elapsed = pricer.allreduce_max(elapsed)
     ctx.set_option("seq_event_stride", 0)
 
-    b_gen = 4.0 * (N + 1) * M
-    b_lsm = lsm_algorithmic_bytes(a.semantics, M, N)
+    # folded storage (omc_result.folded): half the matrix is written and read -- the algorithmic bytes of every kernel halve
+    folded = bool(last_out.get("folded"))
+    cols = M // 2 if folded else M
+    b_gen = 4.0 * (N + 1) * cols
+    b_lsm = lsm_algorithmic_bytes(a.semantics, cols, N)
     line = {
         "metric": "paths x steps / sec (whole American pricing: path-gen + LSM + mean)",
         "value": world * M * N * a.steps / elapsed,
@@ -648,6 +665,9 @@ def main():
                    "baseline_config": a.config, "paths_per_gpu": M, "n_steps": N, "semantics": a.semantics,
                    "parallelism": f"path-sharded x{world}" if world > 1 else "single GPU",
                    "rng": "Philox4x32-10 + Box-Muller, antithetic",
+                   "storage": ("antithetic-folded: [n_steps+1][n_paths/2] float32, first partner of every pair; the partner's "
+                               "moneyness is (C_t/K)/S_t - 1 in float64 (include/omc.h, option fold_antithetic)") if folded
+                              else "full: [n_steps+1][n_paths] float32, both partners of every pair",
                    "arithmetic": "f32 paths, f64 moments / solve / decisions / sums"},
         "paths_x252_per_sec_per_gpu": M * N * a.steps / elapsed / 252.0,
         "price": price, "price_stream": last_stream,
@@ -673,8 +693,8 @@ def main():
 
     kernels = [rf(f"{model}_paths_kernel", b_gen, ms_paths)]
     if a.semantics == "two_pass":
-        kernels.append(rf("lsm_pass1_kernel", 4.0 * M * N, ms_p1))  # rows 1..N-1 + terminal row
-        kernels.append(rf("lsm_pass2_kernel", 4.0 * M * N, ms_p2))  # rows N..1 (upper bound)
+        kernels.append(rf("lsm_pass1_fold_kernel" if folded else "lsm_pass1_kernel", 4.0 * cols * N, ms_p1))  # rows 1..N-1 + terminal row
+        kernels.append(rf("lsm_pass2_fold_kernel" if folded else "lsm_pass2_kernel", 4.0 * cols * N, ms_p2))  # rows N..1 (upper bound)
     else:
         # per-step flows: the pricings of a group share their launches (K per launch; ms_lsm is per pricing)
         k_eff = 1 if a.sync_every_step else ctx.seq_step_width([params(a.semantics, i) for i in range(min(a.group, a.steps))])
@@ -711,6 +731,13 @@ def main():
     whole = (b_gen + b_lsm) / (elapsed / a.steps) / 1e9
     line["roofline_whole_pricing"] = {"bound": "hbm", "bytes_per_pricing": b_gen + b_lsm, "achieved": whole,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": whole / HBM_PEAK_GBS}
+    if folded:
+        # what the same pricing rate would need on full storage (the bytes rounds 1-5 moved): above 1.0 of the peak is
+        # exactly what folding buys -- the work no longer scales with those bytes
+        full_b = 4.0 * (N + 1) * M + lsm_algorithmic_bytes(a.semantics, M, N)
+        line["roofline_whole_pricing"]["full_storage_equivalent"] = {
+            "bytes_per_pricing": full_b, "achieved": full_b / (elapsed / a.steps) / 1e9, "unit": "GB/s",
+            "frac": full_b / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}
 
     # ---- the per-timestep kernel north_star specifies, as a first-class number: the reference per-step
     # flow on the same workload, HIP-event time of its N launches (boundaries included) / N
@@ -843,11 +870,19 @@ def main():
         Mc = min(M, 200_000) // 4 * 4
         try:
             g = _ffi.Context(local_rank) if dist_mode else ctx  # unsharded, no communicator
+            g.set_option("fold_antithetic", 1 if a.storage == "folded" else 0)
             gp = g.price_american(params(a.semantics, last_stream, n_paths=Mc))["price"]
             if g is not ctx:
                 g.close()
             op = oracle_price(model, Mc, N, a.semantics, is_put, 42, last_stream)[0]["price"]
+            fo = None
+            if folded:  # the folded pricing's own oracle on the stored half (same decisions, 1e-9), beside the full-matrix one
+                from oracle import cpu as orc
+                c0, gg = orc.fold_constants(MARKET["S0"], MARKET["K"], MARKET["r"], MARKET["sigma"], MARKET["T"], N)
+                half = orc.gbm_paths(Mc // 2, N, MARKET["S0"], MARKET["r"], MARKET["sigma"], MARKET["T"], 42, last_stream, 0, 0)
+                fo = orc.lsm_two_pass_folded(half, MARKET["K"], MARKET["r"], MARKET["T"], is_put, c0, gg)["price"]
             line["price_check"] = {"gpu": gp, "oracle": op, "abs_err": abs(gp - op),
+                                   "oracle_folded": fo, "rel_err_folded": None if fo is None else abs(gp - fo) / abs(fo),
                                    "rel_err": abs(gp - op) / abs(op), "tolerance_rel": 1e-3,
                                    "same_stream": True, "seed": 42, "stream": last_stream, "paths": Mc,
                                    "note": "oracle = oracle/omc_oracle.c (f64 restatement pinned to the reference's "

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OMC_ABI_VERSION 8
+#define OMC_ABI_VERSION 9
 
 typedef struct omc_ctx omc_ctx;
 
@@ -73,6 +73,8 @@ typedef struct {
     double ms_pass1, ms_pass2;         /* omc_price_american, two-pass flow: the two big LSM kernels */
     int64_t timed;         /* omc_price_american_seq: 1 = this pricing carried its own HIP events (the ms_* kernel
                               times above are its own), 0 = they repeat those of the latest timed pricing before it */
+    int64_t folded;        /* omc_price_american (no S_keep) / _seq: 1 = the pricing ran on antithetic-FOLDED storage
+                              (option "fold_antithetic", below): only the first partner of every pair was stored */
 } omc_result;
 
 /* ---- library / context --------------------------------------------------------------- */
@@ -105,7 +107,16 @@ int omc_alloc(omc_ctx* ctx, size_t bytes, void** dptr);
 int omc_free(omc_ctx* ctx, void* dptr);
 int omc_memcpy_h2d(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
 int omc_memcpy_d2h(omc_ctx* ctx, void* dst, const void* src, size_t bytes);
-/* knobs: "gbm_vec" / "heston_vec" (pairs per thread: 1,2,4; 0 = auto), "world_size" (ranks behind
+/* knobs: "fold_antithetic" (1 = default: the fused pricing calls -- omc_price_american without S_keep and
+ * omc_price_american_seq -- keep antithetic GBM paths of the two-pass flow in FOLDED storage when the pricing has at least
+ * 65,536 paths over all ranks (smaller ones are launch-bound and stay on the full matrix, bit-equal to their
+ * omc_price_american_batch form); 2 = whatever the size; 0 = never.  Folded storage: since S_t S'_t = S0^2
+ * exp(2 drift t) for the partners of a pair, only the first partner's path is generated and stored, half the matrix, and
+ * both sweeps price the partner from the same spot through its moneyness (C_t / K) / S_t - 1 in float64 -- same Philox
+ * normals, same first partners bit for bit, partner spots equal to the stored float32 ones up to their rounding (prices
+ * agree to ~1e-6 relative; omc_result.folded says which storage a pricing used; oracle: orc_lsm_two_pass_folded).
+ * Full storage = both partners, the layout omc_gbm_paths + omc_lsm produce),
+ * "gbm_vec" / "heston_vec" (pairs per thread: 1,2,4; 0 = auto), "world_size" (ranks behind
  * the all-reduce hook, see below), "step_graph" (1 / 0: replay the per-step sweep as one captured HIP
  * graph or launch its kernels one by one; -1 = default, off: same speed at 1M x 252, and a capture per new
  * geometry costs milliseconds), "seq_overlap" (omc_price_american_seq on a context with a communicator, two-pass flow, equal geometry:
@@ -503,6 +514,8 @@ int omc_seq_step_width(omc_ctx* ctx, const omc_params* p, int n);
  * batch runs the kernels a single call runs: the 16-byte ones, taken when EVERY member has whole groups of four path
  * pairs (n_paths % 8 == 0 with antithetic pairs, % 4 without); otherwise all members run the scalar kernels, whose sums
  * are formed in another block geometry: the same decisions (exact ties of a handful of paths aside), prices to 1e-12.
+ * Members are priced on FULL path storage: a member large enough for a single call to fold it (65,536+ paths, option
+ * "fold_antithetic") equals the single call made with that option at 0.
  * Whole-batch kernel times are reported in res[0]. */
 int omc_price_american_batch(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);
 int omc_price_european_batch(omc_ctx* ctx, const omc_params* p, int n, omc_result* res);

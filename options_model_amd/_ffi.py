@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _build
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 SEMANTICS = {"reference": 0, "textbook": 1, "two_pass": 2}
 MODELS = {"gbm": 0, "heston": 1}
@@ -40,7 +40,8 @@ class Result(C.Structure):
                 ("n_paths", C.c_int64), ("n_exercised", C.c_int64), ("n_zero", C.c_int64),
                 ("sum_nitm", C.c_int64),
                 ("ms_paths", C.c_double), ("ms_lsm", C.c_double), ("ms_total", C.c_double),
-                ("ms_pass1", C.c_double), ("ms_pass2", C.c_double), ("timed", C.c_int64)]
+                ("ms_pass1", C.c_double), ("ms_pass2", C.c_double), ("timed", C.c_int64),
+                ("folded", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

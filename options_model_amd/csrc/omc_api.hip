@@ -140,6 +140,12 @@ struct omc_ctx {
     int seq_step_k = -1;       // -1: default (what fits the Infinity Cache, <= 16), 1: off, k: at most k pricings per launch
     int seq_step_wgs = 0;      // workgroups one launch of the multi-pricing sweep may use (0: one per CU)
     int gbm_vec = 0, heston_vec = 0;
+    // antithetic-folded storage of the fused GBM two-pass pricing (omc_lsm_dev.h; option "fold_antithetic": 0 never,
+    // 1 = default: pricings of at least kFoldMinPaths paths over all ranks, 2 always): two cK tables (the overlapped
+    // sequence has two pricings in flight), each remembered by what it was filled from
+    int fold = 1;
+    DevBuf foldC;
+    struct FoldKey { int N = -1; double c0 = 0, g = 0; } fold_key[2];
     int world = 1;  // ranks whose sums the hook / communicator adds up (equal shards)
     omc_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
@@ -671,6 +677,7 @@ int omc_set_option(omc_ctx* c, const char* key, int64_t value)
     if (!c || !key) return fail(-7, "null pointer.");
     if (!strcmp(key, "gbm_vec")) c->gbm_vec = (int)value;
     else if (!strcmp(key, "alloc_limit")) g_alloc_limit = value > 0 ? (size_t)value : 0;
+    else if (!strcmp(key, "fold_antithetic")) c->fold = value <= 0 ? 0 : (value >= 2 ? 2 : 1);
     else if (!strcmp(key, "heston_vec")) c->heston_vec = (int)value;
     else if (!strcmp(key, "world_size")) c->world = value > 0 ? (int)value : 1;
     else if (!strcmp(key, "step_graph")) c->step_graph = value < 0 ? -1 : (value ? 1 : 0);
@@ -1040,15 +1047,53 @@ static int check_params(const omc_params* p)
     return 0;
 }
 
-static int enqueue_paths(omc_ctx* c, const omc_params* p, float* S, int64_t ld)
+// `fold`: only the FIRST partner of every antithetic pair is generated (n_paths / 2 columns; the same Philox counters,
+// hence the same spots, as the first half of the full matrix)
+static int enqueue_paths(omc_ctx* c, const omc_params* p, float* S, int64_t ld, bool fold = false)
 {
     if (p->model == OMC_MODEL_GBM)
-        HIP_TRY(omc::launch_gbm_paths(c->stream, S, ld, p->n_paths, p->n_steps, p->S0, p->r, p->sigma, p->T, p->seed,
-                                      (uint32_t)p->stream, p->pair_offset, p->antithetic, c->gbm_vec));
+        HIP_TRY(omc::launch_gbm_paths(c->stream, S, ld, fold ? p->n_paths / 2 : p->n_paths, p->n_steps, p->S0, p->r,
+                                      p->sigma, p->T, p->seed, (uint32_t)p->stream, p->pair_offset,
+                                      fold ? 0 : p->antithetic, c->gbm_vec));
     else
         HIP_TRY(omc::launch_heston_paths(c->stream, S, ld, p->n_paths, p->n_steps, p->S0, p->r, p->T, p->v0,
                                          p->kappa, p->theta, p->xi, p->rho, p->seed, (uint32_t)p->stream,
                                          p->pair_offset, p->heston_scheme, c->heston_vec));
+    return 0;
+}
+
+// How the fused pricing (the library owns the path matrix) stores the paths of `p`: antithetic GBM in the two-pass flow
+// keeps only the first partner of every pair (omc_lsm_dev.h, "antithetic-folded storage") -- *cK is then table `slot` of
+// S0^2 exp(2 drift t) / K, (re)filled on the stream when its inputs changed -- everything else the full matrix (*cK null).
+// Small pricings stay on the full matrix: they are bound by launch latency, not by bytes (a curve point of a few thousand
+// paths would pay a table refill per point for nothing), and omc_price_american_batch -- which prices such members many
+// per launch on full storage -- keeps returning the bits of the single calls.  The rule looks at the JOB's paths (local
+// paths x ranks), so a sharded pricing and its one-GPU form use the same storage.
+constexpr int64_t kFoldMinPaths = 65536;
+static bool fold_applies(const omc_ctx* c, const omc_params* p)
+{
+    if (!c->fold || p->model != OMC_MODEL_GBM || !p->antithetic || p->semantics != OMC_SEM_TWO_PASS) return false;
+    return c->fold >= 2 || p->n_paths * (int64_t)(c->world > 0 ? c->world : 1) >= kFoldMinPaths;
+}
+
+static int plan_storage(omc_ctx* c, const omc_params* p, int slot, int64_t* ld, const double** cK)
+{
+    *cK = nullptr;
+    *ld = (p->n_paths + 63) / 64 * 64;
+    if (!fold_applies(c, p)) return 0;
+    int rc;
+    const size_t per = (size_t)omc::kMaxSteps + 2;
+    if ((rc = c->foldC.ensure(sizeof(double) * 2 * per))) return rc;
+    double* tab = (double*)c->foldC.p + per * (size_t)slot;
+    double c0, g;
+    omc::gbm_fold_constants(p->S0, p->K, p->r, p->sigma, p->T, p->n_steps, &c0, &g);
+    omc_ctx::FoldKey& key = c->fold_key[slot];
+    if (key.N != p->n_steps || key.c0 != c0 || key.g != g) {
+        HIP_TRY(omc::lsm_fold_table(c->stream, tab, p->n_steps, c0, g));
+        key.N = p->n_steps; key.c0 = c0; key.g = g;
+    }
+    *ld = (p->n_paths / 2 + 63) / 64 * 64;
+    *cK = tab;
     return 0;
 }
 
@@ -1063,22 +1108,24 @@ static int enqueue_pricing(omc_ctx* c, const omc_params* p, float* S_keep, int64
     const int64_t M = p->n_paths;
     const int N = p->n_steps;
     float* S = S_keep;
+    const double* cK = nullptr;
     if (S) {
         if (ld < M) return fail(-6, "leading dimension smaller than n_paths.");
     } else {
-        ld = (M + 63) / 64 * 64;
+        if ((rc = plan_storage(c, p, 0, &ld, &cK))) return rc;
         if ((rc = c->S.ensure(sizeof(float) * (size_t)ld * (size_t)(N + 1)))) return rc;
         S = (float*)c->S.p;
     }
     omc::LsmWorkspace w;
     if ((rc = prepare_lsm(c, M, N, p->r, p->T, p->semantics == OMC_SEM_TWO_PASS, false, &w))) return rc;
     omc::LsmProblem prob{S, ld, M, N, p->is_put ? 1 : 0, p->K, p->r, p->T};
+    prob.fold_cK = cK;
     if (timed) {
         // (pass 1 starts where the generator ends: evs[1] is its begin; an event costs ~3 us of dispatch gap)
         w.ev_p1_end = evs[4]; w.ev_p2_begin = evs[5]; w.ev_p2_end = evs[6];
         HIP_TRY(hipEventRecord(evs[0], c->stream));
     }
-    if ((rc = enqueue_paths(c, p, S, ld))) return rc;
+    if ((rc = enqueue_paths(c, p, S, ld, cK != nullptr))) return rc;
     if (timed) HIP_TRY(hipEventRecord(evs[1], c->stream));
     if (result_dev) w.result = result_dev;
     if ((rc = enqueue_lsm(c, prob, w, p->semantics, false))) return rc;
@@ -1152,6 +1199,7 @@ int omc_price_american(omc_ctx* c, const omc_params* p, omc_result* res, float* 
     memset(res, 0, sizeof *res);
     fill_result(res, hres, c->distributed() ? p->n_paths * c->world : p->n_paths,
                 c->distributed() ? c->world : 1);  // distributed: sums are global
+    res->folded = (!S_keep && fold_applies(c, p)) ? 1 : 0;
     return read_kernel_times(c->ev, p, res);
 }
 
@@ -1378,8 +1426,14 @@ static int enqueue_seq_overlapped(omc_ctx* c, const omc_params* p, int n, double
     }
     float* Sb[2] = {(float*)c->S.p, (float*)c->S2.p};
     double* local = (double*)c->seq_local.p;
+    // every pricing of the sequence chooses its storage for itself (folded matrices are smaller than `sbytes`); the two
+    // pricings in flight use different cK tables
+    std::vector<int64_t> ldk((size_t)n, ld);
+    std::vector<const double*> cKk((size_t)n, nullptr);
     auto problem = [&](int k) {
-        return omc::LsmProblem{Sb[k & 1], ld, M, N, p[k].is_put ? 1 : 0, p[k].K, p[k].r, p[k].T};
+        omc::LsmProblem q{Sb[k & 1], ldk[(size_t)k], M, N, p[k].is_put ? 1 : 0, p[k].K, p[k].r, p[k].T};
+        q.fold_cK = cKk[(size_t)k];
+        return q;
     };
     // paths + pass 1 of pricing k on the main stream, then its moment table's all-reduce on the other one
     auto phase_a = [&](int k) -> int {
@@ -1393,7 +1447,8 @@ static int enqueue_seq_overlapped(omc_ctx* c, const omc_params* p, int n, double
             wk.ev_p1_end = evs[4];
             HIP_TRY(hipEventRecord(evs[0], c->stream));
         }
-        if ((r2 = enqueue_paths(c, &p[k], Sb[b], ld))) return r2;
+        if ((r2 = plan_storage(c, &p[k], b, &ldk[(size_t)k], &cKk[(size_t)k]))) return r2;
+        if ((r2 = enqueue_paths(c, &p[k], Sb[b], ldk[(size_t)k], cKk[(size_t)k] != nullptr))) return r2;
         if (evs) HIP_TRY(hipEventRecord(evs[1], c->stream));
         HIP_TRY(omc::lsm_pass1_moments(c->stream, problem(k), wk));
         HIP_TRY(hipEventRecord(c->ev_moments[b], c->stream));
@@ -1723,6 +1778,7 @@ int omc_price_american_seq(omc_ctx* c, const omc_params* p, int n, omc_result* r
         res[i].ms_total = ms_all / (float)n;
         res[i].ms_lsm = res[i].ms_total - timed.ms_paths;
         res[i].timed = (smp >= 0 && (multi <= 1 || i == 0)) ? 1 : 0;
+        res[i].folded = fold_applies(c, &p[i]) ? 1 : 0;
     }
     return 0;
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cmath>
 
 namespace omc {
 
@@ -77,6 +78,10 @@ struct LsmProblem {
     int64_t ld, M;
     int N, is_put;
     double K, r, T;
+    // Antithetic-FOLDED storage (two-pass flow of the fused GBM pricing; omc_lsm_dev.h): non-null = S holds only the FIRST
+    // partner of every antithetic pair ([N+1][ld], M / 2 columns) and fold_cK[t] = S0^2 exp(2 drift t) / K (device, N + 1
+    // doubles): the partner of a stored spot S_t is C_t / S_t.  M stays the number of PATHS.
+    const double* fold_cK = nullptr;
 };
 
 // device workspace carved by the API layer (all sizes in elements)
@@ -100,6 +105,17 @@ struct LsmWorkspace {
 };
 
 size_t lsm_part1_tiles(int64_t M);
+// LsmProblem::fold_cK: cK[t] = c0 g^t for t = 0 .. N (c0 = S0^2 / K, g = exp(2 drift dt)), N sequential products
+hipError_t lsm_fold_table(hipStream_t st, double* cK, int N, double c0, double g);
+// its two constants, from the float32 drift exponent and start value the generator itself uses (launch_gbm_paths)
+inline void gbm_fold_constants(double S0, double K, double r, double sigma, double T, int n_steps, double* c0, double* g)
+{
+    const double dt = T / n_steps, L2E = 1.4426950408889634074;
+    const float a = (float)((r - 0.5 * sigma * sigma) * dt * L2E);
+    const float s0 = (float)S0;
+    *c0 = (double)s0 * (double)s0 / K;
+    *g = std::exp2(2.0 * (double)a);
+}
 // part[0][q][0..nblk) -> result[q], result[4] = sum_t gmom[t][0] (N<=1: skipped)
 hipError_t lsm_finalize(hipStream_t st, const double* part, const double* gmom, double* result,
                         int nblk, int N);

@@ -58,6 +58,24 @@ __global__ __launch_bounds__(kBlock) void lsm_reduce_pass1_kernel(const double* 
 template <int VEC, bool WRITE_STATE>
 __global__ __launch_bounds__(kBlock) void lsm_pass2_kernel(Pass2Args a) { lsm_pass2_body<VEC, WRITE_STATE>(a); }
 
+// the two sweeps on the antithetic-folded matrix (omc_lsm_dev.h)
+template <int VEC, int TPW, int PUT>
+__global__ __launch_bounds__(kBlock) void lsm_pass1_fold_kernel(Pass1Args a) { lsm_pass1_fold_body<VEC, TPW, PUT>(a); }
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void lsm_pass2_fold_kernel(Pass2Args a) { lsm_pass2_fold_body<VEC>(a); }
+
+// cK[t] = c0 g^t, t = 0 .. N, by N sequential float64 multiplications (IEEE: the host oracle repeats them exactly)
+__global__ void lsm_fold_table_kernel(double* __restrict__ cK, int N, double c0, double g)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double c = c0;
+    cK[0] = c;
+    for (int t = 1; t <= N; ++t) {
+        c *= g;
+        cK[t] = c;
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void lsm_final_kernel(FinalArgs a) { lsm_final_body<VEC>(a); }
 
@@ -309,9 +327,55 @@ hipError_t lsm_reduce_step_moments(hipStream_t st, const LsmWorkspace& w, int t,
     return hipGetLastError();
 }
 
+hipError_t lsm_fold_table(hipStream_t st, double* cK, int N, double c0, double g)
+{
+    hipLaunchKernelGGL(lsm_fold_table_kernel, dim3(1), dim3(64), 0, st, cK, N, c0, g);
+    return hipGetLastError();
+}
+
+// pass 1 on the folded matrix: P = M / 2 stored columns, two tiles of 64 x VEC columns per wave and step (= 1,024 paths, as
+// in the full sweep; OMC_FOLD_TPW = 1 | 4 for experiments)
+static hipError_t lsm_pass1_moments_fold(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w)
+{
+    Pass1Args a;
+    const int64_t P = p.M / 2;
+    a.S = p.S; a.ld = p.ld; a.M = P; a.N = p.N; a.is_put = p.is_put;
+    a.K = p.K; a.invK = 1.0 / p.K; a.D = w.D; a.part1 = w.part1; a.cK = p.fold_cK;
+    const bool v4 = (P % 4) == 0 && (p.ld % 4) == 0 && ((uintptr_t)p.S % 16) == 0;
+    static const int tpw_env = getenv("OMC_FOLD_TPW") ? atoi(getenv("OMC_FOLD_TPW")) : 0;
+    const int tpw = (v4 && (tpw_env == 1 || tpw_env == 4)) ? tpw_env : 2;
+    const int64_t per_wave = 64 * (int64_t)(v4 ? 4 : 1) * tpw;
+    a.ntiles = (P + per_wave - 1) / per_wave;
+    // Steps per workgroup: the folded sweep is bound by its float64 arithmetic, not by the rows it reads, so what counts is
+    // that every CU stays busy to the end -- many short workgroups (measured at C2, 245 tile-workgroups: chunks of 16-32
+    // steps 0.145-0.147 ms, 63 steps 0.156, 84 steps -- one resident round -- 0.162, 126 steps 0.183; 8M paths: 32).
+    static const int tch_env = getenv("OMC_PASS1_TCHUNK") ? atoi(getenv("OMC_PASS1_TCHUNK")) : 0;
+    const int64_t wgs_x = (a.ntiles + 3) / 4;
+    a.tchunk = (tch_env >= 2 && tch_env <= kPass1MaxChunk) ? tch_env : 32;
+    const dim3 grid((unsigned)wgs_x, (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
+    if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
+    if (v4 && tpw == 1) {
+        if (p.is_put) hipLaunchKernelGGL((lsm_pass1_fold_kernel<4, 1, 1>), grid, dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((lsm_pass1_fold_kernel<4, 1, 0>), grid, dim3(kBlock), 0, st, a);
+    } else if (v4 && tpw == 4) {
+        if (p.is_put) hipLaunchKernelGGL((lsm_pass1_fold_kernel<4, 4, 1>), grid, dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((lsm_pass1_fold_kernel<4, 4, 0>), grid, dim3(kBlock), 0, st, a);
+    } else if (v4) {
+        if (p.is_put) hipLaunchKernelGGL((lsm_pass1_fold_kernel<4, 2, 1>), grid, dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((lsm_pass1_fold_kernel<4, 2, 0>), grid, dim3(kBlock), 0, st, a);
+    } else {
+        if (p.is_put) hipLaunchKernelGGL((lsm_pass1_fold_kernel<1, 2, 1>), grid, dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((lsm_pass1_fold_kernel<1, 2, 0>), grid, dim3(kBlock), 0, st, a);
+    }
+    if (w.ev_p1_end) (void)hipEventRecord(w.ev_p1_end, st);
+    hipLaunchKernelGGL(lsm_reduce_pass1_kernel, dim3(p.N - 1), dim3(kBlock), 0, st, w.part1, w.gmom, a.ntiles, p.N);
+    return hipGetLastError();
+}
+
 hipError_t lsm_pass1_moments(hipStream_t st, const LsmProblem& p, const LsmWorkspace& w)
 {
     if (p.N < 2) return hipSuccess;
+    if (p.fold_cK) return lsm_pass1_moments_fold(st, p, w);
     Pass1Args a;
     a.S = p.S; a.ld = p.ld; a.M = p.M; a.N = p.N; a.is_put = p.is_put;
     a.K = p.K; a.invK = 1.0 / p.K; a.D = w.D; a.part1 = w.part1;
@@ -371,12 +435,22 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
         a.gmom = w.gmom;
         a.betas_out = w.betas;
     }
-    const int nblk = lsm_step_blocks(p.M);
+    static const int fvec_env = getenv("OMC_FOLD_P2_VEC") ? atoi(getenv("OMC_FOLD_P2_VEC")) : 0;
+    const int fvec = (fvec_env == 1 || fvec_env == 4) ? fvec_env : 2;
+    const int nblk = lsm_step_blocks(p.fold_cK ? (p.M / 2) * (4 / fvec) : p.M);
     a.nblk = nblk; a.pstride = kPStride;
     const size_t dyn = sizeof(double) * 4 * (size_t)(p.N + 1);
     const bool v4 = vec4_ok(p);
     if (w.ev_p2_begin) (void)hipEventRecord(w.ev_p2_begin, st);
-    if (v4) {
+    if (p.fold_cK) {  // the folded matrix: M / 2 stored columns, both partners decided from every spot; no state arrays
+        if (write_state) return hipErrorInvalidValue;
+        a.M = p.M / 2;
+        a.cK = p.fold_cK;
+        const bool f4 = (a.M % 4) == 0 && (p.ld % 4) == 0 && ((uintptr_t)p.S % 16) == 0;
+        if (f4 && fvec == 4) hipLaunchKernelGGL((lsm_pass2_fold_kernel<4>), dim3(nblk), dim3(kBlock), dyn, st, a);
+        else if (f4 && fvec == 2) hipLaunchKernelGGL((lsm_pass2_fold_kernel<2>), dim3(nblk), dim3(kBlock), dyn, st, a);
+        else hipLaunchKernelGGL((lsm_pass2_fold_kernel<1>), dim3(nblk), dim3(kBlock), dyn, st, a);
+    } else if (v4) {
         if (write_state) hipLaunchKernelGGL((lsm_pass2_kernel<4, true>), dim3(nblk), dim3(kBlock), dyn, st, a);
         else hipLaunchKernelGGL((lsm_pass2_kernel<4, false>), dim3(nblk), dim3(kBlock), dyn, st, a);
     } else {

@@ -19,7 +19,11 @@ __device__ __forceinline__ void loadf(const float* __restrict__ p, float (&v)[VE
     if constexpr (VEC == 4) {
         const float4 x = *reinterpret_cast<const float4*>(p);
         v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else if constexpr (VEC == 2) {
+        const float2 x = *reinterpret_cast<const float2*>(p);
+        v[0] = x.x; v[1] = x.y;
     } else {
+        static_assert(VEC == 1, "loadf: 1, 2 or 4 floats");
         v[0] = *p;
     }
 }
@@ -31,7 +35,12 @@ __device__ __forceinline__ void loadf_stream(const float* __restrict__ p, float 
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 x = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
         v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else if constexpr (VEC == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 x = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p));
+        v[0] = x.x; v[1] = x.y;
     } else {
+        static_assert(VEC == 1, "loadf_stream: 1, 2 or 4 floats");
         v[0] = __builtin_nontemporal_load(p);
     }
 }
@@ -417,6 +426,9 @@ struct Pass1Args {
     double* part1;
     int64_t ntiles;
     int tchunk;
+    // antithetic-FOLDED storage (lsm_pass1_fold_body): S holds only the first partner of every pair, M = stored columns;
+    // cK[t] = C_t / K with C_t = S_t S'_t = S0^2 exp(2 drift t) -- the partner's moneyness is cK[t] / S_t
+    const double* cK = nullptr;
 };
 
 // Pass 1 (options_model_3.py:482-516): no decisions, so every time step is independent.
@@ -574,6 +586,151 @@ __device__ __forceinline__ void lsm_pass1_body(Pass1Args a)
         sweep(std::false_type{});
 }
 
+// ------------------------------------------------------------------ antithetic-folded storage (GBM)
+// For GBM the antithetic partner of a path is a FUNCTION of the path: S_t = S0 exp(sum(a + b z_i)) and
+// S'_t = S0 exp(sum(a - b z_i)) give S_t S'_t = S0^2 exp(2 a t) =: C_t, a per-step constant.  The fused pricing therefore
+// stores only the first partner of every pair -- half the matrix: half the bytes written by the generator and read by both
+// sweeps -- and the sweeps price both partners from every spot they load.  The partner enters all arithmetic through its
+// moneyness, in float64 and never rounded to float32:
+//      u' = x' - 1 = (C_t / K) / S_t - 1 = fma(cK_t, rcp(S_t), -1),
+// its payoff is -K u' (put) / K u' (call), in the money <=> that is > 0, its continuation value the fit at u'.  These three
+// definitions are shared by pass 1, pass 2 and the valuation (fold_u / fold_pay), so the sweeps agree bit for bit on which
+// partner rows exist and what they are worth; the CPU restatement the tests check against repeats them (orc_lsm_two_pass_folded).
+// (1 / S_t: v_rcp_f64 is good to 2^-23; ONE Newton step takes it to 2^-46 = 1.4e-14 relative -- the partner's moneyness is
+//  then 1.4e-14 (absolute) from the exactly divided one, nine orders below the float32 rounding of the spot it is made from)
+__device__ __forceinline__ double fold_u(double cK_t, float s)
+{
+    const double x = (double)s;
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(cK_t, r, -1.0);
+}
+__device__ __forceinline__ double fold_pay(double u, double K, int is_put) { return is_put ? -K * u : K * u; }
+
+// Pass 1 on the folded matrix: as lsm_pass1_body, every loaded spot contributing its own row and its partner's.
+// a.M = stored columns (pairs); TPW tiles of 64 * VEC columns = 2 * TPW * 64 * VEC paths per wave and step.
+template <int VEC, int TPW, int PUT = -1>
+__device__ __forceinline__ void lsm_pass1_fold_body(Pass1Args a)
+{
+    __shared__ double wl[kBlock / 64][kWaveRedDoubles];
+    __shared__ double shD[kBlock / 64][kPass1MaxChunk];
+    __shared__ double shC[kBlock / 64][kPass1MaxChunk];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tg = (int64_t)xcd_block((int)blockIdx.x, (int)gridDim.x) * (kBlock / 64) + wave;
+    if (tg >= a.ntiles) return;  // whole wave leaves; no workgroup barrier below
+    const int64_t base = tg * (64 * VEC * TPW) + (int64_t)lane * VEC;
+    const int t0 = 1 + ((int)gridDim.y - 1 - (int)blockIdx.y) * a.tchunk;
+    const int t1 = min(t0 + a.tchunk, a.N);
+    if (t0 >= t1) return;
+    const double K = a.K, invK = a.invK;
+    const int is_put = PUT < 0 ? a.is_put : PUT;
+    for (int i = lane; i < t1 - t0; i += 64) {
+        shD[wave][i] = a.D[a.N - (t0 + i)];
+        shC[wave][i] = a.cK[t0 + i];
+    }
+    const float* colp[TPW];
+    double pNA[TPW][VEC], pNB[TPW][VEC];
+    bool valid[TPW];
+    const double cKN = a.cK[a.N];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int64_t j = base + (int64_t)k * 64 * VEC;
+        valid[k] = j < a.M;
+        colp[k] = a.S + (valid[k] ? j : 0);
+        float sn[VEC];
+        loadf<VEC>(colp[k] + (int64_t)a.N * a.ld, sn);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const double pa = payoff_d(sn[v], K, is_put), pb = fold_pay(fold_u(cKN, sn[v]), K, is_put);
+            pNA[k][v] = (valid[k] && pa > 0.0) ? pa : 0.0;
+            pNB[k][v] = (valid[k] && pb > 0.0) ? pb : 0.0;
+        }
+    }
+    auto load_rows = [&](float (&buf)[TPW][VEC], int t) {
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) loadf_stream<VEC>(colp[k] + (int64_t)t * a.ld, buf[k]);
+    };
+    const float thr = itm_threshold(K, is_put);
+    float thrk[TPW];  // padding tiles: a threshold no price passes
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) thrk[k] = valid[k] ? thr : (is_put ? -__builtin_inff() : __builtin_inff());
+    auto process = [&](auto put_tag, const float (&buf)[TPW][VEC], int t) {
+        constexpr bool IS_PUT = decltype(put_tag)::value;
+        double acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+        int cnt = 0;
+        const double ck = shC[wave][t - t0];
+        // One row per spot in the common case: of the two partners of a pair at most one is in the money unless the spot lies
+        // between K and C_t / K (S0 = K: an empty or narrow band), so the sums take the PRIMARY row -- the stored path's if it
+        // is in the money, else the partner's -- and the partner's row a second time only where some lane of the wave has
+        // both in the money (a wave-uniform branch per spot slot; deep in the money it is always taken).
+        auto add_row = [&](double u, double y, double m) {  // u, y already zero where m is
+            const double u2 = u * u;
+            acc[1] += u;
+            acc[2] += u2;
+            acc[3] = fma(u2, u, acc[3]);
+            acc[4] = fma(u2, u2, acc[4]);
+            acc[5] = fma(y, m, acc[5]);
+            acc[6] = fma(u, y, acc[6]);
+            acc[7] = fma(u2, y, acc[7]);
+        };
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float sf = buf[k][v];
+                const double ua = fma((double)sf, invK, -1.0);
+                const double ub = fold_u(ck, sf);
+                const bool ia = IS_PUT ? sf < thrk[k] : sf > thrk[k];
+                // the partner: in the money <=> its payoff -K u' (put) / K u' (call) > 0; padding columns never are
+                const bool ib = valid[k] && (IS_PUT ? ub < 0.0 : ub > 0.0);
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ia)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(ib));
+                const double mp = (ia || ib) ? 1.0 : 0.0;
+                add_row((ia ? ua : ub) * mp, ia ? pNA[k][v] : pNB[k][v], mp);
+                const bool both = ia && ib;
+                if (__builtin_amdgcn_ballot_w64(both) != 0) {
+                    asm volatile("; a lane with both partners in the money" ::);  // (keeps the branch: no if-conversion)
+                    const double ms = both ? 1.0 : 0.0;
+                    add_row(ub * ms, pNB[k][v], ms);
+                }
+            }
+        }
+        const double d = shD[wave][t - t0];
+        acc[0] = lane == 0 ? (double)cnt : 0.0;
+        acc[5] *= d;
+        acc[6] *= d;
+        acc[7] *= d;
+        const double s = wave_reduce8(acc, wl[wave]);
+        if ((lane & 7) == 0) a.part1[((size_t)t * a.ntiles + tg) * 8 + (lane >> 3)] = s;
+    };
+    float bufA[TPW][VEC], bufB[TPW][VEC], bufC[TPW][VEC];
+    const int tl = t1 - 1;
+    auto sweep = [&](auto put_tag) {
+        load_rows(bufA, t0);
+        load_rows(bufB, min(t0 + 1, tl));
+        for (int t = t0; t < t1; t += 3) {
+            load_rows(bufC, min(t + 2, tl));
+            __builtin_amdgcn_sched_barrier(0);
+            process(put_tag, bufA, t);
+            if (t + 1 < t1) {
+                load_rows(bufA, min(t + 3, tl));
+                __builtin_amdgcn_sched_barrier(0);
+                process(put_tag, bufB, t + 1);
+            }
+            if (t + 2 < t1) {
+                load_rows(bufB, min(t + 4, tl));
+                __builtin_amdgcn_sched_barrier(0);
+                process(put_tag, bufC, t + 2);
+            }
+        }
+    };
+    if (PUT == 1 || (PUT < 0 && is_put))
+        sweep(std::true_type{});
+    else
+        sweep(std::false_type{});
+}
+
 __device__ __forceinline__ void lsm_reduce_pass1_body(const double* __restrict__ part1,
                                                       double* __restrict__ gmom, int64_t ntiles,
                                                       int N)
@@ -642,6 +799,7 @@ struct Pass2Args {
     // writes them to betas_out [N+1][4]
     const double* gmom = nullptr;
     double* betas_out = nullptr;
+    const double* cK = nullptr;  // antithetic-folded storage (lsm_pass2_fold_body): see Pass1Args::cK; M = stored columns
 };
 
 // Pass 2 (options_model_3.py:615-651) with frozen per-step fits: every path is
@@ -747,6 +905,120 @@ __device__ __forceinline__ void lsm_pass2_body(Pass2Args a)
         if (WRITE_STATE) {
             storef<VEC>(a.sx + j, sx);
             storei<VEC>(a.tex + j, tex);
+        }
+    }
+    const double s = block_reduce8(acc, red);
+    if (tid < 64 && (tid & 7) == 0) a.part[(size_t)(tid >> 3) * a.pstride + blockIdx.x] = s;
+}
+
+// Pass 2 on the folded matrix: a thread walks its VEC stored columns backward and decides for both partners of each from
+// every spot it loads; it stops when all 2 VEC paths have exercised.  A partner that exercises remembers the STORED
+// path's spot at that step (its own value is fold_pay(fold_u(cK[t], spot))): the valuation below recomputes it with the
+// very expressions of the decision.  The fits' table keeps cK[t] in its fourth slot.
+template <int VEC>
+__device__ __forceinline__ void lsm_pass2_fold_body(Pass2Args a)
+{
+    if ((int)blockIdx.x >= a.nblk) return;
+    __shared__ double red[kNQ * kRedStride];
+    extern __shared__ double sh_b[];  // [N+1][4]: b0, b1, b2, cK
+    const int tid = threadIdx.x;
+    const int N = a.N;
+    if (a.gmom) {
+        for (int t = tid; t <= N; t += kBlock) {
+            double m[8], beta[3] = {0.0, 0.0, 0.0};
+            const bool inner = t >= 1 && t < N;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = inner ? a.gmom[(size_t)t * 8 + q] : 0.0;
+            if (inner) solve_poly2(m, beta);
+            const bool fit = inner && m[0] > 0.5;
+            sh_b[4 * t] = fit ? beta[0] : __builtin_huge_val();
+            sh_b[4 * t + 1] = fit ? beta[1] : 0.0;
+            sh_b[4 * t + 2] = fit ? beta[2] : 0.0;
+            sh_b[4 * t + 3] = a.cK[t];
+            if (blockIdx.x == 0 && inner && a.betas_out) {
+                double* bo = a.betas_out + (size_t)t * 4;
+                bo[0] = beta[0]; bo[1] = beta[1]; bo[2] = beta[2]; bo[3] = m[0];
+            }
+        }
+    } else {
+        for (int k = tid; k < (N + 1) * 4; k += kBlock) {
+            const int t = k >> 2;
+            const bool fit = t >= 1 && t < N && a.betas[(size_t)t * 4 + 3] > 0.5;
+            sh_b[k] = (k & 3) == 3 ? a.cK[t] : (fit ? a.betas[k] : ((k & 3) == 0 ? __builtin_huge_val() : 0.0));
+        }
+    }
+    __syncthreads();
+    const double K = a.K, invK = a.invK;
+    const int is_put = a.is_put;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    const int64_t stride = (int64_t)a.nblk * kBlock * VEC;
+    for (int64_t j = ((int64_t)blockIdx.x * kBlock + tid) * VEC; j < a.M; j += stride) {
+        float sxa[VEC], sxb[VEC];
+        int32_t texa[VEC], texb[VEC];
+        loadf<VEC>(a.S + (int64_t)N * a.ld + j, sxa);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            sxb[v] = sxa[v];
+            texa[v] = texb[v] = N;
+        }
+        auto decide = [&](const float (&row)[VEC], int t) {
+            const double b0 = sh_b[4 * t], b1 = sh_b[4 * t + 1], b2 = sh_b[4 * t + 2], ck = sh_b[4 * t + 3];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double sd = (double)row[v];
+                const double imm = is_put ? K - sd : sd - K;
+                const double u = fma(sd, invK, -1.0);
+                const double cont = fma(u, fma(u, b2, b1), b0);
+                const bool ex = (texa[v] == N) & (imm > 0.0) & (imm > cont);
+                sxa[v] = ex ? row[v] : sxa[v];
+                texa[v] = ex ? t : texa[v];
+                const double ub = fold_u(ck, row[v]);
+                const double immb = fold_pay(ub, K, is_put);
+                const double contb = fma(ub, fma(ub, b2, b1), b0);
+                const bool exb = (texb[v] == N) & (immb > 0.0) & (immb > contb);
+                sxb[v] = exb ? row[v] : sxb[v];
+                texb[v] = exb ? t : texb[v];
+            }
+        };
+        auto live = [&]() {
+            bool l = false;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) l |= (texa[v] == N) | (texb[v] == N);
+            return l;
+        };
+        constexpr int U = 8;
+        int t = N - 1;
+        const float* col = a.S + j;
+        for (; t >= U && live(); t -= U) {
+            float st[U][VEC];
+#pragma unroll
+            for (int k = 0; k < U; ++k) loadf_stream<VEC>(col + (int64_t)(t - k) * a.ld, st[k]);
+#pragma unroll
+            for (int k = 0; k < U; ++k) decide(st[k], t - k);
+        }
+        for (; t >= 1 && live(); --t) {
+            float st[VEC];
+            loadf_stream<VEC>(col + (int64_t)t * a.ld, st);
+            decide(st, t);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            double p = payoff_d(sxa[v], K, is_put);
+            p = p > 0.0 ? p : 0.0;
+            const double cf = p * a.D[texa[v] - 1];
+            double pb = fold_pay(fold_u(sh_b[4 * texb[v] + 3], sxb[v]), K, is_put);
+            pb = pb > 0.0 ? pb : 0.0;
+            const double cfb = pb * a.D[texb[v] - 1];
+            acc[0] += cf;
+            acc[1] += cf * cf;
+            acc[2] += (texa[v] < N) ? 1.0 : 0.0;
+            acc[3] += (cf == 0.0) ? 1.0 : 0.0;
+            acc[0] += cfb;
+            acc[1] += cfb * cfb;
+            acc[2] += (texb[v] < N) ? 1.0 : 0.0;
+            acc[3] += (cfb == 0.0) ? 1.0 : 0.0;
         }
     }
     const double s = block_reduce8(acc, red);

@@ -53,6 +53,11 @@ def lib():
                                               C.c_void_p]
         _lib.orc_lsm_apply_frozen.restype = C.c_int
         _lib.orc_lsm_pass1_moments.argtypes = [f32p, i64, i64, i32, dbl, dbl, dbl, i32, C.c_void_p]
+        _lib.orc_fold_table.argtypes = [C.c_void_p, i32, dbl, dbl]
+        _lib.orc_fold_constants.argtypes = [dbl, dbl, dbl, dbl, dbl, i32, C.c_void_p, C.c_void_p]
+        _lib.orc_lsm_two_pass_folded.argtypes = [f32p, i64, i64, i32, dbl, dbl, dbl, i32, dbl, dbl,
+                                                 C.POINTER(LsmResult), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_lsm_two_pass_folded.restype = C.c_int
         _lib.orc_solve_poly2.argtypes = [C.c_void_p, C.c_void_p]
         _lib.orc_heston_terminal_f32.argtypes = [f32p, i64, i32] + [dbl] * 8 + [u64, u32, u64, i32]
         _lib.orc_european_from_paths.argtypes = [f32p, i64, i64, i32, dbl, dbl, dbl, i32,
@@ -128,6 +133,36 @@ def lsm_poly(S, K, r, T, is_put, semantics="reference"):
     assert rc == 0
     return dict(price=res.price, sum=res.sum, sumsq=res.sumsq, n_exercised=res.n_exercised,
                 n_zero=res.n_zero, sum_nitm=res.sum_nitm, betas=betas, nitm=nitm, sx=sx, tex=tex)
+
+
+def fold_constants(S0, K, r, sigma, T, n_steps):
+    """(c0, g) of the folded storage: cK[t] = c0 g^t = S0_f32^2 exp2(2 a_f32 t) / K (orc_fold_constants)."""
+    c0, g = C.c_double(), C.c_double()
+    lib().orc_fold_constants(S0, K, r, sigma, T, n_steps, C.byref(c0), C.byref(g))
+    return c0.value, g.value
+
+
+def fold_table(n_steps, c0, g):
+    t = np.zeros(n_steps + 1)
+    lib().orc_fold_table(_p(t), n_steps, c0, g)
+    return t
+
+
+def lsm_two_pass_folded(S_half, K, r, T, is_put, c0, g):
+    """Two-pass flow over BOTH partners of every antithetic pair from the first partners' paths alone
+    (S_half: [N+1][n_pairs] float32; orc_lsm_two_pass_folded)."""
+    S = np.ascontiguousarray(S_half, np.float32)
+    N, P = S.shape[0] - 1, S.shape[1]
+    res = LsmResult()
+    betas = np.zeros((N + 1, 3))
+    nitm = np.zeros(N + 1, np.int64)
+    texa = np.zeros(P, np.int32)
+    texb = np.zeros(P, np.int32)
+    rc = lib().orc_lsm_two_pass_folded(_p(S), P, P, N, K, r, T, int(is_put), c0, g, C.byref(res), _p(betas), _p(nitm),
+                                       _p(texa), _p(texb))
+    assert rc == 0
+    return dict(price=res.price, sum=res.sum, sumsq=res.sumsq, n_paths=res.n_paths, n_exercised=res.n_exercised,
+                n_zero=res.n_zero, sum_nitm=res.sum_nitm, betas=betas, nitm=nitm, texa=texa, texb=texb)
 
 
 def lsm_apply_frozen(S, K, r, T, is_put, betas, nitm=None):

@@ -18,7 +18,7 @@ int main(void)
     F(omc_result, price); F(omc_result, sum); F(omc_result, sumsq); F(omc_result, std); F(omc_result, zero_prob);
     F(omc_result, n_paths); F(omc_result, n_exercised); F(omc_result, n_zero); F(omc_result, sum_nitm);
     F(omc_result, ms_paths); F(omc_result, ms_lsm); F(omc_result, ms_total); F(omc_result, ms_pass1);
-    F(omc_result, ms_pass2); F(omc_result, timed);
+    F(omc_result, ms_pass2); F(omc_result, timed); F(omc_result, folded);
     printf("  \"sizeof.omc_params\": [%zu, 0],\n  \"sizeof.omc_result\": [%zu, 0],\n", sizeof(omc_params), sizeof(omc_result));
     printf("  \"abi\": [%d, 0]\n}\n", OMC_ABI_VERSION);
     return 0;

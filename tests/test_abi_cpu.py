@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.Params) == 6 * 4 + 8 + 10 * 8 + 3 * 8
-    assert C.sizeof(_ffi.Result) == 5 * 8 + 4 * 8 + 5 * 8 + 8
+    assert C.sizeof(_ffi.Result) == 5 * 8 + 4 * 8 + 5 * 8 + 8 + 8
 
 
 def test_code_object_targets_gfx950():

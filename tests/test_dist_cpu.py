@@ -417,6 +417,9 @@ class _FakeFfi:
             def close(self):
                 pass
 
+            def set_option(self, key, value):
+                outer.calls.append(("option", key, value))
+
         self.Context = Context
 
     @staticmethod
@@ -447,7 +450,7 @@ class _FakePricer:
 
 def _args(**kw):
     import argparse
-    d = dict(config3_paths=None, config3_steps=4, paths_per_gpu=None)
+    d = dict(config3_paths=None, config3_steps=4, paths_per_gpu=None, storage="folded")
     d.update(kw)
     return argparse.Namespace(**d)
 
@@ -467,6 +470,8 @@ def test_config3_block_is_baseline_configs2_at_eight_ranks():
     plain = [c for c in ffi.calls if c[0] == "plain"]
     # ... the same shard, same streams, through a communicator-free context; and no one-GPU leg on a rank other than 0
     assert plain[1][1] == [(8_000_000, 20_000_000, s) for s in (5000, 5001, 5002, 5003)] and len(plain) == 2
+    # the side contexts price with the storage the job's own context uses
+    assert [c for c in ffi.calls if c[0] == "option"] == [("option", "fold_antithetic", 1)] and b["storage"] == "folded"
     assert b["one_gpu"] == {"ms_per_step": 32.0, "rank": 0, "price": 12.003}
     assert b["speedup_vs_one_gpu"] == pytest.approx(32.0 / b["ms_per_step"])
     assert b["efficiency_vs_one_gpu"] == pytest.approx(b["speedup_vs_one_gpu"] / 8)

@@ -494,9 +494,11 @@ def test_calibrator_inner_monte_carlo_matches_the_oracle(ctx, case):
     # the Euler recurrence ITSELF amplifies float32 rounding (d sqrt(v) / dv is unbounded): the soak found a case (xi = 1.5,
     # v0 = 0, 1,000 paths) in which 44 paths of two correct float32 evaluations part ways by more than 1e-4, one by 7 %
     # (tools/exp_heston_path_diff.py, profiles/r05_fuzz_soak.txt), later one with 64 paths -- there the prices are compared
-    # as two estimates of one expectation: a quarter of their standard error.
+    # as two estimates of one expectation: a quarter of their standard error -- one standard error below 1,000 paths, where a
+    # single path that parts ways moves the mean by 1 / M of its spot (the round-6 soak of 12,000 cases: 64 paths, xi = 1.5,
+    # one path, every strike's price off by 0.58 = 0.3 standard errors; profiles/r06_fuzz_soak.txt).
     touches_zero = c["xi"] > 0.0 and (2.0 * c["kappa"] * c["theta"] < c["xi"] ** 2 or c["v0"] == 0.0)  # Feller's condition fails
-    tol = 1e-4 * np.abs(ref) + 1e-4 * c["S0"] * 0.5 + (0.25 * errs if touches_zero else 0.0)
+    tol = 1e-4 * np.abs(ref) + 1e-4 * c["S0"] * 0.5 + ((0.25 if M >= 1000 else 1.0) * errs if touches_zero else 0.0)
     assert np.all(np.abs(prices - ref) <= tol), float(np.abs(prices - ref).max())
     assert np.all(np.isfinite(errs)) and np.all(errs >= 0)
 

@@ -10,6 +10,10 @@ on the same rows with the same seeds; the parent compares parameters, Adam momen
 and prints the time per optimizer step.
 
 usage: exp_fused_step.py [rows] [batch] [epochs] [hidden] [layers] [dropout]     (defaults: config 1's 225,057 rows, 256, 4, 128, 3, 0.1)
+
+NOTE: both variants LOST (39 against 22.3 us per step, profiles/r06_fused_step_experiment.txt) and their kernels
+(mlp_train_q16_fused_kernel, the OMC_MLP_FUSED switch) were taken out of the product again: to re-run this script check out
+commit 38a8e3a, where they live.  On the current tree every variant runs the product's two launches.
 """
 import hashlib
 import json

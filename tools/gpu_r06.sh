@@ -88,7 +88,7 @@ calib)  # f-3 measured: the calibrator's objective evaluation, surface call vs p
   for d in "$R"/gpurun_out/pmc_${TAG}_calib_*; do [ -d "$d" ] && rm -rf "$d"; done
   true
   ;;
-dup)  # pass 1: where the chunk's last two (unused) prefetches point -- its last row (0) or the row being processed (1)
+dup)  # (needs commit 38a8e3a: the OMC_PASS1_DUP switch) pass 1: where the chunk's last two (unused) prefetches point -- its last row (0) or the row being processed (1)
   for REP in 1 2; do
     for CFG in c3 c2; do
       for DUP in 0 1; do
@@ -111,7 +111,7 @@ print('$CFG dup=$DUP rep $REP ms_per_step', round(d['ms_per_step'],4), 'pass1 ms
   for d in "$R"/gpurun_out/pmc_${TAG}_dup_c3_*; do [ -d "$d" ] && rm -rf "$d"; done
   true
   ;;
-fused)  # EXPERIMENT: the default call's optimizer step without its Adam launch (OMC_MLP_FUSED = 1 | 2) vs the product
+fused)  # EXPERIMENT (needs commit 38a8e3a, where the kernels live): the default call's optimizer step without its Adam launch (OMC_MLP_FUSED = 1 | 2) vs the product
   for CASE in "225057 256 4 128 3 0.1" "225057 256 4 64 2 0.1" "5000 256 8 128 3 0.1" "225057 1024 4 128 3 0.1" "225057 256 4 128 3 0.0"; do
     timeout -k 10 900 python tools/exp_fused_step.py $CASE 2>&1 | tee -a gpurun_out/${TAG}_fused_step_experiment.txt; rc=${PIPESTATUS[0]}
     ok $rc || exit 1
@@ -199,6 +199,35 @@ rowstest)  # the NN pass-1 kernels against the oracle (quirks, ragged sizes, con
 soak)  # the seeded fuzz sweeps against the C oracle, 30 (or $4) times as many cases from seeds shifted by $3 (one process, no -x: count every failure)
   OMC_FUZZ_SCALE=${4:-30} OMC_FUZZ_SEED=${3:-1000} timeout -k 10 1100 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -p no:cacheprovider > gpurun_out/${TAG}_fuzz_soak.log 2>&1; rc=$?
   grep -v "^[.s]*\( *\[ *[0-9]*%\]\)\?$" gpurun_out/${TAG}_fuzz_soak.log | tail -40; echo "pytest exit=$rc"
+  ;;
+fold)  # antithetic-folded storage: its tests against the folded oracle, then the headline both ways (timed region only)
+  timeout -k 10 600 python -m pytest tests/test_gpu_fold.py -q -m gpu --durations=5 > gpurun_out/${TAG}_fold_tests.log 2>&1; rc=$?
+  tail -30 gpurun_out/${TAG}_fold_tests.log; echo "pytest exit=$rc"; ok $rc || exit 1
+  [ $rc -eq 0 ] || exit 1
+  for ST in folded full; do
+    timeout -k 10 300 python bench.py --gpus 1 --steps 50 --warmup 20 --storage $ST --only-timed --no-cpu-baseline > gpurun_out/bench_${TAG}_$ST.json 2> gpurun_out/bench_${TAG}_$ST.err; rc=$?
+    echo "bench $ST exit=$rc"; ok $rc || exit 1
+    python3 - "$ST" "$TAG" <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/bench_{sys.argv[2]}_{sys.argv[1]}.json"))
+print(sys.argv[1], "value", d["value"], "ms", d["ms_per_step"], "price", d["price"])
+for k in d["roofline_kernels"]:
+    print("   ", k["kernel"], round(k["ms_per_launch"], 4), "ms", round(k["achieved"]), "GB/s", round(k["frac"], 3))
+print("    whole", d["roofline_whole_pricing"])
+PY
+  done
+  ;;
+foldtune)  # folded kernels: tiles per wave of pass 1 (OMC_FOLD_TPW) x columns per thread of pass 2 (OMC_FOLD_P2_VEC)
+  for CFG in c2 c3; do
+    for KNOB in "2 2 0" "1 2 0" "4 2 0" "2 4 0" "2 2 2" "2 2 1"; do
+      set -- $KNOB
+      OMC_FOLD_TPW=$1 OMC_FOLD_P2_VEC=$2 timeout -k 10 300 python bench.py --config $CFG --steps 30 --warmup 10 --only-timed --option gbm_vec=$3 > gpurun_out/${TAG}_ft_${CFG}_$1_$2.json 2> gpurun_out/${TAG}_ft_${CFG}_$1_$2.err; rc=$?
+      ok $rc || exit 1
+      python3 -c "
+import json; d=json.load(open('gpurun_out/${TAG}_ft_${CFG}_$1_$2.json')); k=d['roofline_kernels']
+print('$CFG tpw=$1 p2vec=$2 gbm_vec=$3 ms_per_step', round(d['ms_per_step'],4), ' '.join(x['kernel'].replace('lsm_','').replace('_kernel','')+' '+str(round(x['ms_per_launch'],4)) for x in k), 'price', d['price'])" | tee -a gpurun_out/${TAG}_fold_tune.txt
+    done
+  done
   ;;
 tests)
   timeout -k 10 1150 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_tests.log 2>&1; rc=$?
