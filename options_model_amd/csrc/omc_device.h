@@ -99,6 +99,25 @@ __device__ __forceinline__ void stage_block(const float* __restrict__ src, const
 }
 
 
+// ------------------------------------------------------------------ sums inside groups of 8 lanes
+// s + the value of lane ^ 1, ^ 2, ^ 4 in turn, as data-parallel-primitive moves in the vector pipe (quad permutes, then the
+// mirror of a half row: after the first two steps the four lanes of a quad agree, so lane 7 - i holds what lane i ^ 4
+// holds) -- the same operand pairs, hence the same bits, as three __shfl_xor, without their three LDS round trips.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sum_group8(double s)
+{
+    s += dpp_move<0xB1>(s);   // quad_perm [1,0,3,2]
+    s += dpp_move<0x4E>(s);   // quad_perm [2,3,0,1]
+    s += dpp_move<0x141>(s);  // row_half_mirror
+    return s;
+}
+
 // ------------------------------------------------------------------ block reduction
 // Sums acc[0..7] over the 256 threads of the block in a fixed order (bitwise
 // reproducible run to run).  `red` is LDS, kNQ*kRedStride doubles.  On return lanes of
@@ -117,9 +136,7 @@ __device__ __forceinline__ double block_reduce8(const double (&acc)[kNQ], double
         const double* p = red + q * kRedStride + sub;
 #pragma unroll 8
         for (int i = 0; i < 32; ++i) s += p[8 * i];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
+        s = sum_group8(s);
     }
     return s;
 }
@@ -128,7 +145,7 @@ __device__ __forceinline__ double block_reduce8(const double (&acc)[kNQ], double
 // Same job for ONE wave, no workgroup barrier: the 64 lanes transpose their 8 accumulators
 // through a wave-private LDS patch (DS instructions of a wave execute in order), each lane
 // then owns 1/8 of one quantity, and three xor-shuffles finish inside groups of 8 lanes.
-// ~8 ds_write_b64 + 8 ds_read_b64 + 3 shuffles instead of 48 shuffles.  Row stride 72 doubles
+// ~8 ds_write_b64 + 8 ds_read_b64 + 3 in-register exchanges (sum_group8) instead of 48 shuffles.  Row stride 72 doubles
 // puts the (q, sub) read pattern on distinct banks.  Every lane returns the total of quantity
 // lane >> 3.
 constexpr int kWaveRedStride = 72;
@@ -146,9 +163,7 @@ __device__ __forceinline__ double wave_reduce8(const double (&acc)[kNQ], double*
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += p[8 * i];
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
+    s = sum_group8(s);
     __builtin_amdgcn_wave_barrier();
     return s;
 }

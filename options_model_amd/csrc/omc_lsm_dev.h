@@ -685,12 +685,14 @@ __device__ __forceinline__ void lsm_pass1_fold_body(Pass1Args a)
                 const bool ia = IS_PUT ? sf < thrk[k] : sf > thrk[k];
                 // the partner: in the money <=> its payoff -K u' (put) / K u' (call) > 0; padding columns never are
                 const bool ib = valid[k] && (IS_PUT ? ub < 0.0 : ub > 0.0);
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ia)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(ib));
-                const double mp = (ia || ib) ? 1.0 : 0.0;
+                const bool any = ia || ib, both = ia && ib;  // rows of this spot: any + both
+                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(any));
+                const double mp = any ? 1.0 : 0.0;
                 add_row((ia ? ua : ub) * mp, ia ? pNA[k][v] : pNB[k][v], mp);
-                const bool both = ia && ib;
-                if (__builtin_amdgcn_ballot_w64(both) != 0) {
+                const unsigned long long bb = __builtin_amdgcn_ballot_w64(both);
+                if (bb != 0) {
                     asm volatile("; a lane with both partners in the money" ::);  // (keeps the branch: no if-conversion)
+                    cnt += __builtin_popcountll(bb);
                     const double ms = both ? 1.0 : 0.0;
                     add_row(ub * ms, pNB[k][v], ms);
                 }
@@ -991,17 +993,30 @@ __device__ __forceinline__ void lsm_pass2_fold_body(Pass2Args a)
         constexpr int U = 8;
         int t = N - 1;
         const float* col = a.S + j;
-        for (; t >= U && live(); t -= U) {
-            float st[U][VEC];
+        // U rows per batch, the NEXT batch requested before the current one is worked on (the decisions of a batch are a
+        // dependent chain of ~450 vector instructions: without the look-ahead every batch waited out a whole memory round
+        // trip with 4 waves per SIMD to cover it).  Rows below 1 are clamped to row 1 and not decided.
+        auto fetch = [&](float (&b)[U][VEC], int tt) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) loadf_stream<VEC>(col + (int64_t)(t - k) * a.ld, st[k]);
+            for (int k = 0; k < U; ++k) loadf_stream<VEC>(col + (int64_t)max(tt - k, 1) * a.ld, b[k]);
+        };
+        auto work = [&](const float (&b)[U][VEC], int tt) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) decide(st[k], t - k);
-        }
-        for (; t >= 1 && live(); --t) {
-            float st[VEC];
-            loadf_stream<VEC>(col + (int64_t)t * a.ld, st);
-            decide(st, t);
+            for (int k = 0; k < U; ++k)
+                if (tt - k >= 1) decide(b[k], tt - k);
+        };
+        float bA[U][VEC], bB[U][VEC];
+        if (t >= 1) fetch(bA, t);
+        while (t >= 1 && live()) {
+            if (t - U >= 1) fetch(bB, t - U);
+            __builtin_amdgcn_sched_barrier(0);
+            work(bA, t);
+            t -= U;
+            if (!(t >= 1 && live())) break;
+            if (t - U >= 1) fetch(bA, t - U);
+            __builtin_amdgcn_sched_barrier(0);
+            work(bB, t);
+            t -= U;
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
