@@ -712,6 +712,8 @@ def main():
             for k in kernels:
                 stem = k["kernel"].replace("gbm_", "").replace("heston_", "")
                 for name, v in pk.items():
+                    if "gbm_paths_kernel" in name and (", false>" in name) != folded:
+                        continue  # (the folded pricing's generator writes the first partners only: half the bytes)
                     if stem in name.replace("_ind_", "_") and same and \
                             v.get("pricings_per_launch", 1) == k.get("pricings_per_launch", 1):
                         k["traffic"] = v["read_bytes"] + v["write_bytes"]

@@ -351,7 +351,7 @@ static hipError_t lsm_pass1_moments_fold(hipStream_t st, const LsmProblem& p, co
     // steps 0.145-0.147 ms, 63 steps 0.156, 84 steps -- one resident round -- 0.162, 126 steps 0.183; 8M paths: 32).
     static const int tch_env = getenv("OMC_PASS1_TCHUNK") ? atoi(getenv("OMC_PASS1_TCHUNK")) : 0;
     const int64_t wgs_x = (a.ntiles + 3) / 4;
-    a.tchunk = (tch_env >= 2 && tch_env <= kPass1MaxChunk) ? tch_env : 32;
+    a.tchunk = (tch_env >= 2 && tch_env <= kFoldMaxChunk) ? tch_env : 32;
     const dim3 grid((unsigned)wgs_x, (unsigned)((p.N - 1 + a.tchunk - 1) / a.tchunk));
     if (w.ev_p1_begin) (void)hipEventRecord(w.ev_p1_begin, st);
     if (v4 && tpw == 1) {

@@ -606,6 +606,7 @@ __device__ __forceinline__ double fold_u(double cK_t, float s)
     return fma(cK_t, r, -1.0);
 }
 __device__ __forceinline__ double fold_pay(double u, double K, int is_put) { return is_put ? -K * u : K * u; }
+constexpr int kFoldMaxChunk = 64;  // steps per workgroup of the folded pass 1, at most
 
 // Pass 1 on the folded matrix: as lsm_pass1_body, every loaded spot contributing its own row and its partner's.
 // a.M = stored columns (pairs); TPW tiles of 64 * VEC columns = 2 * TPW * 64 * VEC paths per wave and step.
@@ -613,8 +614,8 @@ template <int VEC, int TPW, int PUT = -1>
 __device__ __forceinline__ void lsm_pass1_fold_body(Pass1Args a)
 {
     __shared__ double wl[kBlock / 64][kWaveRedDoubles];
-    __shared__ double shD[kBlock / 64][kPass1MaxChunk];
-    __shared__ double shC[kBlock / 64][kPass1MaxChunk];
+    __shared__ double shD[kBlock / 64][kFoldMaxChunk];  // (short tables: LDS must not cap the waves per SIMD)
+    __shared__ double shC[kBlock / 64][kFoldMaxChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tg = (int64_t)xcd_block((int)blockIdx.x, (int)gridDim.x) * (kBlock / 64) + wave;
     if (tg >= a.ntiles) return;  // whole wave leaves; no workgroup barrier below

@@ -20,6 +20,8 @@ for f in files:
         if name in out["kernels"] and out["kernels"][name].get("dispatches", 0) >= v.get("dispatches", 0):
             continue  # (the path generator appears in every flow: keep the sample with more dispatches)
         out["kernels"][name] = v
+    if j.get("storage") == "folded":
+        out["storage"] = "two-pass flow on antithetic-folded storage (kernel names *_fold_kernel, gbm_paths_kernel<., false>)"
     for key in ("paths_kernel_bytes_per_launch", "lsm_two_pass_bytes_per_pricing", "lsm_step_kernel_bytes_per_launch"):
         if j.get(key) and not out.get(key):
             out[key] = j[key]

@@ -20,8 +20,14 @@ SIZES = {"two_pass": (1_000_000, 252), "reference": (1_000_000, 252), "c3": (8_0
 
 def algo(kernel, M, N, K=16):
     """algorithmic bytes per launch."""
+    if "gbm_paths_kernel" in kernel and ", false>" in kernel:  # folded storage: first partners only (every config here is antithetic)
+        return 2.0 * (N + 1) * M, "4 (N+1) M/2 written (folded)"
     if "paths_kernel" in kernel:
         return 4.0 * (N + 1) * M, "4 (N+1) M written"
+    if "lsm_pass1_fold_kernel" in kernel:
+        return 2.0 * N * M, "4 N M/2 read (folded)"
+    if "lsm_pass2_fold_kernel" in kernel:
+        return 2.0 * N * M, "<= 4 N M/2 read (folded)"
     if "lsm_pass1_kernel" in kernel:
         return 4.0 * N * M, "4 N M read"
     if "lsm_pass2_kernel" in kernel:
@@ -74,6 +80,9 @@ for name, (M, N) in SIZES.items():
         if line:
             for k in line.get("roofline_kernels", []) + [line.get("roofline_per_step", {}).get("k16", {})]:
                 stem = (k.get("kernel") or "").replace("gbm_", "").replace("heston_", "")
+                folded_line = str((line.get("config") or {}).get("storage", "")).startswith("antithetic-folded")
+                if "gbm_paths_kernel" in short and folded_line != (", false>" in short):
+                    continue  # (the other storage's generator: launched by this command's per-step extra)
                 if stem and stem in short:
                     bf = f"{k.get('frac', 0):.3f}"
         tr = ""

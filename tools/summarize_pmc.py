@@ -53,9 +53,11 @@ def main():
                    if any(p in n for p in prefixes))
 
     out["paths_kernel_bytes_per_launch"] = tot(["gbm_paths_kernel", "heston_paths_kernel"]) or None
-    out["lsm_two_pass_bytes_per_pricing"] = tot(["lsm_pass1_kernel", "lsm_reduce_pass1_kernel",
-                                                 "lsm_solve_all_kernel", "lsm_pass2_kernel",
+    out["lsm_two_pass_bytes_per_pricing"] = tot(["lsm_pass1_kernel", "lsm_pass1_fold_kernel", "lsm_reduce_pass1_kernel",
+                                                 "lsm_solve_all_kernel", "lsm_pass2_kernel", "lsm_pass2_fold_kernel",
                                                  "lsm_finalize_kernel"]) or None
+    if any("_fold_kernel" in n for n in k):
+        out["storage"] = "folded"
     out["lsm_step_kernel_bytes_per_launch"] = tot(["lsm_step_ind_kernel", "lsm_step_kernel"]) or None
     json.dump(out, open(os.path.join(base, f"pmc_traffic_{tag}.json"), "w"), indent=1)
     print(json.dumps({a: b for a, b in out.items() if a != "kernels"}, indent=1))
