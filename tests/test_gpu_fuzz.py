@@ -122,6 +122,71 @@ def test_fused_pricing_matches_oracle(ctx, case):
         assert _smallest_margin(Sg, c["K"], c["r"], c["T"], c["is_put"], c["sem"]) <= 1e-10, (res, ref)
 
 
+def _fold_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append(dict(M=int(rng.choice([64, 254, 1000, 1026, 4096, 4100, 10_000, 33_334, 131_072, 200_002])),
+                        N=int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 33, 50, 70, 130])), is_put=bool(rng.integers(0, 2)),
+                        S0=float(rng.choice([60.0, 80.0, 100.0, 120.0, 150.0])), K=float(rng.choice([90.0, 100.0, 100.5, 110.0])),
+                        r=float(rng.choice([0.0, 0.03, 0.08])), sigma=float(rng.choice([0.05, 0.1, 0.2, 0.45, 0.9])),
+                        T=float(rng.choice([0.02, 0.1, 1.0, 2.5])), seed=int(rng.integers(1, 2 ** 31)),
+                        stream=int(rng.integers(0, 5)), off=int(rng.choice([0, 0, 12345, 2 ** 33 + 7])),
+                        seq=bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("case", _fold_cases(24 * _SCALE, 6464 + _SHIFT), ids=lambda c: f"{'put' if c['is_put'] else 'call'}-{c['M']}x{c['N']}-S{c['S0']:.0f}K{c['K']:.0f}")
+def test_folded_pricing_matches_its_oracle(ctx, case):
+    """Round 6: the fused two-pass pricing on antithetic-FOLDED storage (only the first partner of every pair stored, the
+    other priced from the same spot) against orc_lsm_two_pass_folded on the device's own half matrix, over random contracts
+    -- far in and out of the money (both partners in the money at once / never), drifts of either sign, one step, ragged
+    pair counts, pair offsets -- alone or as a member of a sequence between two other pricings."""
+    from options_model_amd import _ffi
+    c = case
+    kw = dict(semantics="two_pass", is_put=c["is_put"], S0=c["S0"], K=c["K"], r=c["r"], sigma=c["sigma"], T=c["T"], n_steps=c["N"],
+              seed=c["seed"], pair_offset=c["off"])
+    p = _ffi.make_params(n_paths=c["M"], stream=c["stream"], **kw)
+    ctx.set_option("fold_antithetic", 2)
+    try:
+        if c["seq"]:
+            other = dict(kw, K=c["K"] * 1.07, S0=c["S0"] * 0.97)
+            res = ctx.price_american_seq([_ffi.make_params(n_paths=c["M"], stream=9, **other), p,
+                                          _ffi.make_params(n_paths=c["M"], stream=8, **other)])[1]
+        else:
+            res = ctx.price_american(p)
+        half = ctx.gbm_paths(c["M"] // 2, c["N"], c["S0"], c["r"], c["sigma"], c["T"], c["seed"], c["stream"], c["off"], antithetic=False).to_host()
+    finally:
+        ctx.set_option("fold_antithetic", 1)
+    c0, g = orc.fold_constants(c["S0"], c["K"], c["r"], c["sigma"], c["T"], c["N"])
+    ref = orc.lsm_two_pass_folded(half, c["K"], c["r"], c["T"], c["is_put"], c0, g)
+    assert res["folded"] == 1 and res["n_paths"] == c["M"]
+    counts = (res["n_exercised"], res["n_zero"], res["sum_nitm"]) == (ref["n_exercised"], ref["n_zero"], ref["sum_nitm"])
+    close = abs(res["price"] - ref["price"]) <= 1e-9 * max(abs(ref["price"]), 1e-12) + 1e-15
+    if not (counts and close):
+        # The one situation in which two correct implementations may decide differently: a TIE between exercising and
+        # continuing (test_fused_pricing_matches_oracle).  Folded sweeps meet it in two forms: a fit on a handful of rows
+        # interpolates them; and a call at r = 0 deep in the money with next to no volatility -- the discounted terminal
+        # payoff regressed on the spot IS the immediate payoff (a martingale), so EVERY decision of the sweep is a tie to the
+        # last bits of the fit (the soak's case: S0 = 120, K = 100.5, sigma = 0.05, T = 0.02, 200,002 paths).  Accepted only
+        # with the evidence: the regression rows are the same, the smallest margin of the oracle's own decisions is below
+        # 1e-10 K, and the price -- both branches of a tie are worth the same -- agrees to 1e-6.
+        cK = orc.fold_table(c["N"], c0, g)
+        h = half.astype(np.float64)
+        margin = np.inf
+        for t in range(1, c["N"]):
+            if ref["nitm"][t] == 0:
+                continue
+            b = ref["betas"][t]
+            for u, imm in ((h[t] / c["K"] - 1.0, (c["K"] - h[t]) if c["is_put"] else (h[t] - c["K"])),
+                           (cK[t] / h[t] - 1.0, (-c["K"] if c["is_put"] else c["K"]) * (cK[t] / h[t] - 1.0))):
+                itm = imm > 0
+                if itm.any():
+                    margin = min(margin, float(np.abs(imm[itm] - (b[0] + b[1] * u[itm] + b[2] * u[itm] ** 2)).min()) / c["K"])
+        assert res["sum_nitm"] == ref["sum_nitm"] and margin <= 1e-10, (margin, res, ref)
+        assert abs(res["price"] - ref["price"]) <= 1e-6 * abs(ref["price"]), (res["price"], ref["price"])
+
+
 def _seq_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []

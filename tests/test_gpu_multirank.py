@@ -65,6 +65,10 @@ def test_ranks_sharing_one_gpu_equal_the_unsharded_pricing(ctx, standin, world, 
     lp = d["last_pricing"]
     assert (lp["n_paths"], lp["n_exercised"], lp["n_zero"], lp["sum_nitm"]) == (
         ref["n_paths"], ref["n_exercised"], ref["n_zero"], ref["sum_nitm"])
+    # the two-pass job runs on antithetic-folded storage (the rule looks at the JOB's 200k / 400k paths, not at a rank's share),
+    # the unsharded pricing it is compared with likewise; the per-step flows keep the full matrix
+    assert ref["folded"] == (1 if sem == "two_pass" else 0)
+    assert d["config"]["storage"].startswith("antithetic-folded" if sem == "two_pass" else "full")
     if sem == "two_pass":
         # before timing, every rank priced three streams overlapped (moment all-reduce on a second stream under the
         # next pricing's paths + pass 1) and one after the other, and all ranks saw the same bits
