@@ -72,6 +72,9 @@ CASES = [
     (2, 3, True, 100.0, 120.0, 0.2),                # one pair
     (4_096, 1, True, 100.0, 105.0, 0.2),            # one step: no regression at all
     (6_000, 2, False, 100.0, 90.0, 0.5),
+    (2_048, 4094, True, 100.0, 100.0, 0.2),         # the maximum step count (pass 2's table of fits fills the LDS)
+    (300_000, 40, False, 80.0, 100.0, 0.3),         # call far out of the money: the partner carries most rows
+    (300_000, 40, True, 80.0, 100.0, 0.3),          # put deep in the money: both partners in the money in most lanes
 ]
 
 
