@@ -721,6 +721,23 @@ def main():
                                               f"passes, {pj.get('round', 'r01')}; not measured in this run)"
         except Exception:
             pass
+    # what the SQ counters of the committed pass say about the vector pipe (the folded sweeps are bound by float64 issue,
+    # not by bytes: DESIGN.md section 6.3) -- quoted, like the traffic, from profiles/
+    sqf = os.path.join(ROOT, "profiles", f"pmc_sq_summary_r06_{a.config}.txt")
+    if os.path.exists(sqf) and a.paths_per_gpu in (None, CONFIGS[a.config]["paths_per_gpu"]):
+        try:
+            cur = None
+            for ln in open(sqf):
+                if ln and not ln.startswith(" ") and ":" in ln:
+                    cur = ln.split("<")[0].split(":")[0].strip()
+                elif "VALU issuing" in ln and cur:
+                    pct = float(ln.split("VALU issuing")[1].split("%")[0])
+                    for k in kernels:
+                        if k["kernel"] == cur or (cur.endswith("paths_kernel") and k["kernel"].endswith("paths_kernel")):
+                            k["valu_issue_frac"] = pct / 100.0
+                            k["valu_issue_source"] = f"profiles/{os.path.basename(sqf)} (rocprofv3 --pmc SQ passes; not measured in this run)"
+        except Exception:
+            pass
     dominant = max(kernels, key=lambda k: k["ms_per_launch"] * k["launches_per_pricing"])
     line["roofline"] = dominant
     line["roofline_pathgen"] = kernels[0]
