@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kBlock) void lsm_pass2_kernel(Pass2Args a) { lsm_pa
 // the two sweeps on the antithetic-folded matrix (omc_lsm_dev.h)
 template <int VEC, int TPW, int PUT>
 __global__ __launch_bounds__(kBlock) void lsm_pass1_fold_kernel(Pass1Args a) { lsm_pass1_fold_body<VEC, TPW, PUT>(a); }
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void lsm_pass2_fold_kernel(Pass2Args a) { lsm_pass2_fold_body<VEC>(a); }
+template <int VEC, int PUT>
+__global__ __launch_bounds__(kBlock) void lsm_pass2_fold_kernel(Pass2Args a) { lsm_pass2_fold_body<VEC, PUT>(a); }
 
 // cK[t] = c0 g^t, t = 0 .. N, by N sequential float64 multiplications (IEEE: the host oracle repeats them exactly)
 __global__ void lsm_fold_table_kernel(double* __restrict__ cK, int N, double c0, double g)
@@ -447,9 +447,14 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
         a.M = p.M / 2;
         a.cK = p.fold_cK;
         const bool f4 = (a.M % 4) == 0 && (p.ld % 4) == 0 && ((uintptr_t)p.S % 16) == 0;
-        if (f4 && fvec == 4) hipLaunchKernelGGL((lsm_pass2_fold_kernel<4>), dim3(nblk), dim3(kBlock), dyn, st, a);
-        else if (f4 && fvec == 2) hipLaunchKernelGGL((lsm_pass2_fold_kernel<2>), dim3(nblk), dim3(kBlock), dyn, st, a);
-        else hipLaunchKernelGGL((lsm_pass2_fold_kernel<1>), dim3(nblk), dim3(kBlock), dyn, st, a);
+        auto launch = [&](auto vec) {
+            constexpr int V = decltype(vec)::value;
+            if (p.is_put) hipLaunchKernelGGL((lsm_pass2_fold_kernel<V, 1>), dim3(nblk), dim3(kBlock), dyn, st, a);
+            else hipLaunchKernelGGL((lsm_pass2_fold_kernel<V, 0>), dim3(nblk), dim3(kBlock), dyn, st, a);
+        };
+        if (f4 && fvec == 4) launch(std::integral_constant<int, 4>{});
+        else if (f4 && fvec == 2) launch(std::integral_constant<int, 2>{});
+        else launch(std::integral_constant<int, 1>{});
     } else if (v4) {
         if (write_state) hipLaunchKernelGGL((lsm_pass2_kernel<4, true>), dim3(nblk), dim3(kBlock), dyn, st, a);
         else hipLaunchKernelGGL((lsm_pass2_kernel<4, false>), dim3(nblk), dim3(kBlock), dyn, st, a);

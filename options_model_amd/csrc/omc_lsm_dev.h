@@ -655,6 +655,9 @@ __device__ __forceinline__ void lsm_pass1_fold_body(Pass1Args a)
     float thrk[TPW];  // padding tiles: a threshold no price passes
 #pragma unroll
     for (int k = 0; k < TPW; ++k) thrk[k] = valid[k] ? thr : (is_put ? -__builtin_inff() : __builtin_inff());
+    unsigned long long vmask[TPW];  // lanes whose columns of tile k exist
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) vmask[k] = __builtin_amdgcn_ballot_w64(valid[k]);
     auto process = [&](auto put_tag, const float (&buf)[TPW][VEC], int t) {
         constexpr bool IS_PUT = decltype(put_tag)::value;
         double acc[8];
@@ -685,15 +688,20 @@ __device__ __forceinline__ void lsm_pass1_fold_body(Pass1Args a)
                 const double ub = fold_u(ck, sf);
                 const bool ia = IS_PUT ? sf < thrk[k] : sf > thrk[k];
                 // the partner: in the money <=> its payoff -K u' (put) / K u' (call) > 0; padding columns never are
-                const bool ib = valid[k] && (IS_PUT ? ub < 0.0 : ub > 0.0);
-                const bool any = ia || ib, both = ia && ib;  // rows of this spot: any + both
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(any));
-                const double mp = any ? 1.0 : 0.0;
+                const bool ibc = IS_PUT ? ub < 0.0 : ub > 0.0;
+                // (the wave's lane masks straight from the two compares and combined in scalar registers: a ballot of
+                //  `ia || ib` makes the compiler materialise the boolean in a vector register and compare it again)
+                const unsigned long long ma = __builtin_amdgcn_ballot_w64(ia);
+                const unsigned long long mb = __builtin_amdgcn_ballot_w64(ibc) & vmask[k];
+                const bool ib = valid[k] && ibc;
+                cnt += __builtin_popcountll(ma | mb);  // rows of this spot: any + both
+                const double mp = (ia || ib) ? 1.0 : 0.0;
                 add_row((ia ? ua : ub) * mp, ia ? pNA[k][v] : pNB[k][v], mp);
-                const unsigned long long bb = __builtin_amdgcn_ballot_w64(both);
+                const unsigned long long bb = ma & mb;
                 if (bb != 0) {
                     asm volatile("; a lane with both partners in the money" ::);  // (keeps the branch: no if-conversion)
                     cnt += __builtin_popcountll(bb);
+                    const bool both = ia && ib;
                     const double ms = both ? 1.0 : 0.0;
                     add_row(ub * ms, pNB[k][v], ms);
                 }
@@ -918,7 +926,7 @@ __device__ __forceinline__ void lsm_pass2_body(Pass2Args a)
 // every spot it loads; it stops when all 2 VEC paths have exercised.  A partner that exercises remembers the STORED
 // path's spot at that step (its own value is fold_pay(fold_u(cK[t], spot))): the valuation below recomputes it with the
 // very expressions of the decision.  The fits' table keeps cK[t] in its fourth slot.
-template <int VEC>
+template <int VEC, int PUT = -1>
 __device__ __forceinline__ void lsm_pass2_fold_body(Pass2Args a)
 {
     if ((int)blockIdx.x >= a.nblk) return;
@@ -952,7 +960,7 @@ __device__ __forceinline__ void lsm_pass2_fold_body(Pass2Args a)
     }
     __syncthreads();
     const double K = a.K, invK = a.invK;
-    const int is_put = a.is_put;
+    const int is_put = PUT < 0 ? a.is_put : PUT;  // (a compile-time side: the payoff is one subtraction, not two and a select)
     double acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.0;
