@@ -408,7 +408,7 @@ def main():
     ap.add_argument("--config3-steps", type=int, default=10, help="timed pricings of the config3 block (3 untimed first)")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the config3 block (default: every `--config c2 --semantics two_pass` line carries it)")
-    ap.add_argument("--kernel-samples", type=int, default=8,
+    ap.add_argument("--kernel-samples", type=int, default=4,
                     help="at least this many pricings of the timed region carry their own HIP events")
     a = ap.parse_args()
     if a.group is None:

@@ -51,12 +51,12 @@ sq)  # SQ counters of the three c2 kernels on the current library (VERDICT r5 it
   for d in "$R"/gpurun_out/pmc_${TAG}_sqc2_*; do [ -d "$d" ] && rm -rf "$d"; done
   true
   ;;
-tch)  # pass 1's reads by time-chunk length: every (tile, chunk) re-reads the terminal row and its last prefetches are clamped
+tch)  # (full storage: the step predates folded storage, whose pass 1 runs chunks of 32 steps) pass 1's reads by time-chunk length: every (tile, chunk) re-reads the terminal row and its last prefetches are clamped
       # duplicates -> exact request-size counters + timing at c3 and c2 for OMC_PASS1_TCHUNK = auto / 32 / 63 / 126 / 251
   for CFG in c3 c2; do
     for TCH in 0 32 63 126 251; do
       export OMC_PASS1_TCHUNK=$TCH
-      timeout -k 10 300 python bench.py --config $CFG --steps 12 --warmup 4 --only-timed > gpurun_out/${TAG}_tch_${CFG}_${TCH}.json 2> gpurun_out/${TAG}_tch_${CFG}_${TCH}.err; rc=$?
+      timeout -k 10 300 python bench.py --config $CFG --steps 12 --warmup 4 --only-timed --storage full > gpurun_out/${TAG}_tch_${CFG}_${TCH}.json 2> gpurun_out/${TAG}_tch_${CFG}_${TCH}.err; rc=$?
       ok $rc || exit 1
       python3 -c "
 import json; d=json.load(open('gpurun_out/${TAG}_tch_${CFG}_${TCH}.json')); k={x['kernel']:x for x in d['roofline_kernels']}
@@ -65,10 +65,10 @@ print('$CFG tchunk=$TCH ms_per_step', round(d['ms_per_step'],4), 'pass1 ms', rou
   done
   for TCH in 0 126 251; do
     export OMC_PASS1_TCHUNK=$TCH
-    pmc "tch_c3_${TCH}_a" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
-    pmc "tch_c3_${TCH}_b" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
-    pmc "tch_c3_${TCH}_c" "TCC_HIT_sum TCC_MISS_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
-    pmc "tch_c3_${TCH}_d" "FETCH_SIZE" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
+    pmc "tch_c3_${TCH}_a" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed --storage full || exit 1
+    pmc "tch_c3_${TCH}_b" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed --storage full || exit 1
+    pmc "tch_c3_${TCH}_c" "TCC_HIT_sum TCC_MISS_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed --storage full || exit 1
+    pmc "tch_c3_${TCH}_d" "FETCH_SIZE" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed --storage full || exit 1
   done
   unset OMC_PASS1_TCHUNK
   python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_tch_c3_" --by-dir | tee "$R/gpurun_out/${TAG}_pass1_reads_by_tchunk.txt"
@@ -103,8 +103,8 @@ print('$CFG dup=$DUP rep $REP ms_per_step', round(d['ms_per_step'],4), 'pass1 ms
   done
   for DUP in 0 1; do
     export OMC_PASS1_DUP=$DUP
-    pmc "dup_c3_${DUP}_a" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
-    pmc "dup_c3_${DUP}_b" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed || exit 1
+    pmc "dup_c3_${DUP}_a" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed --storage full || exit 1
+    pmc "dup_c3_${DUP}_b" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "$R/bench.py" --config c3 --steps 3 --warmup 1 --min-warmup-seconds 0.02 --only-timed --storage full || exit 1
   done
   unset OMC_PASS1_DUP
   python3 "$R/tools/summarize_sq.py" "$R/gpurun_out" "pmc_${TAG}_dup_c3_" --by-dir | grep -A3 "====\|pass1" | tee -a "$R/gpurun_out/${TAG}_pass1_dup.txt"
