@@ -7,6 +7,12 @@ Longstaff-Schwartz backward induction -> discounted mean.  Nothing is cached bet
 steps (each step uses a fresh Philox sub-stream); inputs are scalars, so there is no
 host->device data and `value` is the HBM-resident rate by construction.
 
+Storage of the paths (`--storage`, `config.storage` in the line): the library's default for antithetic GBM in the two-pass
+flow is FOLDED -- only the first partner of every antithetic pair is generated and stored ([step][path/2]), the partner is
+priced from the same spot (S_t S'_t = S0^2 exp(2 drift t); include/omc.h, option "fold_antithetic") -- so every kernel's
+algorithmic bytes are half those of the full matrix, and the line says so; `--storage full` runs the two-halves matrix of
+rounds 1-5 (and of Heston, which cannot fold).
+
 Workload (BASELINE.json configs[1], `--config c2`): GBM American put, S0=K=100, r=5%, sigma=20%,
 T=1, 1,000,000 paths x 252 steps per GPU, polynomial LSM.  `--config c3` is BASELINE configs[2]'s
 per-GPU shard (8,000,000 paths per GPU: 64M paths over 8 GPUs), `--config c4` configs[3] (Heston
