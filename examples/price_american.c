@@ -37,9 +37,9 @@ int main(int argc, char** argv)
         omc_ctx_destroy(ctx);
         return 1;
     }
-    printf("price %.6f  stderr %.6f  paths %lld  exercised %lld  kernels: paths %.3f ms, lsm %.3f ms\n", res.price,
+    printf("price %.6f  stderr %.6f  paths %lld  exercised %lld  kernels: paths %.3f ms, lsm %.3f ms  storage: %s\n", res.price,
            res.std / sqrt((double)(res.n_paths > 0 ? res.n_paths : 1)), (long long)res.n_paths,
-           (long long)res.n_exercised, res.ms_paths, res.ms_lsm);
+           (long long)res.n_exercised, res.ms_paths, res.ms_lsm, res.folded ? "antithetic-folded" : "full");
     omc_ctx_destroy(ctx);
     return 0;
 }
