@@ -226,6 +226,7 @@ def test_c_host_example_prices_config2(tmp_path, ctx):
     price = float(re.search(r"price ([0-9.]+)", out).group(1))
     ref = ctx.price_american(_ffi.make_params(semantics="two_pass", n_paths=200000, n_steps=50, seed=42))
     assert abs(price - ref["price"]) < 1e-6
+    assert "storage: antithetic-folded" in out and ref["folded"] == 1  # 200,000 paths: the library's default storage
 
 
 def test_sequence_of_pricings_equals_individual_calls(ctx):
