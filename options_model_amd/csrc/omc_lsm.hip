@@ -436,7 +436,9 @@ hipError_t lsm_pass2_apply(hipStream_t st, const LsmProblem& p, const LsmWorkspa
         a.betas_out = w.betas;
     }
     static const int fvec_env = getenv("OMC_FOLD_P2_VEC") ? atoi(getenv("OMC_FOLD_P2_VEC")) : 0;
-    const int fvec = (fvec_env == 1 || fvec_env == 4) ? fvec_env : 2;
+    // columns per thread of the folded pass 2: 2 (8-byte loads, twice the threads) until the 16-byte form alone fills the
+    // chip with workgroups (measured: C2's 0.5M columns 0.131 against 0.136 ms, C3's 4M columns 1.026 against 1.008)
+    const int fvec = (fvec_env == 1 || fvec_env == 2 || fvec_env == 4) ? fvec_env : ((p.M / 2) >= (int64_t(1) << 21) ? 4 : 2);
     const int nblk = lsm_step_blocks(p.fold_cK ? (p.M / 2) * (4 / fvec) : p.M);
     a.nblk = nblk; a.pstride = kPStride;
     const size_t dyn = sizeof(double) * 4 * (size_t)(p.N + 1);
