@@ -75,6 +75,7 @@ CASES = [
     (2_048, 4094, True, 100.0, 100.0, 0.2),         # the maximum step count (pass 2's table of fits fills the LDS)
     (300_000, 40, False, 80.0, 100.0, 0.3),         # call far out of the money: the partner carries most rows
     (300_000, 40, True, 80.0, 100.0, 0.3),          # put deep in the money: both partners in the money in most lanes
+    (4_194_312, 12, True, 100.0, 100.0, 0.25),      # 2,097,156 stored columns: pass 2 takes its 16-byte form from 2^21 on
 ]
 
 
