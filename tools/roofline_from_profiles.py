@@ -70,7 +70,7 @@ for name, (M, N) in SIZES.items():
     pj = pmc(cfg)
     for kname, (avg_ns, calls) in sorted(st.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         b, why = algo(kname, M, N)
-        if b is None:
+        if b is None or calls <= 2:  # (one or two launches: the line's price check on a 200k-path slice, not this workload)
             continue
         if "lsm_step_multi_kernel" in kname and name != "reference":
             continue  # (launched there by bench.py's per-step extra at other pricings-per-launch: see the `reference` rows)
