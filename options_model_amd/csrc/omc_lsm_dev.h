@@ -633,24 +633,34 @@ __device__ __forceinline__ void lsm_pass1_fold_body(Pass1Args a)
     double pNA[TPW][VEC], pNB[TPW][VEC];
     bool valid[TPW];
     const double cKN = a.cK[a.N];
+    float sn[TPW][VEC];
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         const int64_t j = base + (int64_t)k * 64 * VEC;
         valid[k] = j < a.M;
         colp[k] = a.S + (valid[k] ? j : 0);
-        float sn[VEC];
-        loadf<VEC>(colp[k] + (int64_t)a.N * a.ld, sn);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const double pa = payoff_d(sn[v], K, is_put), pb = fold_pay(fold_u(cKN, sn[v]), K, is_put);
-            pNA[k][v] = (valid[k] && pa > 0.0) ? pa : 0.0;
-            pNB[k][v] = (valid[k] && pb > 0.0) ? pb : 0.0;
-        }
+        loadf<VEC>(colp[k] + (int64_t)a.N * a.ld, sn[k]);
     }
     auto load_rows = [&](float (&buf)[TPW][VEC], int t) {
 #pragma unroll
         for (int k = 0; k < TPW; ++k) loadf_stream<VEC>(colp[k] + (int64_t)t * a.ld, buf[k]);
     };
+    // the chunk's first two rows are requested BEFORE the terminal row is worked on (a short chunk lives ~11 us: a second
+    // memory round trip in its prologue would be a fifth of that)
+    float bufA[TPW][VEC], bufB[TPW][VEC], bufC[TPW][VEC];
+    const int tl = t1 - 1;
+    load_rows(bufA, t0);
+    load_rows(bufB, min(t0 + 1, tl));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const double pa = payoff_d(sn[k][v], K, is_put), pb = fold_pay(fold_u(cKN, sn[k][v]), K, is_put);
+            pNA[k][v] = (valid[k] && pa > 0.0) ? pa : 0.0;
+            pNB[k][v] = (valid[k] && pb > 0.0) ? pb : 0.0;
+        }
+    }
     const float thr = itm_threshold(K, is_put);
     float thrk[TPW];  // padding tiles: a threshold no price passes
 #pragma unroll
@@ -715,11 +725,7 @@ __device__ __forceinline__ void lsm_pass1_fold_body(Pass1Args a)
         const double s = wave_reduce8(acc, wl[wave]);
         if ((lane & 7) == 0) a.part1[((size_t)t * a.ntiles + tg) * 8 + (lane >> 3)] = s;
     };
-    float bufA[TPW][VEC], bufB[TPW][VEC], bufC[TPW][VEC];
-    const int tl = t1 - 1;
     auto sweep = [&](auto put_tag) {
-        load_rows(bufA, t0);
-        load_rows(bufB, min(t0 + 1, tl));
         for (int t = t0; t < t1; t += 3) {
             load_rows(bufC, min(t + 2, tl));
             __builtin_amdgcn_sched_barrier(0);
